@@ -1,0 +1,43 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    z = np.load(os.path.join(GOLDEN_DIR, "encodec_golden.npz"))
+    meta = json.loads(bytes(z["meta_json"]).decode())
+    return z, meta
+
+
+_CKPT = {}
+
+
+@pytest.fixture(scope="session")
+def checkpoints():
+    """(cfg_name, seed) -> (cfg, HF-format synthetic state dict); cached for the session."""
+    from audiocodecs_amd import checkpoint
+    from audiocodecs_amd.config import ENCODEC_24KHZ, TINY
+
+    def get(cfg_name, seed):
+        key = (cfg_name, seed)
+        if key not in _CKPT:
+            cfg = {"full": ENCODEC_24KHZ, "tiny": TINY}[cfg_name]
+            _CKPT[key] = (cfg, checkpoint.synthetic_state_dict(cfg, seed=seed))
+        return _CKPT[key]
+
+    return get
