@@ -1,0 +1,104 @@
+"""ctypes binding of libaudiocodecs_amd.so (include/audiocodecs_amd.h).
+
+The shared library is the product; there is NO fallback: if it is missing, or no gfx950 device is
+visible, every compute entry point raises.  `import torch` must precede the load so that the HIP
+runtime torch already mapped (libamdhip64.so.7) is the one the library binds to.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (loads libamdhip64 first)
+
+__all__ = ["lib", "lib_path", "AcConfig", "AcKernelStat", "NativeError", "check", "EXPORTS"]
+
+AC_MAX_RATIOS = 8
+lib_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libaudiocodecs_amd.so")
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+class AcConfig(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_int32),
+        ("sampling_rate", C.c_int32),
+        ("num_filters", C.c_int32),
+        ("hidden_size", C.c_int32),
+        ("num_ratios", C.c_int32),
+        ("upsampling_ratios", C.c_int32 * AC_MAX_RATIOS),
+        ("kernel_size", C.c_int32),
+        ("last_kernel_size", C.c_int32),
+        ("residual_kernel_size", C.c_int32),
+        ("compress", C.c_int32),
+        ("num_lstm_layers", C.c_int32),
+        ("codebook_size", C.c_int32),
+        ("num_quantizers", C.c_int32),
+        ("device", C.c_int32),
+    ]
+
+
+class AcKernelStat(C.Structure):
+    _fields_ = [
+        ("name", C.c_char * 48),
+        ("launches", C.c_int32),
+        ("total_ms", C.c_float),
+        ("flops", C.c_double),
+        ("bytes", C.c_double),
+    ]
+
+
+_vp, _i, _sz = C.c_void_p, C.c_int, C.c_size_t
+# name -> (restype, argtypes): every symbol include/audiocodecs_amd.h declares
+EXPORTS = {
+    "ac_version": (_i, []),
+    "ac_create": (_i, [C.POINTER(AcConfig), C.POINTER(_vp)]),
+    "ac_load_weights": (_i, [_vp, C.c_char_p, _vp, _sz]),
+    "ac_finalize": (_i, [_vp]),
+    "ac_num_frames": (_i, [_vp, _i]),
+    "ac_hop_length": (_i, [_vp]),
+    "ac_hidden_size": (_i, [_vp]),
+    "ac_encode_workspace_bytes": (_sz, [_vp, _i, _i]),
+    "ac_decode_workspace_bytes": (_sz, [_vp, _i, _i]),
+    "ac_encode": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "ac_encode_feats": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
+    "ac_decode": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "ac_quantize": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    "ac_dequantize": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    "ac_embs": (_i, [_vp, _i, _vp, _vp]),
+    "ac_profile_begin": (_i, [_vp]),
+    "ac_profile_end": (_i, [_vp, C.POINTER(AcKernelStat), _i]),
+    "ac_debug_capture": (_i, [_vp, _vp, _sz]),
+    "ac_debug_captured": (_sz, [_vp]),
+    "ac_last_error": (C.c_char_p, [_vp]),
+    "ac_destroy": (None, [_vp]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the library; raises NativeError when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(lib_path):
+            raise NativeError(
+                f"{lib_path} not found: build the HIP extension first "
+                "(python -c 'import __graft_entry__ as g; g.build()' or audiocodecs_amd/csrc/build.sh)"
+            )
+        L = C.CDLL(lib_path)
+        for name, (res, args) in EXPORTS.items():
+            fn = getattr(L, name)  # AttributeError if the .so lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc: int, handle=None, what: str = "") -> None:
+    if rc < 0:
+        msg = lib().ac_last_error(handle).decode() if handle else ""
+        raise NativeError(f"{what} failed with code {rc}: {msg}")

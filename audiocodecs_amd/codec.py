@@ -1,0 +1,145 @@
+"""Codec interface -- host-side mirror of the reference's `audiocodecs.Codec`
+(/root/reference/audiocodecs/codec.py:33-214): same constructor, public methods, argument
+meaning (relative `length`, [B,T] signals, [B,N,K] tokens) and error behaviour, so callers such as
+downstream/test_sr.py:57,83 run unchanged.  Written from the interface, not copied.
+"""
+
+from __future__ import annotations
+
+from abc import ABC, abstractmethod
+
+import torch
+
+from .resample import resample as _resample
+
+__all__ = ["Codec"]
+
+
+class Codec(torch.nn.Module, ABC):
+    _MODES = ["encode", "decode", "reconstruct"]
+
+    def __init__(self, sample_rate, orig_sample_rate, mode="reconstruct"):
+        super().__init__()
+        if mode not in self._MODES:
+            raise ValueError(f"`mode` ({mode}) must be one of {self._MODES}")  # codec.py:38-39
+        self.sample_rate = sample_rate
+        self.orig_sample_rate = orig_sample_rate
+        self.mode = mode
+        self._logits = None
+
+    # codec.py:45-55
+    def forward(self, input, length=None):
+        if self.mode == "encode":
+            return self.sig_to_toks(input, length)
+        if self.mode == "decode":
+            return self.toks_to_sig(input, length)
+        toks = self.sig_to_toks(input, length)
+        return self.toks_to_sig(toks, length)
+
+    def _in(self, sig):
+        return _resample(sig, self.sample_rate, self.orig_sample_rate)
+
+    def _out(self, sig):
+        return _resample(sig, self.orig_sample_rate, self.sample_rate)
+
+    _accepts_none_length = False  # subclasses that can skip the all-ones mask set this
+
+    def _ones(self, x):
+        # codec.py:64-65: length defaults to ones(B) -- the "no padding" case
+        return None if self._accepts_none_length else torch.ones(len(x), device=x.device)
+
+    def sig_to_toks(self, sig, length=None):  # codec.py:57-66
+        sig = self._in(sig)
+        return self._sig_to_toks(sig, self._ones(sig) if length is None else length)
+
+    def sig_to_feats(self, sig, length=None):  # codec.py:68-77
+        sig = self._in(sig)
+        return self._sig_to_feats(sig, self._ones(sig) if length is None else length)
+
+    def sig_to_qfeats(self, sig, length=None):  # codec.py:79-88
+        sig = self._in(sig)
+        return self._sig_to_qfeats(sig, self._ones(sig) if length is None else length)
+
+    def toks_to_sig(self, toks, length=None):  # codec.py:90-100
+        sig = self._toks_to_sig(toks, self._ones(toks) if length is None else length)
+        return self._out(sig)
+
+    def toks_to_qfeats(self, toks, length=None):  # codec.py:102-107
+        return self._toks_to_qfeats(toks, self._ones(toks) if length is None else length)
+
+    def feats_to_sig(self, feats, length=None):  # codec.py:109-119
+        sig = self._feats_to_sig(feats, self._ones(feats) if length is None else length)
+        return self._out(sig)
+
+    # ---- token-resampling utilities (codec.py:121-180; no caller in the reference tree) --------
+    def resample(self, toks, p=0.2, temp=1.0, top_k=None, top_p=None):
+        if p <= 0.0:
+            return toks
+        out = toks.clone()
+        K = toks.shape[-1]
+        flat = toks.flatten(end_dim=-2).T  # [K, BN]
+        logits = self.logits()  # [K, C, C]
+        vocab = logits.shape[-1]
+        sel = logits.gather(1, flat[..., None].expand(-1, -1, vocab)).flatten(end_dim=-2)  # [K*BN, C]
+        probs = (sel / temp).softmax(dim=-1)
+        if top_k is None and top_p is None:
+            samples = probs.multinomial(num_samples=1)
+        elif top_k is not None and top_p is None:
+            samples = self._sample_top_k(probs, top_k)
+        elif top_k is None and top_p is not None:
+            samples = self._sample_top_p(probs, top_p)
+        else:
+            raise NotImplementedError
+        samples = samples.reshape(K, -1).T.reshape_as(out)
+        mask = torch.rand(out.shape, device=out.device) < p
+        out[mask] = samples[mask]
+        return out
+
+    @torch.no_grad()
+    def logits(self):
+        if self._logits is None:
+            embs = self.embs()  # [K, C, H]
+            logits = -torch.cdist(embs, embs)
+            eye = torch.eye(logits.shape[-1], device=logits.device).bool().expand(len(logits), -1, -1)
+            logits[eye] = -float("inf")
+            self._logits = logits
+        return self._logits.clone()
+
+    def _sample_top_k(self, probs, k):
+        probs, idx = probs.topk(k, dim=-1)
+        probs = probs / probs.sum(dim=-1, keepdim=True)
+        return idx.gather(-1, probs.multinomial(num_samples=1))[:, 0]
+
+    def _sample_top_p(self, probs, p):
+        probs, idx = probs.sort(dim=-1, descending=True)
+        csum = probs.cumsum(dim=-1)
+        probs = probs.masked_fill(csum - probs > p, 0.0)
+        probs = probs / probs.sum(dim=-1, keepdim=True)
+        return idx.gather(-1, torch.multinomial(probs, num_samples=1))[:, 0]
+
+    # ---- subclass obligations (codec.py:182-214) ------------------------------------------------
+    @abstractmethod
+    def embs(self):
+        raise NotImplementedError
+
+    @abstractmethod
+    def _sig_to_toks(self, sig, length):
+        raise NotImplementedError
+
+    @abstractmethod
+    def _sig_to_feats(self, sig, length):
+        raise NotImplementedError
+
+    @abstractmethod
+    def _sig_to_qfeats(self, sig, length):
+        raise NotImplementedError
+
+    @abstractmethod
+    def _toks_to_sig(self, toks, length):
+        raise NotImplementedError
+
+    def _toks_to_qfeats(self, toks, length):
+        raise NotImplementedError
+
+    def _feats_to_sig(self, feats, length):
+        raise NotImplementedError

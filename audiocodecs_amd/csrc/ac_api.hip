@@ -1,0 +1,957 @@
+// C ABI of the MI355X EnCodec path (include/audiocodecs_amd.h): model plan, weight packing,
+// workspace layout and the launch sequences of encode / decode.  gfx950 only.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/audiocodecs_amd.h"
+#include "lstm.h"
+#include "rvq.h"
+#include "tap_gemm.h"
+
+using namespace ac;
+
+namespace {
+
+struct ConvSpec {
+    std::string prefix;
+    int transposed, cin, cout, k, s;
+};
+
+struct PackedGemm {      // one tap_gemm launch worth of weights
+    size_t w_off = 0, b_off = 0;  // float offsets into the device blob
+    int N = 0, Ktot = 0;
+};
+
+struct ResBlockPlan {
+    int C;
+    PackedGemm c3;     // k3 conv C -> C/2
+    PackedGemm fused;  // [ELU(h) | x] * [W1; Ws] + (b1 + bs)
+};
+
+struct LstmPlan {
+    int D, layers;
+    std::vector<PackedGemm> ih;     // [4D][D] + (b_ih + b_hh)
+    std::vector<size_t> hh_off;     // packed W_hh per layer
+};
+
+struct ProfRec {
+    int name_id;
+    int count;
+    hipEvent_t e0, e1;
+    double flops, bytes;
+};
+
+}  // namespace
+
+struct ac_handle {
+    ac_config cfg{};
+    std::string err;
+    std::map<std::string, std::vector<float>> host;
+    bool finalized = false;
+    float* blob = nullptr;
+    size_t blob_floats = 0;
+    int hop = 1, D = 0;
+    // encoder plan
+    PackedGemm enc_stem, enc_final;
+    std::vector<ResBlockPlan> enc_rb;
+    std::vector<PackedGemm> enc_down;
+    LstmPlan enc_lstm, dec_lstm;
+    // decoder plan
+    PackedGemm dec_first, dec_head;
+    std::vector<PackedGemm> dec_up;
+    std::vector<ResBlockPlan> dec_rb;
+    // codebooks
+    size_t cb_plain = 0, cb_packed = 0, cb_ee = 0;
+    // test hook: copy every layer output (standard [B][L][C] layout) into a caller buffer
+    float* dbg = nullptr;
+    size_t dbg_cap = 0, dbg_used = 0;
+    // profiling
+    bool prof = false;
+    std::vector<ProfRec> recs;
+    std::vector<std::string> prof_names;
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
+};
+
+namespace {
+
+int fail(ac_handle* h, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (h) h->err = buf;
+    return code;
+}
+
+#define HIPCHK(h, call)                                                                         \
+    do {                                                                                        \
+        hipError_t e_ = (call);                                                                 \
+        if (e_ != hipSuccess) return fail(h, AC_EHIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ---------------------------------------------------------------------------------------------
+// architecture enumeration (HF module order)
+// ---------------------------------------------------------------------------------------------
+struct Arch {
+    std::vector<ConvSpec> enc_rb3, enc_rb1, enc_rbs, enc_down;  // per stage
+    ConvSpec enc_stem, enc_final, dec_first, dec_head;
+    std::vector<ConvSpec> dec_up, dec_rb3, dec_rb1, dec_rbs;
+    std::string enc_lstm, dec_lstm;
+    int D;
+};
+
+Arch make_arch(const ac_config& c) {
+    Arch a;
+    const int F = c.num_filters, H = c.hidden_size, n = c.num_ratios;
+    auto P = [](const char* part, int i, const char* rest) {
+        return std::string(part) + ".layers." + std::to_string(i) + rest;
+    };
+    a.enc_stem = {P("encoder", 0, ".conv"), 0, 1, F, c.kernel_size, 1};
+    int i = 1, ch = F;
+    for (int r = n - 1; r >= 0; --r) {
+        const int ratio = c.upsampling_ratios[r];
+        const int hid = ch / c.compress;
+        a.enc_rb3.push_back({P("encoder", i, ".block.1.conv"), 0, ch, hid, c.residual_kernel_size, 1});
+        a.enc_rb1.push_back({P("encoder", i, ".block.3.conv"), 0, hid, ch, 1, 1});
+        a.enc_rbs.push_back({P("encoder", i, ".shortcut.conv"), 0, ch, ch, 1, 1});
+        a.enc_down.push_back({P("encoder", i + 2, ".conv"), 0, ch, 2 * ch, 2 * ratio, ratio});
+        i += 3;
+        ch *= 2;
+    }
+    a.D = ch;
+    a.enc_lstm = P("encoder", i, ".lstm");
+    a.enc_final = {P("encoder", i + 2, ".conv"), 0, ch, H, c.last_kernel_size, 1};
+    a.dec_first = {P("decoder", 0, ".conv"), 0, H, ch, c.kernel_size, 1};
+    a.dec_lstm = P("decoder", 1, ".lstm");
+    i = 2;
+    for (int r = 0; r < n; ++r) {
+        const int ratio = c.upsampling_ratios[r];
+        a.dec_up.push_back({P("decoder", i + 1, ".conv"), 1, ch, ch / 2, 2 * ratio, ratio});
+        const int c2 = ch / 2, hid = c2 / c.compress;
+        a.dec_rb3.push_back({P("decoder", i + 2, ".block.1.conv"), 0, c2, hid, c.residual_kernel_size, 1});
+        a.dec_rb1.push_back({P("decoder", i + 2, ".block.3.conv"), 0, hid, c2, 1, 1});
+        a.dec_rbs.push_back({P("decoder", i + 2, ".shortcut.conv"), 0, c2, c2, 1, 1});
+        i += 3;
+        ch = c2;
+    }
+    a.dec_head = {P("decoder", i + 1, ".conv"), 0, ch, 1, c.last_kernel_size, 1};
+    return a;
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight access + packing
+// ---------------------------------------------------------------------------------------------
+struct Packer {
+    ac_handle* h;
+    std::vector<float> blob;
+    int rc = AC_OK;
+
+    const std::vector<float>* get(const std::string& name, size_t n) {
+        auto it = h->host.find(name);
+        if (it == h->host.end()) {
+            rc = fail(h, AC_ESTATE, "missing tensor '%s'", name.c_str());
+            return nullptr;
+        }
+        if (it->second.size() != n) {
+            rc = fail(h, AC_EINVAL, "tensor '%s' has %zu elements, expected %zu", name.c_str(), it->second.size(), n);
+            return nullptr;
+        }
+        return &it->second;
+    }
+    // conv weight in HF layout ([cout][cin][k], or [cin][cout][k] when transposed), folding
+    // weight-norm when only (g, v) were given: w = v * (g / ||v||_2), norm over dims (1,2).
+    bool weight(const ConvSpec& s, std::vector<float>& w) {
+        const size_t n = (size_t)s.cin * s.cout * s.k;
+        auto it = h->host.find(s.prefix + ".weight");
+        if (it != h->host.end()) {
+            if (it->second.size() != n) {
+                rc = fail(h, AC_EINVAL, "tensor '%s.weight' has %zu elements, expected %zu", s.prefix.c_str(), it->second.size(), n);
+                return false;
+            }
+            w = it->second;
+            return true;
+        }
+        const int d0 = s.transposed ? s.cin : s.cout;
+        const std::vector<float>* g = get(s.prefix + ".parametrizations.weight.original0", d0);
+        if (!g) return false;
+        const std::vector<float>* v = get(s.prefix + ".parametrizations.weight.original1", n);
+        if (!v) return false;
+        w.resize(n);
+        const size_t inner = n / d0;
+        for (int i = 0; i < d0; ++i) {
+            double ss = 0.0;
+            for (size_t j = 0; j < inner; ++j) ss += (double)(*v)[i * inner + j] * (*v)[i * inner + j];
+            const float scale = (*g)[i] / (float)std::sqrt(ss);
+            for (size_t j = 0; j < inner; ++j) w[i * inner + j] = (*v)[i * inner + j] * scale;
+        }
+        return true;
+    }
+    size_t reserve(size_t n) {
+        const size_t off = align_up(blob.size(), 64);
+        blob.resize(off + n, 0.f);
+        return off;
+    }
+    // plain conv (stride 1 or k = 2*stride): packed[n][tap*cin + ci] = w[n][ci][tap]
+    bool conv(const ConvSpec& s, PackedGemm& g) {
+        std::vector<float> w;
+        if (!weight(s, w)) return false;
+        const std::vector<float>* b = get(s.prefix + ".bias", s.cout);
+        if (!b) return false;
+        g.N = s.cout;
+        g.Ktot = s.k * s.cin;
+        g.w_off = reserve((size_t)g.N * g.Ktot);
+        for (int n = 0; n < s.cout; ++n)
+            for (int ci = 0; ci < s.cin; ++ci)
+                for (int t = 0; t < s.k; ++t)
+                    blob[g.w_off + (size_t)n * g.Ktot + (size_t)t * s.cin + ci] = w[((size_t)n * s.cin + ci) * s.k + t];
+        g.b_off = reserve(g.N);
+        std::copy(b->begin(), b->end(), blob.begin() + g.b_off);
+        return true;
+    }
+    // transposed conv, k = 2*s: out row m = [x[m-1] | x[m]] * Wp,  n = p*cout + co,
+    // Wp[n][j*cin + ci] = w[ci][co][p + (1-j)*s]
+    bool convtr(const ConvSpec& s, PackedGemm& g) {
+        std::vector<float> w;
+        if (!weight(s, w)) return false;
+        const std::vector<float>* b = get(s.prefix + ".bias", s.cout);
+        if (!b) return false;
+        g.N = s.s * s.cout;
+        g.Ktot = 2 * s.cin;
+        g.w_off = reserve((size_t)g.N * g.Ktot);
+        for (int p = 0; p < s.s; ++p)
+            for (int co = 0; co < s.cout; ++co)
+                for (int j = 0; j < 2; ++j)
+                    for (int ci = 0; ci < s.cin; ++ci)
+                        blob[g.w_off + (size_t)(p * s.cout + co) * g.Ktot + (size_t)j * s.cin + ci] =
+                            w[((size_t)ci * s.cout + co) * s.k + p + (1 - j) * s.s];
+        g.b_off = reserve(g.N);
+        for (int p = 0; p < s.s; ++p)
+            for (int co = 0; co < s.cout; ++co) blob[g.b_off + (size_t)p * s.cout + co] = (*b)[co];
+        return true;
+    }
+    bool resblock(const ConvSpec& c3, const ConvSpec& c1, const ConvSpec& sc, ResBlockPlan& rb) {
+        rb.C = c3.cin;
+        if (!conv(c3, rb.c3)) return false;
+        std::vector<float> w1, ws;
+        if (!weight(c1, w1) || !weight(sc, ws)) return false;
+        const std::vector<float>* b1 = get(c1.prefix + ".bias", c1.cout);
+        const std::vector<float>* bs = get(sc.prefix + ".bias", sc.cout);
+        if (!b1 || !bs) return false;
+        const int C = rb.C, hid = c1.cin;
+        rb.fused.N = C;
+        rb.fused.Ktot = hid + C;
+        rb.fused.w_off = reserve((size_t)C * (hid + C));
+        for (int n = 0; n < C; ++n) {
+            for (int ci = 0; ci < hid; ++ci) blob[rb.fused.w_off + (size_t)n * (hid + C) + ci] = w1[(size_t)n * hid + ci];
+            for (int ci = 0; ci < C; ++ci) blob[rb.fused.w_off + (size_t)n * (hid + C) + hid + ci] = ws[(size_t)n * C + ci];
+        }
+        rb.fused.b_off = reserve(C);
+        for (int n = 0; n < C; ++n) blob[rb.fused.b_off + n] = (*b1)[n] + (*bs)[n];
+        return true;
+    }
+    bool lstm(const std::string& prefix, int D, int layers, LstmPlan& lp) {
+        lp.D = D;
+        lp.layers = layers;
+        for (int l = 0; l < layers; ++l) {
+            const std::string sfx = "_l" + std::to_string(l);
+            const std::vector<float>* wih = get(prefix + ".weight_ih" + sfx, (size_t)4 * D * D);
+            const std::vector<float>* whh = get(prefix + ".weight_hh" + sfx, (size_t)4 * D * D);
+            const std::vector<float>* bih = get(prefix + ".bias_ih" + sfx, (size_t)4 * D);
+            const std::vector<float>* bhh = get(prefix + ".bias_hh" + sfx, (size_t)4 * D);
+            if (!wih || !whh || !bih || !bhh) return false;
+            PackedGemm g;
+            g.N = 4 * D;
+            g.Ktot = D;
+            g.w_off = reserve((size_t)4 * D * D);
+            std::copy(wih->begin(), wih->end(), blob.begin() + g.w_off);
+            g.b_off = reserve((size_t)4 * D);
+            for (int n = 0; n < 4 * D; ++n) blob[g.b_off + n] = (*bih)[n] + (*bhh)[n];
+            lp.ih.push_back(g);
+            // W_hh in MFMA B-fragment order: [ug][kstep][lane][u] = Whh[(lane&15 >> 2)*D + ug*4 + (lane&3)][kstep*16 + 4*(lane>>4) + u]
+            const size_t off = reserve((size_t)4 * D * D);
+            for (int ug = 0; ug < D / 4; ++ug)
+                for (int ks = 0; ks < D / 16; ++ks)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int u = 0; u < 4; ++u) {
+                            const int j = lane & 15, kq = lane >> 4;
+                            const int row = (j >> 2) * D + ug * 4 + (j & 3);
+                            const int k = ks * 16 + 4 * kq + u;
+                            blob[off + (((size_t)ug * (D / 16) + ks) * 64 + lane) * 4 + u] = (*whh)[(size_t)row * D + k];
+                        }
+            lp.hh_off.push_back(off);
+        }
+        return true;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// launches
+// ---------------------------------------------------------------------------------------------
+struct Act {          // a channels-last activation view
+    const float* p;
+    long long bs, ts;
+    int L, C;
+};
+
+int prof_name(ac_handle* h, const char* nm) {
+    for (size_t i = 0; i < h->prof_names.size(); ++i)
+        if (h->prof_names[i] == nm) return (int)i;
+    h->prof_names.push_back(nm);
+    return (int)h->prof_names.size() - 1;
+}
+
+hipEvent_t next_event(ac_handle* h) {
+    if (h->ev_used == h->ev_pool.size()) {
+        hipEvent_t e;
+        (void)hipEventCreate(&e);
+        h->ev_pool.push_back(e);
+    }
+    return h->ev_pool[h->ev_used++];
+}
+
+struct ProfScope {
+    ac_handle* h;
+    hipStream_t st;
+    ProfRec r{};
+    bool on;
+    ProfScope(ac_handle* h_, hipStream_t st_, const char* nm, double flops, double bytes, int count = 1)
+        : h(h_), st(st_), on(h_->prof) {
+        if (!on) return;
+        r.name_id = prof_name(h, nm);
+        r.count = count;
+        r.flops = flops;
+        r.bytes = bytes;
+        r.e0 = next_event(h);
+        r.e1 = next_event(h);
+        (void)hipEventRecord(r.e0, st);
+    }
+    ~ProfScope() {
+        if (!on) return;
+        (void)hipEventRecord(r.e1, st);
+        h->recs.push_back(r);
+    }
+};
+
+template <int WGM, int WGN, int WM, int WN, bool VEC>
+void launch_tap(const TapGemmParams& p0, hipStream_t st) {
+    TapGemmParams p = p0;
+    constexpr int BM = WGM * WM * 16, BN = WGN * WN * 16;
+    p.mtiles = cdiv(p.M, BM);
+    p.ntiles = cdiv(p.N, BN);
+    const size_t lds = tap_gemm_lds_bytes<WGM, WGN, WM, WN>();
+    const long long blocks = (long long)p.B * p.mtiles * p.ntiles;
+    hipLaunchKernelGGL((tap_gemm_kernel<WGM, WGN, WM, WN, VEC>), dim3((unsigned)blocks), dim3(WGM * WGN * 64), lds, st, p);
+}
+
+// One segment of the A operand for a conv reading `x` (time steps of C channels).
+TapSeg make_seg(const Act& x, int s, int J, bool reflect, bool elu, int extra, int kofs, const float* rel_len) {
+    TapSeg g{};
+    g.x = x.p;
+    g.bs = x.bs;
+    g.ts = x.ts;
+    g.rel_len = rel_len;
+    g.L = x.L;
+    g.cin = x.C;
+    g.cin_shift = -1;
+    for (int sh = 0; sh < 30; ++sh)
+        if ((1 << sh) == x.C) g.cin_shift = sh;
+    g.s = s;
+    g.J = J;
+    const int pad_left = (J - 1) * s;
+    const int max_pad = std::max(pad_left, extra);
+    g.Lp = (reflect && x.L <= max_pad) ? max_pad + 1 : x.L;
+    g.lim = reflect ? x.L + extra : x.L;
+    g.reflect = reflect ? 1 : 0;
+    g.elu = elu ? 1 : 0;
+    g.kofs = kofs;
+    return g;
+}
+
+int run_tap(ac_handle* h, hipStream_t st, TapGemmParams& p) {
+    bool vec = (p.Ktot % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.w) & 15) == 0);
+    for (int i = 0; i < p.nseg; ++i) {
+        const TapSeg& s = p.seg[i];
+        vec = vec && (s.cin % 4 == 0) && (s.ts % 4 == 0) && (s.bs % 4 == 0) && (s.kofs % 4 == 0) &&
+              ((reinterpret_cast<uintptr_t>(s.x) & 15) == 0);
+        if (s.J > 8) return fail(h, AC_EINVAL, "conv with %d taps exceeds the kernel limit of 8", s.J);
+    }
+    double kk = 0, inb = 0;
+    for (int i = 0; i < p.nseg; ++i) {
+        kk += (double)p.seg[i].J * p.seg[i].s * p.seg[i].cin;
+        inb += (double)p.B * p.seg[i].L * p.seg[i].cin * 4.0;
+    }
+    const double flops = 2.0 * p.B * (double)p.M * p.N * kk;
+    const double bytes = inb + (double)p.B * p.M * p.N * 4.0 + (double)p.N * p.Ktot * 4.0;
+    const char* nm;
+#define TAP_CASE(WGM, WGN, WM, WN)                                                                          \
+    do {                                                                                                    \
+        if (vec) {                                                                                          \
+            nm = "tap_gemm_kernel<" #WGM ", " #WGN ", " #WM ", " #WN ", true>";                             \
+            ProfScope ps(h, st, nm, flops, bytes);                                                          \
+            launch_tap<WGM, WGN, WM, WN, true>(p, st);                                                      \
+        } else {                                                                                            \
+            nm = "tap_gemm_kernel<" #WGM ", " #WGN ", " #WM ", " #WN ", false>";                            \
+            ProfScope ps(h, st, nm, flops, bytes);                                                          \
+            launch_tap<WGM, WGN, WM, WN, false>(p, st);                                                     \
+        }                                                                                                   \
+    } while (0)
+    if (p.N <= 16) TAP_CASE(4, 1, 2, 1);
+    else if (p.N <= 32) TAP_CASE(4, 1, 2, 2);
+    else if (p.N <= 64) TAP_CASE(2, 2, 2, 2);
+    else TAP_CASE(2, 2, 4, 4);
+#undef TAP_CASE
+    HIPCHK(h, hipGetLastError());
+    return AC_OK;
+}
+
+// conv (stride 1 or k = 2*stride), causal reflect padding.  Returns the output view in `y`.
+int conv_fwd(ac_handle* h, hipStream_t st, const PackedGemm& g, const Act& x, int k, int s, bool elu,
+             const float* rel_len, float* out, long long out_bs, long long out_rs, int B, Act* y) {
+    const int M = cdiv(x.L, s);
+    const int extra = M * s - x.L;
+    TapGemmParams p{};
+    p.nseg = 1;
+    if (s != 1 && k != 2 * s) return fail(h, AC_EINVAL, "strided conv needs kernel == 2*stride (got k=%d, s=%d)", k, s);
+    p.seg[0] = make_seg(x, s, s == 1 ? k : 2, true, elu, extra, 0, rel_len);
+    p.w = h->blob + g.w_off;
+    p.bias = h->blob + g.b_off;
+    p.y = out;
+    p.y_bs = out_bs;
+    p.y_rs = out_rs;
+    p.B = B;
+    p.M = M;
+    p.N = g.N;
+    p.Ktot = g.Ktot;
+    if (y) *y = Act{out, out_bs, out_rs, M, g.N};
+    return run_tap(h, st, p);
+}
+
+int convtr_fwd(ac_handle* h, hipStream_t st, const PackedGemm& g, const Act& x, int s, float* out, int B, Act* y) {
+    const int cout = g.N / s;
+    TapGemmParams p{};
+    p.nseg = 1;
+    p.seg[0] = make_seg(x, 1, 2, false, true, 0, 0, nullptr);
+    p.w = h->blob + g.w_off;
+    p.bias = h->blob + g.b_off;
+    p.y = out;
+    p.y_bs = (long long)x.L * g.N;
+    p.y_rs = g.N;
+    p.B = B;
+    p.M = x.L;
+    p.N = g.N;
+    p.Ktot = g.Ktot;
+    *y = Act{out, (long long)x.L * s * cout, cout, x.L * s, cout};
+    return run_tap(h, st, p);
+}
+
+// ResBlock: hbuf = conv3(ELU(x));  out = [ELU(hbuf) | x] * [W1; Ws] + (b1 + bs)
+int resblock_fwd(ac_handle* h, hipStream_t st, const ResBlockPlan& rb, const Act& x, float* hbuf, float* out, int B, Act* y) {
+    Act hv;
+    int rc = conv_fwd(h, st, rb.c3, x, h->cfg.residual_kernel_size, 1, true, nullptr, hbuf,
+                      (long long)x.L * rb.c3.N, rb.c3.N, B, &hv);
+    if (rc) return rc;
+    TapGemmParams p{};
+    p.nseg = 2;
+    p.seg[0] = make_seg(hv, 1, 1, true, true, 0, 0, nullptr);
+    p.seg[1] = make_seg(x, 1, 1, true, false, 0, hv.C, nullptr);
+    p.w = h->blob + rb.fused.w_off;
+    p.bias = h->blob + rb.fused.b_off;
+    p.y = out;
+    p.y_bs = (long long)x.L * rb.C;
+    p.y_rs = rb.C;
+    p.B = B;
+    p.M = x.L;
+    p.N = rb.C;
+    p.Ktot = rb.fused.Ktot;
+    *y = Act{out, p.y_bs, p.y_rs, x.L, rb.C};
+    return run_tap(h, st, p);
+}
+
+void capture(ac_handle* h, hipStream_t st, const Act& a, int B) {
+    if (!h->dbg) return;
+    const size_t n = (size_t)B * a.L * a.C;
+    if (h->dbg_used + n <= h->dbg_cap)
+        (void)hipMemcpyAsync(h->dbg + h->dbg_used, a.p, n * sizeof(float), hipMemcpyDeviceToDevice, st);
+    h->dbg_used += n;
+}
+
+struct LstmWs {
+    float *gin, *hseq0, *hseq1, *c;
+};
+
+// x [B][T][D] (standard layout) -> out[B][T][D] = lstm(x) + x
+int lstm_fwd(ac_handle* h, hipStream_t st, const LstmPlan& lp, const Act& x, const LstmWs& ws, float* out, int B, Act* y) {
+    const int D = lp.D, T = x.L;
+    if (D % 32 != 0) return fail(h, AC_EINVAL, "LSTM width %d must be a multiple of 32", D);
+    Act in = x;
+    for (int l = 0; l < lp.layers; ++l) {
+        // input projection for all t: gin[t][b][4D]
+        TapGemmParams p{};
+        p.nseg = 1;
+        p.seg[0] = make_seg(in, 1, 1, false, false, 0, 0, nullptr);
+        p.w = h->blob + lp.ih[l].w_off;
+        p.bias = h->blob + lp.ih[l].b_off;
+        p.y = ws.gin;
+        p.y_bs = 4LL * D;
+        p.y_rs = (long long)B * 4 * D;
+        p.B = B;
+        p.M = T;
+        p.N = 4 * D;
+        p.Ktot = D;
+        int rc = run_tap(h, st, p);
+        if (rc) return rc;
+        float* hseq = (l & 1) ? ws.hseq1 : ws.hseq0;
+        const bool last = l == lp.layers - 1;
+        {
+            ProfScope ps(h, st, "lstm_step_kernel", 2.0 * T * (double)B * 4 * D * D,
+                         (double)T * ((double)B * 4 * D * 4 + 4.0 * D * D * 4 + 2.0 * B * D * 4), T);
+            for (int t = 0; t < T; ++t) {
+                LstmStepParams q{};
+                q.gin = ws.gin + (long long)t * B * 4 * D;
+                q.gin_bs = 4LL * D;
+                q.hprev = t ? hseq + (long long)(t - 1) * B * D : nullptr;
+                q.hnext = hseq + (long long)t * B * D;
+                q.c = ws.c;
+                q.wpk = h->blob + lp.hh_off[l];
+                q.B = B;
+                q.D = D;
+                q.first = t == 0;
+                if (last) {
+                    q.skip = x.p + (long long)t * x.ts;
+                    q.skip_bs = x.bs;
+                    q.yout = out + (long long)t * D;
+                    q.y_bs = (long long)T * D;
+                }
+                hipLaunchKernelGGL(lstm_step_kernel, dim3(D / 4, cdiv(B, 32)), dim3(256), 0, st, q);
+            }
+        }
+        HIPCHK(h, hipGetLastError());
+        in = Act{hseq, (long long)D, (long long)B * D, T, D};
+    }
+    *y = Act{out, (long long)T * D, D, T, D};
+    return AC_OK;
+}
+
+int rvq_encode_fwd(ac_handle* h, hipStream_t st, const float* feats, int F, int K, long long* toks) {
+    RvqEncParams p{};
+    p.x = feats;
+    p.epk = h->blob + h->cb_packed;
+    p.e = h->blob + h->cb_plain;
+    p.ee = h->blob + h->cb_ee;
+    p.toks = toks;
+    p.F = F;
+    p.H = h->cfg.hidden_size;
+    p.C = h->cfg.codebook_size;
+    p.K = K;
+    const int HV = p.H / 16;
+    const dim3 grid(cdiv(F, 16)), block(64);
+    ProfScope ps(h, st, "rvq_encode_kernel", 2.0 * F * (double)p.C * p.H * K,
+                 (double)F * p.H * 4 + (double)F * K * 8 + (double)K * p.C * p.H * 4);
+    switch (HV) {
+        case 1: hipLaunchKernelGGL(rvq_encode_kernel<1>, grid, block, 0, st, p); break;
+        case 2: hipLaunchKernelGGL(rvq_encode_kernel<2>, grid, block, 0, st, p); break;
+        case 4: hipLaunchKernelGGL(rvq_encode_kernel<4>, grid, block, 0, st, p); break;
+        case 8: hipLaunchKernelGGL(rvq_encode_kernel<8>, grid, block, 0, st, p); break;
+        case 16: hipLaunchKernelGGL(rvq_encode_kernel<16>, grid, block, 0, st, p); break;
+        default: return fail(h, AC_EINVAL, "hidden_size %d unsupported by the RVQ kernel (need 16*{1,2,4,8,16})", p.H);
+    }
+    HIPCHK(h, hipGetLastError());
+    return AC_OK;
+}
+
+int rvq_decode_fwd(ac_handle* h, hipStream_t st, const long long* toks, int F, int K, float* out) {
+    RvqDecParams p{};
+    p.toks = toks;
+    p.e = h->blob + h->cb_plain;
+    p.out = out;
+    p.F = F;
+    p.H = h->cfg.hidden_size;
+    p.C = h->cfg.codebook_size;
+    p.K = K;
+    const long long n = (long long)F * (p.H / 4);
+    ProfScope ps(h, st, "rvq_decode_kernel", (double)F * p.H * K, (double)F * K * 8 + (double)F * p.H * 4 * (K + 1));
+    hipLaunchKernelGGL(rvq_decode_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p);
+    HIPCHK(h, hipGetLastError());
+    return AC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// workspace layout
+// ---------------------------------------------------------------------------------------------
+struct Workspace {
+    size_t act_floats = 0;     // each of the 3 rotating activation buffers
+    size_t gin = 0, hseq = 0, c = 0;
+    size_t total_bytes = 0;
+};
+
+Workspace plan_ws(const ac_handle* h, int B, int T_in /*samples, encoder*/, int N_frames /*decoder*/, bool enc) {
+    const ac_config& c = h->cfg;
+    Workspace w;
+    size_t mx = 0;
+    int N;
+    if (enc) {
+        long long L = T_in;
+        int ch = c.num_filters;
+        mx = std::max(mx, (size_t)L * ch);
+        for (int r = c.num_ratios - 1; r >= 0; --r) {
+            L = (L + c.upsampling_ratios[r] - 1) / c.upsampling_ratios[r];
+            ch *= 2;
+            mx = std::max(mx, (size_t)L * ch);
+        }
+        N = (int)L;
+    } else {
+        N = N_frames;
+        long long L = N;
+        int ch = h->D;
+        mx = std::max(mx, (size_t)L * ch);
+        for (int r = 0; r < c.num_ratios; ++r) {
+            L *= c.upsampling_ratios[r];
+            ch /= 2;
+            mx = std::max(mx, (size_t)L * ch);
+        }
+    }
+    mx = std::max(mx, (size_t)N * std::max(h->D, c.hidden_size));
+    w.act_floats = align_up(mx * B, 64);
+    w.gin = align_up((size_t)N * B * 4 * h->D, 64);
+    w.hseq = align_up((size_t)N * B * h->D, 64);
+    w.c = align_up((size_t)B * h->D, 64);
+    w.total_bytes = (3 * w.act_floats + w.gin + 2 * w.hseq + w.c) * sizeof(float) + 256;
+    return w;
+}
+
+struct WsPtrs {
+    float* act[3];
+    LstmWs lstm;
+};
+
+int carve(ac_handle* h, const Workspace& w, void* ws, size_t ws_bytes, WsPtrs* o) {
+    if (!ws) return fail(h, AC_EINVAL, "workspace pointer is null");
+    if (ws_bytes < w.total_bytes) return fail(h, AC_ENOMEM, "workspace too small: %zu < %zu bytes", ws_bytes, w.total_bytes);
+    float* p = reinterpret_cast<float*>(align_up(reinterpret_cast<uintptr_t>(ws), 256));
+    for (int i = 0; i < 3; ++i) { o->act[i] = p; p += w.act_floats; }
+    o->lstm.gin = p; p += w.gin;
+    o->lstm.hseq0 = p; p += w.hseq;
+    o->lstm.hseq1 = p; p += w.hseq;
+    o->lstm.c = p;
+    return AC_OK;
+}
+
+int check_ready(ac_handle* h) {
+    if (!h) return AC_EINVAL;
+    if (!h->finalized) return fail(h, AC_ESTATE, "ac_finalize has not been called");
+    return AC_OK;
+}
+
+// encoder: sig -> feats [B][N][H] written to `feats`
+int encoder_fwd(ac_handle* h, hipStream_t st, const float* sig, const float* rel_len, int B, int T, float* feats, const WsPtrs& ws) {
+    const ac_config& c = h->cfg;
+    Act x{sig, (long long)T, 1, T, 1};
+    Act y;
+    int cur = 0;
+    int rc = conv_fwd(h, st, h->enc_stem, x, c.kernel_size, 1, false, rel_len, ws.act[cur], (long long)T * c.num_filters,
+                      c.num_filters, B, &y);
+    if (rc) return rc;
+    x = y;
+    capture(h, st, x, B);
+    for (int i = 0; i < c.num_ratios; ++i) {
+        const int ratio = c.upsampling_ratios[c.num_ratios - 1 - i];
+        const int hb = (cur + 1) % 3, ob = (cur + 2) % 3;
+        rc = resblock_fwd(h, st, h->enc_rb[i], x, ws.act[hb], ws.act[ob], B, &y);
+        if (rc) return rc;
+        x = y;
+        capture(h, st, x, B);
+        cur = ob;
+        const int nb = (cur + 1) % 3;
+        const int M = cdiv(x.L, ratio);
+        rc = conv_fwd(h, st, h->enc_down[i], x, 2 * ratio, ratio, true, nullptr, ws.act[nb], (long long)M * h->enc_down[i].N,
+                      h->enc_down[i].N, B, &y);
+        if (rc) return rc;
+        x = y;
+        capture(h, st, x, B);
+        cur = nb;
+    }
+    const int ob = (cur + 1) % 3;
+    rc = lstm_fwd(h, st, h->enc_lstm, x, ws.lstm, ws.act[ob], B, &y);
+    if (rc) return rc;
+    x = y;
+    capture(h, st, x, B);
+    return conv_fwd(h, st, h->enc_final, x, c.last_kernel_size, 1, true, nullptr, feats, (long long)x.L * c.hidden_size,
+                    c.hidden_size, B, nullptr);
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// exported entry points
+// ---------------------------------------------------------------------------------------------
+extern "C" {
+
+int ac_version(void) { return 100; }
+
+int ac_create(const ac_config* cfg, ac_handle** out) {
+    if (!cfg || !out) return AC_EINVAL;
+    *out = nullptr;
+    if (cfg->struct_size != (int32_t)sizeof(ac_config)) return AC_EINVAL;
+    if (cfg->num_ratios < 1 || cfg->num_ratios > AC_MAX_RATIOS || cfg->num_filters < 1 || cfg->hidden_size < 16 ||
+        cfg->hidden_size % 16 || cfg->compress < 1 || cfg->num_lstm_layers < 1 || cfg->codebook_size % 16 ||
+        cfg->codebook_size < 16 || cfg->num_quantizers < 1 || cfg->kernel_size < 1 || cfg->kernel_size > 8 ||
+        cfg->last_kernel_size < 1 || cfg->last_kernel_size > 8 || cfg->residual_kernel_size < 1 || cfg->residual_kernel_size > 8)
+        return AC_EINVAL;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= cfg->device || cfg->device < 0) return AC_ENODEV;
+    ac_handle* h = new (std::nothrow) ac_handle();
+    if (!h) return AC_ENOMEM;
+    h->cfg = *cfg;
+    h->hop = 1;
+    for (int i = 0; i < cfg->num_ratios; ++i) h->hop *= cfg->upsampling_ratios[i];
+    h->D = cfg->num_filters << cfg->num_ratios;
+    *out = h;
+    return AC_OK;
+}
+
+int ac_load_weights(ac_handle* h, const char* name, const void* host_ptr, size_t bytes) {
+    if (!h || !name || !host_ptr) return h ? fail(h, AC_EINVAL, "null argument") : AC_EINVAL;
+    if (h->finalized) return fail(h, AC_ESTATE, "handle already finalized");
+    if (bytes % 4) return fail(h, AC_EINVAL, "tensor '%s': byte size %zu is not a multiple of 4", name, bytes);
+    const float* f = static_cast<const float*>(host_ptr);
+    h->host[name].assign(f, f + bytes / 4);
+    return AC_OK;
+}
+
+int ac_finalize(ac_handle* h) {
+    if (!h) return AC_EINVAL;
+    if (h->finalized) return fail(h, AC_ESTATE, "handle already finalized");
+    const ac_config& c = h->cfg;
+    Arch a = make_arch(c);
+    Packer pk{h};
+    bool ok = pk.conv(a.enc_stem, h->enc_stem);
+    h->enc_rb.resize(c.num_ratios);
+    h->enc_down.resize(c.num_ratios);
+    h->dec_up.resize(c.num_ratios);
+    h->dec_rb.resize(c.num_ratios);
+    for (int i = 0; ok && i < c.num_ratios; ++i) {
+        ok = ok && pk.resblock(a.enc_rb3[i], a.enc_rb1[i], a.enc_rbs[i], h->enc_rb[i]);
+        ok = ok && pk.conv(a.enc_down[i], h->enc_down[i]);
+    }
+    ok = ok && pk.lstm(a.enc_lstm, a.D, c.num_lstm_layers, h->enc_lstm);
+    ok = ok && pk.conv(a.enc_final, h->enc_final);
+    ok = ok && pk.conv(a.dec_first, h->dec_first);
+    ok = ok && pk.lstm(a.dec_lstm, a.D, c.num_lstm_layers, h->dec_lstm);
+    for (int i = 0; ok && i < c.num_ratios; ++i) {
+        ok = ok && pk.convtr(a.dec_up[i], h->dec_up[i]);
+        ok = ok && pk.resblock(a.dec_rb3[i], a.dec_rb1[i], a.dec_rbs[i], h->dec_rb[i]);
+    }
+    ok = ok && pk.conv(a.dec_head, h->dec_head);
+    if (!ok) return pk.rc;
+    // codebooks: plain [K][C][H], MFMA B-fragment order, squared norms
+    const int C = c.codebook_size, H = c.hidden_size, Q = c.num_quantizers;
+    h->cb_plain = pk.reserve((size_t)Q * C * H);
+    h->cb_packed = pk.reserve((size_t)Q * C * H);
+    h->cb_ee = pk.reserve((size_t)Q * C);
+    for (int q = 0; q < Q; ++q) {
+        const std::vector<float>* e = pk.get("quantizer.layers." + std::to_string(q) + ".codebook.embed", (size_t)C * H);
+        if (!e) return pk.rc;
+        std::copy(e->begin(), e->end(), pk.blob.begin() + h->cb_plain + (size_t)q * C * H);
+        for (int code = 0; code < C; ++code) {
+            double ss = 0.0;
+            for (int d = 0; d < H; ++d) ss += (double)(*e)[(size_t)code * H + d] * (*e)[(size_t)code * H + d];
+            pk.blob[h->cb_ee + (size_t)q * C + code] = (float)ss;
+        }
+        const int HV = H / 16;
+        for (int ct = 0; ct < C / 16; ++ct)
+            for (int v = 0; v < HV; ++v)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int u = 0; u < 4; ++u)
+                        pk.blob[h->cb_packed + (size_t)q * C * H + (((size_t)ct * HV + v) * 64 + lane) * 4 + u] =
+                            (*e)[(size_t)(ct * 16 + (lane & 15)) * H + v * 16 + 4 * (lane >> 4) + u];
+    }
+    HIPCHK(h, hipSetDevice(c.device));
+    hipDeviceProp_t prop;
+    HIPCHK(h, hipGetDeviceProperties(&prop, c.device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(h, AC_ENODEV, "device %d is %s; this library is built for gfx950 only", c.device, prop.gcnArchName);
+    h->blob_floats = pk.blob.size();
+    HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&h->blob), h->blob_floats * sizeof(float)));
+    HIPCHK(h, hipMemcpy(h->blob, pk.blob.data(), h->blob_floats * sizeof(float), hipMemcpyHostToDevice));
+    h->host.clear();
+    h->finalized = true;
+    return AC_OK;
+}
+
+int ac_num_frames(const ac_handle* h, int T) {
+    if (!h || T < 1) return AC_EINVAL;
+    long long L = T;
+    for (int r = h->cfg.num_ratios - 1; r >= 0; --r) L = (L + h->cfg.upsampling_ratios[r] - 1) / h->cfg.upsampling_ratios[r];
+    return (int)L;
+}
+int ac_hop_length(const ac_handle* h) { return h ? h->hop : AC_EINVAL; }
+int ac_hidden_size(const ac_handle* h) { return h ? h->cfg.hidden_size : AC_EINVAL; }
+
+size_t ac_encode_workspace_bytes(const ac_handle* h, int B, int T) {
+    if (!h || B < 1 || T < 1) return 0;
+    return plan_ws(h, B, T, 0, true).total_bytes;
+}
+size_t ac_decode_workspace_bytes(const ac_handle* h, int B, int N) {
+    if (!h || B < 1 || N < 1) return 0;
+    return plan_ws(h, B, 0, N, false).total_bytes;
+}
+
+int ac_encode_feats(ac_handle* h, const float* sig, const float* rel_len, int B, int T, float* feats, void* ws, size_t ws_bytes, void* stream) {
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (!sig || !feats || B < 1 || T < 1) return fail(h, AC_EINVAL, "ac_encode_feats: bad argument (B=%d, T=%d)", B, T);
+    WsPtrs p;
+    rc = carve(h, plan_ws(h, B, T, 0, true), ws, ws_bytes, &p);
+    if (rc) return rc;
+    return encoder_fwd(h, (hipStream_t)stream, sig, rel_len, B, T, feats, p);
+}
+
+int ac_encode(ac_handle* h, const float* sig, const float* rel_len, int B, int T, int K, int64_t* toks, void* ws, size_t ws_bytes, void* stream) {
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (!sig || !toks || B < 1 || T < 1) return fail(h, AC_EINVAL, "ac_encode: bad argument (B=%d, T=%d)", B, T);
+    if (K < 1 || K > h->cfg.num_quantizers) return fail(h, AC_EINVAL, "ac_encode: K=%d outside [1, %d]", K, h->cfg.num_quantizers);
+    WsPtrs p;
+    rc = carve(h, plan_ws(h, B, T, 0, true), ws, ws_bytes, &p);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const int N = ac_num_frames(h, T);
+    // feats land in the activation buffer the encoder's last conv does not read from
+    float* feats = p.lstm.gin;  // free again once the LSTM is done
+    rc = encoder_fwd(h, st, sig, rel_len, B, T, feats, p);
+    if (rc) return rc;
+    return rvq_encode_fwd(h, st, feats, B * N, K, reinterpret_cast<long long*>(toks));
+}
+
+int ac_quantize(ac_handle* h, const float* feats, int B, int N, int K, int64_t* toks, void* stream) {
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (!feats || !toks || B < 1 || N < 1 || K < 1 || K > h->cfg.num_quantizers) return fail(h, AC_EINVAL, "ac_quantize: bad argument");
+    return rvq_encode_fwd(h, (hipStream_t)stream, feats, B * N, K, reinterpret_cast<long long*>(toks));
+}
+
+int ac_dequantize(ac_handle* h, const int64_t* toks, int B, int N, int K, float* qfeats, void* stream) {
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (!qfeats || !toks || B < 1 || N < 1 || K < 1 || K > h->cfg.num_quantizers) return fail(h, AC_EINVAL, "ac_dequantize: bad argument");
+    return rvq_decode_fwd(h, (hipStream_t)stream, reinterpret_cast<const long long*>(toks), B * N, K, qfeats);
+}
+
+int ac_decode(ac_handle* h, const int64_t* toks, int B, int N, int K, float* sig, void* ws, size_t ws_bytes, void* stream) {
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (!sig || !toks || B < 1 || N < 1) return fail(h, AC_EINVAL, "ac_decode: bad argument (B=%d, N=%d)", B, N);
+    if (K < 1 || K > h->cfg.num_quantizers) return fail(h, AC_EINVAL, "ac_decode: K=%d outside [1, %d]", K, h->cfg.num_quantizers);
+    WsPtrs p;
+    rc = carve(h, plan_ws(h, B, 0, N, false), ws, ws_bytes, &p);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const ac_config& c = h->cfg;
+    int cur = 0;
+    rc = rvq_decode_fwd(h, st, reinterpret_cast<const long long*>(toks), B * N, K, p.act[cur]);
+    if (rc) return rc;
+    Act x{p.act[cur], (long long)N * c.hidden_size, c.hidden_size, N, c.hidden_size}, y;
+    int nb = (cur + 1) % 3;
+    rc = conv_fwd(h, st, h->dec_first, x, c.kernel_size, 1, false, nullptr, p.act[nb], (long long)N * h->D, h->D, B, &y);
+    if (rc) return rc;
+    x = y;
+    capture(h, st, x, B);
+    cur = nb;
+    nb = (cur + 1) % 3;
+    rc = lstm_fwd(h, st, h->dec_lstm, x, p.lstm, p.act[nb], B, &y);
+    if (rc) return rc;
+    x = y;
+    capture(h, st, x, B);
+    cur = nb;
+    for (int i = 0; i < c.num_ratios; ++i) {
+        nb = (cur + 1) % 3;
+        rc = convtr_fwd(h, st, h->dec_up[i], x, c.upsampling_ratios[i], p.act[nb], B, &y);
+        if (rc) return rc;
+        x = y;
+        capture(h, st, x, B);
+        cur = nb;
+        const int hb = (cur + 1) % 3, ob = (cur + 2) % 3;
+        rc = resblock_fwd(h, st, h->dec_rb[i], x, p.act[hb], p.act[ob], B, &y);
+        if (rc) return rc;
+        x = y;
+        capture(h, st, x, B);
+        cur = ob;
+    }
+    return conv_fwd(h, st, h->dec_head, x, c.last_kernel_size, 1, true, nullptr, sig, (long long)x.L, 1, B, nullptr);
+}
+
+int ac_embs(ac_handle* h, int K, float* embs, void* stream) {
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (!embs || K < 1 || K > h->cfg.num_quantizers) return fail(h, AC_EINVAL, "ac_embs: bad argument");
+    const size_t n = (size_t)K * h->cfg.codebook_size * h->cfg.hidden_size * sizeof(float);
+    HIPCHK(h, hipMemcpyAsync(embs, h->blob + h->cb_plain, n, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return AC_OK;
+}
+
+int ac_debug_capture(ac_handle* h, float* buf_dev, size_t cap_floats) {
+    if (!h) return AC_EINVAL;
+    h->dbg = buf_dev;
+    h->dbg_cap = buf_dev ? cap_floats : 0;
+    h->dbg_used = 0;
+    return AC_OK;
+}
+
+size_t ac_debug_captured(const ac_handle* h) { return h ? h->dbg_used : 0; }
+
+int ac_profile_begin(ac_handle* h) {
+    if (!h) return AC_EINVAL;
+    h->prof = true;
+    h->recs.clear();
+    h->ev_used = 0;
+    return AC_OK;
+}
+
+int ac_profile_end(ac_handle* h, ac_kernel_stat* out, int cap) {
+    if (!h) return AC_EINVAL;
+    h->prof = false;
+    std::vector<ac_kernel_stat> st(h->prof_names.size());
+    for (size_t i = 0; i < st.size(); ++i) {
+        std::memset(&st[i], 0, sizeof st[i]);
+        std::snprintf(st[i].name, sizeof st[i].name, "%s", h->prof_names[i].c_str());
+    }
+    for (const ProfRec& r : h->recs) {
+        if (hipEventSynchronize(r.e1) != hipSuccess) return fail(h, AC_EHIP, "hipEventSynchronize failed");
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) return fail(h, AC_EHIP, "hipEventElapsedTime failed");
+        st[r.name_id].launches += r.count;
+        st[r.name_id].total_ms += ms;
+        st[r.name_id].flops += r.flops;
+        st[r.name_id].bytes += r.bytes;
+    }
+    h->recs.clear();
+    h->ev_used = 0;
+    int n = 0;
+    for (size_t i = 0; i < st.size() && n < cap; ++i)
+        if (st[i].launches) out[n++] = st[i];
+    return n;
+}
+
+const char* ac_last_error(const ac_handle* h) { return h ? h->err.c_str() : "null handle"; }
+
+void ac_destroy(ac_handle* h) {
+    if (!h) return;
+    if (h->blob) (void)hipFree(h->blob);
+    for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
+    delete h;
+}
+
+}  // extern "C"

@@ -1,0 +1,140 @@
+// Residual vector quantiser of [HF] EncodecResidualVectorQuantizer (:424-447) over
+// EncodecEuclideanCodebook.quantize (:364-369):
+//     dist = -(sum(x^2) - 2 x.E^T + sum(E^2));  idx = argmax(dist) (first index on ties);
+//     residual -= E[idx];   K stages.
+// Encode: one wave owns 16 frames for ALL K stages.  The residual tile lives in registers in MFMA
+// A-fragment order (H/16 16-byte vectors per lane); each stage streams the codebook (pre-packed in
+// B-fragment order, L2-resident: 512 KB/stage) through v_mfma_f32_16x16x4_f32, keeps a running
+// (max, first index) per accumulator row, finishes the row argmax with a 16-lane butterfly
+// (wavefront reduction), gathers the winning code vectors and subtracts them in registers.
+// The distance matrix ([48000,1024] fp32 = 197 MB per stage in the reference) never exists.
+// Decode: sum_k E_k[tok] accumulated in stage order from 0.0, one thread per 4 latent dims.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "tap_gemm.h"
+
+namespace ac {
+
+struct RvqEncParams {
+    const float* x;      // [F][H] frames (channels-last encoder output), F = B*N
+    const float* epk;    // packed codebooks: [K][C/16 code tiles][H/16 ksteps][64 lanes][4]
+    const float* e;      // plain codebooks [K][C][H] (for the residual update)
+    const float* ee;     // [K][C] squared norms of the code vectors
+    long long* toks;     // [F][K]
+    int F, H, C, K;
+};
+
+template <int HV>  // HV = H/16: 16-byte vectors of the residual per lane
+__global__ __launch_bounds__(64) void rvq_encode_kernel(const RvqEncParams p) {
+    const int lane = threadIdx.x & 63;
+    const int li = lane & 15, kq = lane >> 4;
+    const int f0 = blockIdx.x * 16;
+    const int frow = f0 + li;                  // the frame whose A-fragment this lane holds
+    const bool fvalid = frow < p.F;
+    const int H = p.H;
+
+    f32x4 res[HV];
+#pragma unroll
+    for (int v = 0; v < HV; ++v)
+        res[v] = fvalid ? *reinterpret_cast<const f32x4*>(p.x + (long long)frow * H + v * 16 + 4 * kq)
+                        : f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int ctiles = p.C / 16;
+    for (int k = 0; k < p.K; ++k) {
+        // ||x||^2 of frame li: partial over this lane's k's, then across the 4 kq lanes
+        float xx = 0.f;
+#pragma unroll
+        for (int v = 0; v < HV; ++v) {
+            xx = fmaf(res[v].x, res[v].x, xx); xx = fmaf(res[v].y, res[v].y, xx);
+            xx = fmaf(res[v].z, res[v].z, xx); xx = fmaf(res[v].w, res[v].w, xx);
+        }
+        xx += __shfl_xor(xx, 16);
+        xx += __shfl_xor(xx, 32);
+        // accumulator row r of this lane is frame kq*4 + r: fetch its ||x||^2
+        float xxr[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) xxr[r] = __shfl(xx, kq * 4 + r);
+
+        float best[4] = {-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
+        int bidx[4] = {0, 0, 0, 0};
+        const float* ep = p.epk + (long long)k * p.C * H + lane * 4;
+        const float* eek = p.ee + (long long)k * p.C;
+        for (int ct = 0; ct < ctiles; ++ct) {
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+            const float* et = ep + (long long)ct * HV * 256;
+#pragma unroll
+            for (int v = 0; v < HV; ++v) {
+                const f32x4 bw = *reinterpret_cast<const f32x4*>(et + v * 256);
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(res[v][u], bw[u], acc, 0, 0, 0);
+            }
+            const int code = ct * 16 + li;
+            const float eev = eek[code];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                // dist = -((xx - 2*dot) + ee), evaluated in the reference's order
+                const float d = -((xxr[r] - 2.0f * acc[r]) + eev);
+                if (d > best[r]) { best[r] = d; bidx[r] = code; }
+            }
+        }
+        // row argmax across the 16 lanes holding the row's columns; ties -> smaller index
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int m = 1; m < 16; m <<= 1) {
+                const float ob = __shfl_xor(best[r], m);
+                const int oi = __shfl_xor(bidx[r], m);
+                if (ob > best[r] || (ob == best[r] && oi < bidx[r])) { best[r] = ob; bidx[r] = oi; }
+            }
+        }
+        // token out: lane li == 0 of each row group writes rows kq*4 + r
+        if (li == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int f = f0 + kq * 4 + r;
+                if (f < p.F) p.toks[(long long)f * p.K + k] = (long long)bidx[r];
+            }
+        }
+        // residual update: this lane needs the index of frame li = row (li>>2)*4 + (li&3)
+        int myidx = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int v = __shfl(bidx[r], (li >> 2) * 16);
+            if ((li & 3) == r) myidx = v;
+        }
+        if (k + 1 < p.K) {
+            const float* q = p.e + ((long long)k * p.C + myidx) * H + 4 * kq;
+#pragma unroll
+            for (int v = 0; v < HV; ++v) {
+                const f32x4 qv = *reinterpret_cast<const f32x4*>(q + v * 16);
+                res[v].x -= qv.x; res[v].y -= qv.y; res[v].z -= qv.z; res[v].w -= qv.w;
+            }
+        }
+    }
+}
+
+struct RvqDecParams {
+    const long long* toks;  // [F][K]
+    const float* e;         // [Kall][C][H]
+    float* out;             // [F][H]
+    int F, H, C, K;
+};
+
+__global__ __launch_bounds__(256) void rvq_decode_kernel(const RvqDecParams p) {
+    const int hv = p.H / 4;
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (long long)p.F * hv) return;
+    const long long f = gid / hv;
+    const int q = (int)(gid % hv);
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < p.K; ++k) {
+        long long idx = p.toks[f * p.K + k];
+        idx = idx < 0 ? 0 : (idx >= p.C ? p.C - 1 : idx);   // F.embedding would raise; stay in bounds
+        const f32x4 v = *reinterpret_cast<const f32x4*>(p.e + ((long long)k * p.C + idx) * p.H + 4 * q);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    *reinterpret_cast<f32x4*>(p.out + f * p.H + 4 * q) = acc;
+}
+
+}  // namespace ac

@@ -1,0 +1,214 @@
+// tap_gemm: every convolution of the SEANet stack as ONE fp32-MFMA GEMM over channels-last rows.
+//
+// Activations live in HBM channels-last, [B][time][C] (C contiguous).  In that layout
+//   * a stride-1 conv with k taps reads, for output row m, the k consecutive input rows
+//     m-(k-1)..m  (causal left pad)                     -> A row = k*Cin contiguous-ish floats;
+//   * a strided conv with k = 2*s (every down-sampler of EnCodec) is a 2-tap stride-1 conv over
+//     the input viewed as rows of s time steps (s*Cin floats): out[m] = Xr[m-1]*W0 + Xr[m]*W1;
+//   * a transposed conv with k = 2*s is a 2-tap stride-1 conv whose output row m holds the s
+//     output time steps m*s..m*s+s-1 (s*Cout floats): exactly the channels-last output layout,
+//     and the reference's right-trim of k-s samples is "the row after the last" -- never computed;
+//   * a linear layer (LSTM input projection) is the 1-tap case.
+// So all of [HF] EncodecConv1d (:157-176), EncodecConvTranspose1d (:206-233) and the ResBlock's
+// 1x1 convs + shortcut (:277-282, fused as a K-concatenation of two sources) run through this one
+// kernel: out[b][m][n] = bias[n] + sum_seg sum_j sum_c act(Xr_seg[b][m-(J-1)+j][c]) * W[n][k(seg,j,c)].
+//
+// Padding never materialises: the loader maps a (row, column) of the LDS slab to a source time
+// index with the reference's reflect rule -- including the small-input workaround of
+// [HF]:148-155 (zero-extend to max_pad+1, reflect, drop) -- or to zero (transposed conv, masked
+// samples, rows past the end).  ELU ([HF] nn.ELU before every conv but the first) is applied once
+// per staged element.
+//
+// MFMA: v_mfma_f32_16x16x4_f32 (exact fp32 products, fp32 accumulate; 157 TF peak).  Per 16-wide
+// k-step a lane reads ONE 16-byte vector of A and of B (its 4 consecutive k's) from LDS and issues
+// 4 MFMAs; MFMA u of the step contracts k = 16*ks + 4*(lane>>4) + u.  The k order inside the
+// accumulation chain is therefore a fixed permutation -- deterministic run to run.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ac {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct TapSeg {
+    const float* x;     // [B][L][cin] with strides below
+    long long bs;       // batch stride (floats)
+    long long ts;       // time-step stride (floats)
+    const float* rel_len;  // optional [B] relative lengths: zero samples with !(t < L*rel_len[b])
+    int L;              // time steps per item
+    int cin;            // channels per time step
+    int cin_shift;      // log2(cin) or -1
+    int s;              // time steps per reshaped row (row width Cw = s*cin)
+    int J;              // taps = reshaped rows per output row
+    int Lp;             // reflect period base: L if L > max_pad else max_pad+1 ([HF]:148-155)
+    int lim;            // valid padded range is [-(J-1)*s, lim): lim = L + extra_padding
+    int reflect;        // 1 reflect, 0 zero
+    int elu;            // 1: ELU(alpha=1) on load
+    int kofs;           // offset of this segment inside a packed weight row
+};
+
+struct TapGemmParams {
+    TapSeg seg[2];
+    int nseg;
+    const float* w;     // packed [N][Ktot], K contiguous; k = kofs + j*Cw + c
+    const float* bias;  // [N]
+    float* y;           // out[b*y_bs + m*y_rs + n]
+    long long y_bs, y_rs;
+    int B, M, N, Ktot;
+    int mtiles, ntiles;
+};
+
+__device__ __forceinline__ float elu1(float v) { return v > 0.f ? v : (expf(v) - 1.0f); }
+
+constexpr int KC = 32;        // K chunk staged per iteration
+constexpr int KCP = KC + 4;   // LDS pitch (floats): keeps 16-B alignment, spreads banks
+
+// Source value for padded time index i (may be <0 or >= L) and channel ci of item b.
+__device__ __forceinline__ long long src_index(const TapSeg& sg, int i) {
+    if (i >= sg.lim) return -1;
+    int j = i;
+    if (j < 0) {
+        if (!sg.reflect) return -1;
+        j = -j;
+    } else if (j >= sg.Lp) {
+        j = 2 * (sg.Lp - 1) - j;
+    }
+    if (j < 0 || j >= sg.L) return -1;   // zero-extension of the small-input rule / guard
+    return j;
+}
+
+template <int WGM, int WGN, int WM, int WN, bool VEC>
+__global__ __launch_bounds__(WGM* WGN * 64) void tap_gemm_kernel(const TapGemmParams p) {
+    constexpr int BM = WGM * WM * 16, BN = WGN * WN * 16, NT = WGM * WGN * 64;
+    constexpr int MAXJ = 8;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                              // [(BM + MAXJ-1)][KCP]
+    float* Ws = smem + (BM + MAXJ - 1) * KCP;      // [BN][KCP]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int li = lane & 15, kq = lane >> 4;
+
+    int id = blockIdx.x;
+    const int nt = id % p.ntiles; id /= p.ntiles;
+    const int mt = id % p.mtiles;
+    const int b = id / p.mtiles;
+    const int m0 = mt * BM, n0 = nt * BN;
+
+    f32x4 acc[WM][WN];
+#pragma unroll
+    for (int a = 0; a < WM; ++a)
+#pragma unroll
+        for (int c = 0; c < WN; ++c) acc[a][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int si = 0; si < p.nseg; ++si) {
+        const TapSeg& sg = p.seg[si];
+        const int Cw = sg.s * sg.cin;
+        const int R = BM + sg.J - 1;
+        const float* xb = sg.x + (long long)b * sg.bs;
+        float alen = 3.0e38f;
+        if (sg.rel_len) alen = (float)sg.L * sg.rel_len[b];
+        for (int c0 = 0; c0 < Cw; c0 += KC) {
+            // ---- stage the A slab: rows m0-(J-1) .. m0+BM-1, columns c0..c0+KC of the reshaped input
+            if (VEC) {
+                for (int e = tid; e < R * (KC / 4); e += NT) {
+                    const int row = e / (KC / 4), q = e % (KC / 4);
+                    const int c = c0 + 4 * q;
+                    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (c < Cw) {
+                        const int r = m0 - (sg.J - 1) + row;
+                        const int tp = sg.cin_shift >= 0 ? (c >> sg.cin_shift) : (c / sg.cin);
+                        const int ci = c - tp * sg.cin;
+                        const long long j = src_index(sg, r * sg.s + tp);
+                        if (j >= 0 && (float)j < alen) {
+                            v = *reinterpret_cast<const f32x4*>(xb + j * sg.ts + ci);
+                            if (sg.elu) { v.x = elu1(v.x); v.y = elu1(v.y); v.z = elu1(v.z); v.w = elu1(v.w); }
+                        }
+                    }
+                    *reinterpret_cast<f32x4*>(&As[row * KCP + 4 * q]) = v;
+                }
+            } else {
+                for (int e = tid; e < R * KC; e += NT) {
+                    const int row = e / KC, cc = e % KC;
+                    const int c = c0 + cc;
+                    float v = 0.f;
+                    if (c < Cw) {
+                        const int r = m0 - (sg.J - 1) + row;
+                        const int tp = c / sg.cin;
+                        const int ci = c - tp * sg.cin;
+                        const long long j = src_index(sg, r * sg.s + tp);
+                        if (j >= 0 && (float)j < alen) {
+                            v = xb[j * sg.ts + ci];
+                            if (sg.elu) v = elu1(v);
+                        }
+                    }
+                    As[row * KCP + cc] = v;
+                }
+            }
+            for (int j = 0; j < sg.J; ++j) {
+                // ---- stage the weight chunk for tap j: Ws[n][kk] = w[n0+n][kofs + j*Cw + c0 + kk]
+                const long long kbase = (long long)sg.kofs + (long long)j * Cw + c0;
+                if (VEC) {
+                    for (int e = tid; e < BN * (KC / 4); e += NT) {
+                        const int n = e / (KC / 4), q = e % (KC / 4);
+                        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+                        if (n0 + n < p.N && c0 + 4 * q < Cw)
+                            v = *reinterpret_cast<const f32x4*>(p.w + (long long)(n0 + n) * p.Ktot + kbase + 4 * q);
+                        *reinterpret_cast<f32x4*>(&Ws[n * KCP + 4 * q]) = v;
+                    }
+                } else {
+                    for (int e = tid; e < BN * KC; e += NT) {
+                        const int n = e / KC, cc = e % KC;
+                        float v = 0.f;
+                        if (n0 + n < p.N && c0 + cc < Cw) v = p.w[(long long)(n0 + n) * p.Ktot + kbase + cc];
+                        Ws[n * KCP + cc] = v;
+                    }
+                }
+                __syncthreads();
+                // ---- MFMA over this (chunk, tap)
+#pragma unroll
+                for (int ks = 0; ks < KC / 16; ++ks) {
+                    f32x4 af[WM], bf[WN];
+#pragma unroll
+                    for (int a = 0; a < WM; ++a)
+                        af[a] = *reinterpret_cast<const f32x4*>(&As[((wm * WM + a) * 16 + li + j) * KCP + ks * 16 + 4 * kq]);
+#pragma unroll
+                    for (int c = 0; c < WN; ++c)
+                        bf[c] = *reinterpret_cast<const f32x4*>(&Ws[((wn * WN + c) * 16 + li) * KCP + ks * 16 + 4 * kq]);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int a = 0; a < WM; ++a)
+#pragma unroll
+                            for (int c = 0; c < WN; ++c)
+                                acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a][u], bf[c][u], acc[a][c], 0, 0, 0);
+                }
+                __syncthreads();
+            }
+        }
+    }
+    // ---- epilogue: C layout of 16x16x4: col = lane&15, row = (lane>>4)*4 + reg
+    float* yb = p.y + (long long)b * p.y_bs;
+#pragma unroll
+    for (int a = 0; a < WM; ++a)
+#pragma unroll
+        for (int c = 0; c < WN; ++c) {
+            const int n = n0 + (wn * WN + c) * 16 + li;
+            if (n < p.N) {
+                const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = m0 + (wm * WM + a) * 16 + kq * 4 + r;
+                    if (m < p.M) yb[(long long)m * p.y_rs + n] = acc[a][c][r] + bv;
+                }
+            }
+        }
+}
+
+template <int WGM, int WGN, int WM, int WN>
+constexpr size_t tap_gemm_lds_bytes() {
+    return (size_t)((WGM * WM * 16 + 8 - 1) * KCP + WGN * WN * 16 * KCP) * sizeof(float);
+}
+
+}  // namespace ac

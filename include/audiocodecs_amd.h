@@ -1,0 +1,150 @@
+/*
+ * audiocodecs_amd.h -- C ABI of the MI355X (gfx950) EnCodec encode/decode path.
+ *
+ * Drop-in boundary: the reference is pure Python and has no FFI of its own; the calls this
+ * library replaces are the third-party model calls inside the reference wrapper
+ *     audiocodecs/encodec.py:90-93   self.model.encode(sig[:, None], padding_mask[:, None], bandwidth)
+ *     audiocodecs/encodec.py:139-140 self.model.decode(toks[None].movedim(-1, -2), [None])
+ *     audiocodecs/encodec.py:116     self.model.encoder(input_values)            (_sig_to_feats)
+ *     audiocodecs/encodec.py:125,147 self.model.quantizer.decode(toks)           (_sig_to_qfeats/_toks_to_qfeats)
+ *     audiocodecs/encodec.py:74-79   quantizer.layers[k].codebook.embed           (embs)
+ * which sit behind Codec.sig_to_toks / toks_to_sig / sig_to_feats / toks_to_qfeats / embs
+ * (audiocodecs/codec.py:57-107,182-184).  INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; every *_dev pointer is HIP device memory owned by the caller;
+ *  - all work is enqueued on the caller's `stream` (a hipStream_t passed as void*); no entry point
+ *    synchronises the device, so the caller's own fences (torch.cuda.synchronize in
+ *    downstream/test_sr.py:58,84) time the real work;
+ *  - return 0 on success, a negative AC_E* code on failure; never throws across the ABI;
+ *    ac_last_error() returns a human-readable message for the last failure on that handle;
+ *  - a handle is not thread-safe; one handle per process/GPU like the reference's one codec/rank;
+ *  - activations are fp32 ("parity mode": fp32 MFMA v_mfma_f32_16x16x4_f32, exact fp32 products and
+ *    accumulation); tokens are int64 like the reference's.
+ */
+#ifndef AUDIOCODECS_AMD_H
+#define AUDIOCODECS_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AC_OK 0
+#define AC_EINVAL (-1)   /* bad argument / shape / unsupported configuration            */
+#define AC_ESTATE (-2)   /* call order (weights missing, not finalized, ...)             */
+#define AC_ENOMEM (-3)   /* device allocation failed or workspace too small              */
+#define AC_EHIP (-4)     /* a HIP runtime call or kernel launch failed                   */
+#define AC_ENODEV (-5)   /* no gfx950 device visible                                     */
+
+#define AC_MAX_RATIOS 8
+
+typedef struct ac_handle ac_handle;
+
+/* Mirrors the fields of transformers.EncodecConfig the path depends on.
+ * Causal convs, reflect padding, weight-norm (pre-folded), mono, no chunking, normalize=False:
+ * the facebook/encodec_24khz variant the reference wrapper loads (encodec.py:49-51). */
+typedef struct ac_config {
+    int32_t struct_size;               /* = sizeof(ac_config)                                  */
+    int32_t sampling_rate;             /* 24000                                                */
+    int32_t num_filters;               /* 32                                                   */
+    int32_t hidden_size;               /* 128 (latent width == codebook dim)                   */
+    int32_t num_ratios;                /* 4                                                    */
+    int32_t upsampling_ratios[AC_MAX_RATIOS]; /* 8,5,4,2 (decoder order; encoder uses reverse) */
+    int32_t kernel_size;               /* 7                                                    */
+    int32_t last_kernel_size;          /* 7                                                    */
+    int32_t residual_kernel_size;      /* 3                                                    */
+    int32_t compress;                  /* 2                                                    */
+    int32_t num_lstm_layers;           /* 2                                                    */
+    int32_t codebook_size;             /* 1024                                                 */
+    int32_t num_quantizers;            /* 32                                                   */
+    int32_t device;                    /* HIP device ordinal                                   */
+} ac_config;
+
+/* Library/ABI version: major*10000 + minor*100 + patch. */
+int ac_version(void);
+
+/* Create a handle for `cfg` on device cfg->device.  No device memory is allocated yet. */
+int ac_create(const ac_config* cfg, ac_handle** out);
+
+/* Hand one fp32 tensor to the handle (copied).  `name` uses the HF state-dict keys of
+ * EncodecModel with weight-norm either
+ *   - already folded:   "<prefix>.weight"  (what the Python host passes; folded with the same torch
+ *                        primitive the reference's parametrisation evaluates), or
+ *   - unfolded:         "<prefix>.parametrizations.weight.original0" (g) and "...original1" (v);
+ *                        folded inside ac_finalize as  w = v * (g / ||v||_2), norm over dims (1,2).
+ * plus "<prefix>.bias", "<lstm>.weight_{ih,hh}_l{n}", "<lstm>.bias_{ih,hh}_l{n}",
+ * "quantizer.layers.{k}.codebook.embed".  Other keys (embed_avg, cluster_size, inited) are
+ * accepted and ignored.  `bytes` must equal 4 * number of elements expected for that key. */
+int ac_load_weights(ac_handle* h, const char* name, const void* host_ptr, size_t bytes);
+
+/* Check that every tensor of the configuration arrived, fold/pack them into the kernels' layouts
+ * and upload them (one device allocation owned by the handle). */
+int ac_finalize(ac_handle* h);
+
+/* Frames produced for T samples: ceil at every strided conv (T=1..320 -> 1, 321 -> 2, ...). */
+int ac_num_frames(const ac_handle* h, int T);
+/* Hop length (product of ratios, 320) and latent width (128). */
+int ac_hop_length(const ac_handle* h);
+int ac_hidden_size(const ac_handle* h);
+
+/* Scratch the caller must provide (device memory, 256-byte aligned) for one call. */
+size_t ac_encode_workspace_bytes(const ac_handle* h, int B, int T);
+size_t ac_decode_workspace_bytes(const ac_handle* h, int B, int N);
+
+/* sig_dev [B,T] fp32  ->  toks_dev [B,N,K] int64,  N = ac_num_frames(T).
+ * rel_len_dev: NULL, or [B] fp32 relative lengths (SpeechBrain style): sample t of clip b is
+ * zeroed before the encoder iff not (float)t < (float)T * rel_len[b]   (encodec.py:84-89,
+ * [HF] modeling_encodec.py:589-590).  Tokens are produced for all N frames regardless.
+ * K = number of codebooks (quantizer stages), 1 <= K <= num_quantizers. */
+int ac_encode(ac_handle* h, const float* sig_dev, const float* rel_len_dev, int B, int T, int K,
+              int64_t* toks_dev, void* workspace_dev, size_t workspace_bytes, void* stream);
+
+/* Encoder only: sig_dev [B,T] -> feats_dev [B,N,H] fp32 (channels-last, i.e. the wrapper's
+ * `feats.movedim(-1,-2)` layout, encodec.py:116-118).  rel_len_dev as in ac_encode (the reference's
+ * _sig_to_feats does not mask for the 24 kHz model: pass NULL to reproduce it). */
+int ac_encode_feats(ac_handle* h, const float* sig_dev, const float* rel_len_dev, int B, int T,
+                    float* feats_dev, void* workspace_dev, size_t workspace_bytes, void* stream);
+
+/* toks_dev [B,N,K] int64 (any ids in [0, codebook_size)) -> sig_dev [B, N*hop] fp32.
+ * The output is not trimmed to the encoder's input length (encodec.py:139-140). */
+int ac_decode(ac_handle* h, const int64_t* toks_dev, int B, int N, int K, float* sig_dev,
+              void* workspace_dev, size_t workspace_bytes, void* stream);
+
+/* RVQ only.  ac_quantize: feats_dev [B,N,H] -> toks_dev [B,N,K] ([HF]:424-438).
+ * ac_dequantize: toks_dev [B,N,K] -> qfeats_dev [B,N,H] = sum_k E_k[tok]  ([HF]:440-447). */
+int ac_quantize(ac_handle* h, const float* feats_dev, int B, int N, int K, int64_t* toks_dev, void* stream);
+int ac_dequantize(ac_handle* h, const int64_t* toks_dev, int B, int N, int K, float* qfeats_dev, void* stream);
+
+/* Copy the first K codebooks to embs_dev [K, codebook_size, H] fp32 (encodec.py:74-79). */
+int ac_embs(ac_handle* h, int K, float* embs_dev, void* stream);
+
+/* Optional per-kernel timing with HIP events on the caller's stream (bench.py's roofline leg).
+ * ac_profile_begin arms it; every launch made by subsequent calls is bracketed by events.
+ * ac_profile_end synchronises those events and writes up to `cap` records; returns the count. */
+typedef struct ac_kernel_stat {
+    char name[48];       /* kernel (family) name as it appears in rocprofv3 --kernel-trace */
+    int32_t launches;
+    float total_ms;
+    double flops;        /* algorithmic flops of those launches (2*M*N*K, ...)             */
+    double bytes;        /* algorithmic HBM bytes (inputs read once + outputs written once) */
+} ac_kernel_stat;
+int ac_profile_begin(ac_handle* h);
+int ac_profile_end(ac_handle* h, ac_kernel_stat* out, int cap);
+
+/* Test hook: while armed (buf_dev != NULL), ac_encode/ac_encode_feats/ac_decode append every module
+ * output -- in HF module order, standard channels-last [B][L][C] layout -- to buf_dev.
+ * ac_debug_captured returns the floats appended so far (may exceed cap_floats: nothing is written
+ * past the capacity).  Disarm with ac_debug_capture(h, NULL, 0). */
+int ac_debug_capture(ac_handle* h, float* buf_dev, size_t cap_floats);
+size_t ac_debug_captured(const ac_handle* h);
+
+const char* ac_last_error(const ac_handle* h);
+void ac_destroy(ac_handle* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AUDIOCODECS_AMD_H */

@@ -1,0 +1,56 @@
+"""Size-independent properties at BASELINE.json's full configuration (EnCodec-24k, 8 codebooks,
+batch 64 x 10 s) where the CPU oracle is too slow to be the checker for the whole batch."""
+import numpy as np
+import pytest
+import torch
+
+from golden_cases import noise
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def codec(checkpoints):
+    from audiocodecs_amd import Encodec
+
+    cfg, sd = checkpoints("full", 0)
+    return Encodec(24000, num_codebooks=8, state_dict=sd, config=cfg).eval()
+
+
+def test_full_batch_properties(codec, checkpoints):
+    from oracle import encodec_oracle as O
+
+    B, T = 64, 240000
+    sig = noise(123, B, T).cuda()
+    toks = codec.sig_to_toks(sig)
+    assert toks.shape == (B, 750, 8) and toks.dtype == torch.int64
+    assert int(toks.min()) >= 0 and int(toks.max()) < 1024
+    # run-to-run determinism (fixed accumulation order, no atomics)
+    assert torch.equal(toks, codec.sig_to_toks(sig))
+    # clips are independent units: a clip encoded alone gives the same ids as inside the batch
+    for b in (0, 37, 63):
+        assert torch.equal(codec.sig_to_toks(sig[b : b + 1]), toks[b : b + 1])
+    rec = codec.toks_to_sig(toks)
+    assert rec.shape == (B, T) and bool(torch.isfinite(rec).all())
+    assert torch.equal(codec.toks_to_sig(toks[5:6]), rec[5:6])
+    # causality: tokens of the first 5 s do not depend on the last 5 s
+    half = codec.sig_to_toks(sig[:2, : T // 2])
+    assert torch.equal(half, toks[:2, :375])
+    # spot-check two whole clips against the CPU oracle
+    cfg, sd = checkpoints("full", 0)
+    W = O.fold_weight_norm(sd)
+    W64 = O.fold_weight_norm(sd, torch.float64)
+    idx = [3, 60]
+    with torch.no_grad():
+        s = sig[idx].cpu()
+        otoks = O.sig_to_toks(cfg, W, s)
+        _, m64 = O.sig_to_toks(cfg, W64, s.double(), None, 8, True)
+        orec = O.toks_to_sig(cfg, W, otoks)
+    from test_oracle_golden import tokens_match_up_to_ties
+
+    n, bad, excused = tokens_match_up_to_ties(toks[idx].cpu().numpy(), otoks.numpy(), m64.numpy())
+    exact = float((toks[idx].cpu() == otoks).float().mean())
+    print(f"full-size: exact token match {exact:.6f}; excused near-ties {excused}/{otoks.numel()}")
+    assert bad == 0 and exact > 0.999
+    err = (codec.toks_to_sig(otoks.cuda()).cpu() - orec).numpy().astype(np.float64)
+    assert float(np.sqrt(np.mean(err**2))) < 1e-5
