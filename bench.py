@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: EnCodec-24k, 8 codebooks, encode + decode of 64 x 10 s per GPU.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A step = Codec.sig_to_toks + Codec.toks_to_sig over one synthetic batch that is already resident
+in HBM (BASELINE.json configs[1]; weights: seeded synthetic checkpoint -- no pretrained weights
+exist offline).  Clips are independent units: every rank encodes/decodes its own 64 clips
+(weak scaling); with N > 1 the only collective is the RCCL all_gather of the token ids, and it is
+inside the timed step.  Rank 0 prints ONE JSON line (contract in the task statement) carrying
+  roofline     -- dominant kernel (by HIP-event time measured in the timed steps) against the fp32
+                  MFMA peak of MI355X (157.3 TFLOP/s; parity mode computes in fp32) or HBM (8 TB/s)
+  cpu_baseline -- the CPU oracle (torch-CPU restatement of the reference) timed on this host's
+                  cores on a bounded sample of the same workload.  Baseline only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
+PEAK_HBM_GBS = 8000.0          # same guide, "HBM3E peak BW" (spec; 6.29 TB/s achievable)
+# algorithmic work per audio-second of encode+decode (EnCodec-24k, K=8)
+FLOP_PER_AUDIO_S = 6.12e9
+LAYER_BYTES_PER_AUDIO_S = 117.6e6
+
+
+def cpu_baseline(cfg, sd, sig_cpu, threads, clips=8):
+    """Oracle (kind 'port') on the host cores: `clips` clips of the same batch, 1 warm-up + 2 runs."""
+    from oracle import encodec_oracle as O  # checker/baseline only -- never on the product path
+
+    torch.set_num_threads(threads)
+    W = O.fold_weight_norm(sd)
+    x = sig_cpu[:clips]
+    best = None
+    with torch.inference_mode():
+        for it in range(3):
+            t0 = time.perf_counter()
+            toks = O.sig_to_toks(cfg, W, x)
+            O.toks_to_sig(cfg, W, toks)
+            dt = time.perf_counter() - t0
+            if it:
+                best = dt if best is None else min(best, dt)
+    audio_s = x.shape[0] * x.shape[1] / cfg.sampling_rate
+    return {
+        "value": round(audio_s / best, 2),
+        "unit": "audio-s/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"{clips} clips x {x.shape[1] / cfg.sampling_rate:.0f} s of the same batch, fp32 torch-CPU oracle, best of 2 after 1 warm-up",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="clips per GPU")
+    ap.add_argument("--seconds", type=float, default=10.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from audiocodecs_amd import Encodec, checkpoint, prng
+    from audiocodecs_amd.config import ENCODEC_24KHZ as cfg
+    from audiocodecs_amd.sharding import gather_tokens
+
+    B, T = args.batch, int(round(args.seconds * cfg.sampling_rate))
+    sd = checkpoint.synthetic_state_dict(cfg, seed=0)
+    codec = Encodec(cfg.sampling_rate, num_codebooks=8, state_dict=sd).eval()
+    # sig = 0.1*N(0,1), repo PRNG seed 123; each rank draws its own shard
+    sig_cpu = torch.from_numpy((prng.normal(123, f"bench.sig.rank{rank}", (B, T)) * 0.1).astype(np.float32))
+    sig = sig_cpu.cuda()
+
+    def step():
+        toks = codec.sig_to_toks(sig)
+        if dist is not None:
+            gather_tokens(toks)
+        return codec.toks_to_sig(toks)
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            step()
+        fence()
+        t0 = time.perf_counter()
+        stats = codec.profile_kernels(lambda: [step() for _ in range(args.steps)])
+        fence()
+        dt = time.perf_counter() - t0
+        # unprofiled repeat (no per-kernel events on the stream) as a side figure
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        dt_plain = time.perf_counter() - t1
+
+    if dist is not None:
+        tt = torch.tensor([dt, dt_plain], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt, dt_plain = tt.tolist()
+
+    audio_s = world * B * T / cfg.sampling_rate * args.steps
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        stats.sort(key=lambda s: -s[2])
+        name, launches, tot_ms, flops, nbytes = stats[0]
+        avg_us = tot_ms / launches * 1e3
+        ai = flops / max(nbytes, 1.0)
+        if ai > PEAK_FP32_MFMA_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9):
+            roof = {"bound": "mfma", "achieved": round(flops / (tot_ms * 1e-3) / 1e12, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
+                    "unit": "TFLOP/s"}
+        else:
+            roof = {"bound": "hbm", "achieved": round(nbytes / (tot_ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s"}
+        roof["frac"] = round(roof["achieved"] / roof["peak"], 4)
+        roof["traffic"] = None
+        roof["kernel"] = name
+        roof["launches_per_step"] = launches / args.steps
+        roof["avg_launch_us"] = round(avg_us, 2)
+        roof["share_of_step"] = round(tot_ms / (dt * 1e3), 4)
+        out = {
+            "metric": "encode+decode audio-sec/s, EnCodec-24k 8cb",
+            "value": round(audio_s / dt, 1),
+            "unit": "audio-s/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic (0.1*N(0,1) clips, seeded synthetic weights of the EnCodec-24k architecture)",
+            "config": {"workload": f"EnCodec-24k 8 codebooks, encode+decode, {B} clips x {args.seconds:g} s per GPU, resident in HBM",
+                       "clips_per_gpu": B, "seconds_per_clip": args.seconds, "parallelism": f"clip-sharded x{world}"},
+            "rtf": round(dt / audio_s, 7),
+            "x_realtime_per_gpu": round(audio_s / dt / world, 1),
+            "whole_path": {
+                "mfma_fp32_frac": round(FLOP_PER_AUDIO_S * audio_s / world / dt / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4),
+                "hbm_layer_boundary_frac": round(LAYER_BYTES_PER_AUDIO_S * audio_s / world / dt / (PEAK_HBM_GBS * 1e9), 4),
+                "ms_per_step_without_kernel_events": round(dt_plain / args.steps * 1e3, 3),
+            },
+            "roofline": roof,
+            "kernels": [
+                {"name": s[0], "launches_per_step": s[1] / args.steps, "ms_per_step": round(s[2] / args.steps, 3),
+                 "tflops": round(s[3] / (s[2] * 1e-3) / 1e12, 2), "gbs": round(s[4] / (s[2] * 1e-3) / 1e9, 1)}
+                for s in stats
+            ],
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            threads = max(1, (os.cpu_count() or 2) // 2)
+            out["cpu_baseline"] = cpu_baseline(cfg, sd, sig_cpu, threads)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
