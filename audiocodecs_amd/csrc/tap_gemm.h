@@ -59,7 +59,11 @@ struct TapGemmParams {
     int mtiles, ntiles;
 };
 
-__device__ __forceinline__ float elu1(float v) { return v > 0.f ? v : (expf(v) - 1.0f); }
+// ELU(alpha=1) as torch evaluates it on CPU: x > 0 ? x : exp(x) - 1 (not expm1).  exp goes through the
+// hardware v_exp_f32 (2^x, ~1 ulp) after one multiply by log2(e): absolute error of the result
+// <= ~1.2e-7, the same class as the reference's own vectorised expf, at 5 instructions per element
+// instead of ~15 -- staging instruction count bounds the MFMA kernels (profiles/r1_tapgemm_trace.md).
+__device__ __forceinline__ float elu1(float v) { return v > 0.f ? v : (__expf(v) - 1.0f); }
 
 constexpr int KC = 32;        // K chunk staged per iteration
 constexpr int KCP = KC + 4;   // LDS pitch (floats): keeps 16-B alignment, spreads banks

@@ -239,7 +239,7 @@ class Encodec(Codec):
     # ---- measurement hook used by bench.py ------------------------------------------------------
     def profile_kernels(self, fn):
         """Run fn() with per-kernel HIP-event timing armed; returns [(name, launches, ms, flops, bytes)]."""
-        nat = next(iter(self._natives.values()))
+        nat = self._native_for(torch.empty(0, device=torch.device("cuda", torch.cuda.current_device())))
         _native.check(nat.lib.ac_profile_begin(nat.h), nat.h, "ac_profile_begin")
         try:
             fn()
