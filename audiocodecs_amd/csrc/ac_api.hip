@@ -15,6 +15,7 @@
 #include "lstm.h"
 #include "rvq.h"
 #include "tap_gemm.h"
+#include "tap_gemm4.h"
 
 using namespace ac;
 
@@ -356,8 +357,27 @@ void launch_tap(const TapGemmParams& p0, hipStream_t st) {
     hipLaunchKernelGGL((tap_gemm_kernel<WGM, WGN, WM, WN, VEC>), dim3((unsigned)blocks), dim3(WGM * WGN * 64), lds, st, p);
 }
 
-// One segment of the A operand for a conv reading `x` (time steps of C channels).
-TapSeg make_seg(const Act& x, int s, int J, bool reflect, bool elu, int extra, int kofs, const float* rel_len) {
+template <int WGM, int WGN, int WM, int WN>
+int launch_tap4(ac_handle* h, const TapGemmParams& p0, hipStream_t st) {
+    using Cfg = Tap4Cfg<WGM, WGN, WM, WN>;
+    TapGemmParams p = p0;
+    p.mtiles = cdiv(p.M, Cfg::BM);
+    p.ntiles = cdiv(p.N, Cfg::BN);
+    static bool attr_set = false;   // > 64 KB of dynamic LDS must be opted into once per kernel
+    if (!attr_set) {
+        HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(tap_gemm4_kernel<WGM, WGN, WM, WN>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::lds_bytes));
+        attr_set = true;
+    }
+    const long long blocks = (long long)p.B * p.mtiles * p.ntiles;
+    const size_t lds = Cfg::lds_bytes;
+    hipLaunchKernelGGL((tap_gemm4_kernel<WGM, WGN, WM, WN>), dim3((unsigned)blocks), dim3(Cfg::NT), lds, st, p);
+    return AC_OK;
+}
+
+// One segment of the A operand for a conv reading `x` (time steps of C channels).  Inputs are
+// already activated by their producer (TapGemmParams::y_elu), so no segment carries ELU.
+TapSeg make_seg(const Act& x, int s, int J, bool reflect, int extra, int kofs, const float* rel_len) {
     TapSeg g{};
     g.x = x.p;
     g.bs = x.bs;
@@ -375,36 +395,43 @@ TapSeg make_seg(const Act& x, int s, int J, bool reflect, bool elu, int extra, i
     g.Lp = (reflect && x.L <= max_pad) ? max_pad + 1 : x.L;
     g.lim = reflect ? x.L + extra : x.L;
     g.reflect = reflect ? 1 : 0;
-    g.elu = elu ? 1 : 0;
+    g.elu = 0;
     g.kofs = kofs;
     return g;
 }
 
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
 int run_tap(ac_handle* h, hipStream_t st, TapGemmParams& p) {
-    bool vec = (p.Ktot % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.w) & 15) == 0);
+    bool vec = (p.Ktot % 4 == 0) && aligned16(p.w);
+    bool fast = vec && (p.N % 4 == 0) && (p.y_rs % 4 == 0) && (p.y_bs % 4 == 0) && (!p.y || aligned16(p.y)) &&
+                (!p.y_elu || aligned16(p.y_elu)) && (long long)p.N * p.Ktot * 4 < (1LL << 31);
     for (int i = 0; i < p.nseg; ++i) {
         const TapSeg& s = p.seg[i];
-        vec = vec && (s.cin % 4 == 0) && (s.ts % 4 == 0) && (s.bs % 4 == 0) && (s.kofs % 4 == 0) &&
-              ((reinterpret_cast<uintptr_t>(s.x) & 15) == 0);
+        vec = vec && (s.cin % 4 == 0) && (s.ts % 4 == 0) && (s.bs % 4 == 0) && (s.kofs % 4 == 0) && aligned16(s.x);
+        fast = fast && ((s.s * s.cin) % KC == 0) && (s.ts == s.cin || s.s == 1) && !s.rel_len && !s.elu &&
+               ((long long)(s.L - 1) * s.ts + s.cin) * 4 < (1LL << 31);
         if (s.J > 8) return fail(h, AC_EINVAL, "conv with %d taps exceeds the kernel limit of 8", s.J);
     }
+    fast = fast && vec;
     double kk = 0, inb = 0;
     for (int i = 0; i < p.nseg; ++i) {
         kk += (double)p.seg[i].J * p.seg[i].s * p.seg[i].cin;
         inb += (double)p.B * p.seg[i].L * p.seg[i].cin * 4.0;
     }
     const double flops = 2.0 * p.B * (double)p.M * p.N * kk;
-    const double bytes = inb + (double)p.B * p.M * p.N * 4.0 + (double)p.N * p.Ktot * 4.0;
-    const char* nm;
+    const double bytes = inb + (double)p.B * p.M * p.N * 4.0 * ((p.y ? 1 : 0) + (p.y_elu ? 1 : 0)) + (double)p.N * p.Ktot * 4.0;
+    int rc = AC_OK;
 #define TAP_CASE(WGM, WGN, WM, WN)                                                                          \
     do {                                                                                                    \
-        if (vec) {                                                                                          \
-            nm = "tap_gemm_kernel<" #WGM ", " #WGN ", " #WM ", " #WN ", true>";                             \
-            ProfScope ps(h, st, nm, flops, bytes);                                                          \
+        if (fast) {                                                                                         \
+            ProfScope ps(h, st, "tap_gemm4_kernel<" #WGM ", " #WGN ", " #WM ", " #WN ">", flops, bytes);    \
+            rc = launch_tap4<WGM, WGN, WM, WN>(h, p, st);                                                   \
+        } else if (vec) {                                                                                   \
+            ProfScope ps(h, st, "tap_gemm_kernel<" #WGM ", " #WGN ", " #WM ", " #WN ", true>", flops, bytes); \
             launch_tap<WGM, WGN, WM, WN, true>(p, st);                                                      \
         } else {                                                                                            \
-            nm = "tap_gemm_kernel<" #WGM ", " #WGN ", " #WM ", " #WN ", false>";                            \
-            ProfScope ps(h, st, nm, flops, bytes);                                                          \
+            ProfScope ps(h, st, "tap_gemm_kernel<" #WGM ", " #WGN ", " #WM ", " #WN ", false>", flops, bytes); \
             launch_tap<WGM, WGN, WM, WN, false>(p, st);                                                     \
         }                                                                                                   \
     } while (0)
@@ -413,70 +440,89 @@ int run_tap(ac_handle* h, hipStream_t st, TapGemmParams& p) {
     else if (p.N <= 64) TAP_CASE(2, 2, 2, 2);
     else TAP_CASE(2, 2, 4, 4);
 #undef TAP_CASE
+    if (rc) return rc;
     HIPCHK(h, hipGetLastError());
     return AC_OK;
 }
 
-// conv (stride 1 or k = 2*stride), causal reflect padding.  Returns the output view in `y`.
-int conv_fwd(ac_handle* h, hipStream_t st, const PackedGemm& g, const Act& x, int k, int s, bool elu,
-             const float* rel_len, float* out, long long out_bs, long long out_rs, int B, Act* y) {
+// What a layer should produce: the raw output, its ELU, or both (SEANet consumers all start with ELU;
+// shortcuts, LSTMs and the public outputs want the raw value).
+struct Out {
+    float* raw = nullptr;
+    float* elu = nullptr;
+};
+struct Act2 {       // a layer output in up to two flavours (same shape/strides)
+    Act raw{}, elu{};
+};
+
+// conv (stride 1 or k = 2*stride), causal reflect padding.
+int conv_fwd(ac_handle* h, hipStream_t st, const PackedGemm& g, const Act& x, int k, int s, const float* rel_len, Out out,
+             long long out_bs, long long out_rs, int B, Act2* y) {
     const int M = cdiv(x.L, s);
     const int extra = M * s - x.L;
     TapGemmParams p{};
     p.nseg = 1;
     if (s != 1 && k != 2 * s) return fail(h, AC_EINVAL, "strided conv needs kernel == 2*stride (got k=%d, s=%d)", k, s);
-    p.seg[0] = make_seg(x, s, s == 1 ? k : 2, true, elu, extra, 0, rel_len);
+    p.seg[0] = make_seg(x, s, s == 1 ? k : 2, true, extra, 0, rel_len);
     p.w = h->blob + g.w_off;
     p.bias = h->blob + g.b_off;
-    p.y = out;
+    p.y = out.raw;
+    p.y_elu = out.elu;
     p.y_bs = out_bs;
     p.y_rs = out_rs;
     p.B = B;
     p.M = M;
     p.N = g.N;
     p.Ktot = g.Ktot;
-    if (y) *y = Act{out, out_bs, out_rs, M, g.N};
+    if (y) {
+        y->raw = Act{out.raw, out_bs, out_rs, M, g.N};
+        y->elu = Act{out.elu, out_bs, out_rs, M, g.N};
+    }
     return run_tap(h, st, p);
 }
 
-int convtr_fwd(ac_handle* h, hipStream_t st, const PackedGemm& g, const Act& x, int s, float* out, int B, Act* y) {
+int convtr_fwd(ac_handle* h, hipStream_t st, const PackedGemm& g, const Act& x, int s, Out out, int B, Act2* y) {
     const int cout = g.N / s;
     TapGemmParams p{};
     p.nseg = 1;
-    p.seg[0] = make_seg(x, 1, 2, false, true, 0, 0, nullptr);
+    p.seg[0] = make_seg(x, 1, 2, false, 0, 0, nullptr);
     p.w = h->blob + g.w_off;
     p.bias = h->blob + g.b_off;
-    p.y = out;
+    p.y = out.raw;
+    p.y_elu = out.elu;
     p.y_bs = (long long)x.L * g.N;
     p.y_rs = g.N;
     p.B = B;
     p.M = x.L;
     p.N = g.N;
     p.Ktot = g.Ktot;
-    *y = Act{out, (long long)x.L * s * cout, cout, x.L * s, cout};
+    y->raw = Act{out.raw, (long long)x.L * s * cout, cout, x.L * s, cout};
+    y->elu = Act{out.elu, (long long)x.L * s * cout, cout, x.L * s, cout};
     return run_tap(h, st, p);
 }
 
-// ResBlock: hbuf = conv3(ELU(x));  out = [ELU(hbuf) | x] * [W1; Ws] + (b1 + bs)
-int resblock_fwd(ac_handle* h, hipStream_t st, const ResBlockPlan& rb, const Act& x, float* hbuf, float* out, int B, Act* y) {
-    Act hv;
-    int rc = conv_fwd(h, st, rb.c3, x, h->cfg.residual_kernel_size, 1, true, nullptr, hbuf,
-                      (long long)x.L * rb.c3.N, rb.c3.N, B, &hv);
+// ResBlock: hbuf = ELU(conv3(ELU(x)));  out = [hbuf | x] * [W1; Ws] + (b1 + bs)
+int resblock_fwd(ac_handle* h, hipStream_t st, const ResBlockPlan& rb, const Act2& x, float* hbuf, Out out, int B, Act2* y) {
+    Act2 hv;
+    int rc = conv_fwd(h, st, rb.c3, x.elu, h->cfg.residual_kernel_size, 1, nullptr, Out{nullptr, hbuf},
+                      (long long)x.elu.L * rb.c3.N, rb.c3.N, B, &hv);
     if (rc) return rc;
     TapGemmParams p{};
     p.nseg = 2;
-    p.seg[0] = make_seg(hv, 1, 1, true, true, 0, 0, nullptr);
-    p.seg[1] = make_seg(x, 1, 1, true, false, 0, hv.C, nullptr);
+    p.seg[0] = make_seg(hv.elu, 1, 1, true, 0, 0, nullptr);
+    p.seg[1] = make_seg(x.raw, 1, 1, true, 0, hv.elu.C, nullptr);
     p.w = h->blob + rb.fused.w_off;
     p.bias = h->blob + rb.fused.b_off;
-    p.y = out;
-    p.y_bs = (long long)x.L * rb.C;
+    p.y = out.raw;
+    p.y_elu = out.elu;
+    p.y_bs = (long long)x.raw.L * rb.C;
     p.y_rs = rb.C;
     p.B = B;
-    p.M = x.L;
+    p.M = x.raw.L;
     p.N = rb.C;
     p.Ktot = rb.fused.Ktot;
-    *y = Act{out, p.y_bs, p.y_rs, x.L, rb.C};
+    y->raw = Act{out.raw, p.y_bs, p.y_rs, x.raw.L, rb.C};
+    y->elu = Act{out.elu, p.y_bs, p.y_rs, x.raw.L, rb.C};
     return run_tap(h, st, p);
 }
 
@@ -492,8 +538,8 @@ struct LstmWs {
     float *gin, *hseq0, *hseq1, *c;
 };
 
-// x [B][T][D] (standard layout) -> out[B][T][D] = lstm(x) + x
-int lstm_fwd(ac_handle* h, hipStream_t st, const LstmPlan& lp, const Act& x, const LstmWs& ws, float* out, int B, Act* y) {
+// x [B][T][D] (standard layout) -> lstm(x) + x as raw and/or ELU'd [B][T][D]
+int lstm_fwd(ac_handle* h, hipStream_t st, const LstmPlan& lp, const Act& x, const LstmWs& ws, Out out, int B, Act2* y) {
     const int D = lp.D, T = x.L;
     if (D % 32 != 0) return fail(h, AC_EINVAL, "LSTM width %d must be a multiple of 32", D);
     Act in = x;
@@ -501,7 +547,7 @@ int lstm_fwd(ac_handle* h, hipStream_t st, const LstmPlan& lp, const Act& x, con
         // input projection for all t: gin[t][b][4D]
         TapGemmParams p{};
         p.nseg = 1;
-        p.seg[0] = make_seg(in, 1, 1, false, false, 0, 0, nullptr);
+        p.seg[0] = make_seg(in, 1, 1, false, 0, 0, nullptr);
         p.w = h->blob + lp.ih[l].w_off;
         p.bias = h->blob + lp.ih[l].b_off;
         p.y = ws.gin;
@@ -532,7 +578,8 @@ int lstm_fwd(ac_handle* h, hipStream_t st, const LstmPlan& lp, const Act& x, con
                 if (last) {
                     q.skip = x.p + (long long)t * x.ts;
                     q.skip_bs = x.bs;
-                    q.yout = out + (long long)t * D;
+                    q.yout = out.raw ? out.raw + (long long)t * D : nullptr;
+                    q.yout_elu = out.elu ? out.elu + (long long)t * D : nullptr;
                     q.y_bs = (long long)T * D;
                 }
                 hipLaunchKernelGGL(lstm_step_kernel, dim3(D / 4, cdiv(B, 32)), dim3(256), 0, st, q);
@@ -541,7 +588,8 @@ int lstm_fwd(ac_handle* h, hipStream_t st, const LstmPlan& lp, const Act& x, con
         HIPCHK(h, hipGetLastError());
         in = Act{hseq, (long long)D, (long long)B * D, T, D};
     }
-    *y = Act{out, (long long)T * D, D, T, D};
+    y->raw = Act{out.raw, (long long)T * D, D, T, D};
+    y->elu = Act{out.elu, (long long)T * D, D, T, D};
     return AC_OK;
 }
 
@@ -591,8 +639,10 @@ int rvq_decode_fwd(ac_handle* h, hipStream_t st, const long long* toks, int F, i
 // ---------------------------------------------------------------------------------------------
 // workspace layout
 // ---------------------------------------------------------------------------------------------
+constexpr int NACT = 6;   // rotating activation buffers: x.raw, x.elu, hidden, y.elu (+ y.raw when capturing)
+
 struct Workspace {
-    size_t act_floats = 0;     // each of the 3 rotating activation buffers
+    size_t act_floats = 0;     // each of the NACT rotating activation buffers
     size_t gin = 0, hseq = 0, c = 0;
     size_t total_bytes = 0;
 };
@@ -628,20 +678,31 @@ Workspace plan_ws(const ac_handle* h, int B, int T_in /*samples, encoder*/, int 
     w.gin = align_up((size_t)N * B * 4 * h->D, 64);
     w.hseq = align_up((size_t)N * B * h->D, 64);
     w.c = align_up((size_t)B * h->D, 64);
-    w.total_bytes = (3 * w.act_floats + w.gin + 2 * w.hseq + w.c) * sizeof(float) + 256;
+    w.total_bytes = (NACT * w.act_floats + w.gin + 2 * w.hseq + w.c) * sizeof(float) + 256;
     return w;
 }
 
 struct WsPtrs {
-    float* act[3];
+    float* act[NACT];
+    bool used[NACT];
     LstmWs lstm;
+    float* take() {
+        for (int i = 0; i < NACT; ++i)
+            if (!used[i]) { used[i] = true; return act[i]; }
+        return nullptr;   // cannot happen: at most 5 are live at once
+    }
+    void give(const float* p) {
+        for (int i = 0; i < NACT; ++i)
+            if (act[i] == p) used[i] = false;
+    }
+    void give(const Act2& a) { give(a.raw.p); give(a.elu.p); }
 };
 
 int carve(ac_handle* h, const Workspace& w, void* ws, size_t ws_bytes, WsPtrs* o) {
     if (!ws) return fail(h, AC_EINVAL, "workspace pointer is null");
     if (ws_bytes < w.total_bytes) return fail(h, AC_ENOMEM, "workspace too small: %zu < %zu bytes", ws_bytes, w.total_bytes);
     float* p = reinterpret_cast<float*>(align_up(reinterpret_cast<uintptr_t>(ws), 256));
-    for (int i = 0; i < 3; ++i) { o->act[i] = p; p += w.act_floats; }
+    for (int i = 0; i < NACT; ++i) { o->act[i] = p; o->used[i] = false; p += w.act_floats; }
     o->lstm.gin = p; p += w.gin;
     o->lstm.hseq0 = p; p += w.hseq;
     o->lstm.hseq1 = p; p += w.hseq;
@@ -655,41 +716,82 @@ int check_ready(ac_handle* h) {
     return AC_OK;
 }
 
-// encoder: sig -> feats [B][N][H] written to `feats`
-int encoder_fwd(ac_handle* h, hipStream_t st, const float* sig, const float* rel_len, int B, int T, float* feats, const WsPtrs& ws) {
+// encoder: sig -> feats [B][N][H] written to `feats`.
+// Flavours: a tensor is written raw where a shortcut / LSTM / caller reads it, ELU'd where the next
+// conv reads it (all SEANet convs but the first are preceded by nn.ELU), both where both happen.
+// While the test hook is armed every module output is also written raw so it can be captured.
+int encoder_fwd(ac_handle* h, hipStream_t st, const float* sig, const float* rel_len, int B, int T, float* feats, WsPtrs& ws) {
     const ac_config& c = h->cfg;
-    Act x{sig, (long long)T, 1, T, 1};
-    Act y;
-    int cur = 0;
-    int rc = conv_fwd(h, st, h->enc_stem, x, c.kernel_size, 1, false, rel_len, ws.act[cur], (long long)T * c.num_filters,
-                      c.num_filters, B, &y);
+    const bool dbg = h->dbg != nullptr;
+    Act xin{sig, (long long)T, 1, T, 1};
+    Act2 x, y;
+    int rc = conv_fwd(h, st, h->enc_stem, xin, c.kernel_size, 1, rel_len, Out{ws.take(), ws.take()},
+                      (long long)T * c.num_filters, c.num_filters, B, &x);
     if (rc) return rc;
-    x = y;
-    capture(h, st, x, B);
+    capture(h, st, x.raw, B);
     for (int i = 0; i < c.num_ratios; ++i) {
         const int ratio = c.upsampling_ratios[c.num_ratios - 1 - i];
-        const int hb = (cur + 1) % 3, ob = (cur + 2) % 3;
-        rc = resblock_fwd(h, st, h->enc_rb[i], x, ws.act[hb], ws.act[ob], B, &y);
+        float* hb = ws.take();
+        rc = resblock_fwd(h, st, h->enc_rb[i], x, hb, Out{dbg ? ws.take() : nullptr, ws.take()}, B, &y);
         if (rc) return rc;
+        ws.give(hb);
+        ws.give(x);
+        if (dbg) { capture(h, st, y.raw, B); ws.give(y.raw.p); y.raw.p = nullptr; }
         x = y;
-        capture(h, st, x, B);
-        cur = ob;
-        const int nb = (cur + 1) % 3;
-        const int M = cdiv(x.L, ratio);
-        rc = conv_fwd(h, st, h->enc_down[i], x, 2 * ratio, ratio, true, nullptr, ws.act[nb], (long long)M * h->enc_down[i].N,
-                      h->enc_down[i].N, B, &y);
+        const int M = cdiv(x.elu.L, ratio);
+        const bool last = i == c.num_ratios - 1;    // the last down-sampler feeds the LSTM: raw only
+        rc = conv_fwd(h, st, h->enc_down[i], x.elu, 2 * ratio, ratio, nullptr, Out{ws.take(), last ? nullptr : ws.take()},
+                      (long long)M * h->enc_down[i].N, h->enc_down[i].N, B, &y);
         if (rc) return rc;
+        ws.give(x);
         x = y;
-        capture(h, st, x, B);
-        cur = nb;
+        capture(h, st, x.raw, B);
     }
-    const int ob = (cur + 1) % 3;
-    rc = lstm_fwd(h, st, h->enc_lstm, x, ws.lstm, ws.act[ob], B, &y);
+    rc = lstm_fwd(h, st, h->enc_lstm, x.raw, ws.lstm, Out{dbg ? ws.take() : nullptr, ws.take()}, B, &y);
     if (rc) return rc;
+    ws.give(x);
+    if (dbg) { capture(h, st, y.raw, B); ws.give(y.raw.p); y.raw.p = nullptr; }
     x = y;
-    capture(h, st, x, B);
-    return conv_fwd(h, st, h->enc_final, x, c.last_kernel_size, 1, true, nullptr, feats, (long long)x.L * c.hidden_size,
-                    c.hidden_size, B, nullptr);
+    rc = conv_fwd(h, st, h->enc_final, x.elu, c.last_kernel_size, 1, nullptr, Out{feats, nullptr},
+                  (long long)x.elu.L * c.hidden_size, c.hidden_size, B, nullptr);
+    ws.give(x);
+    return rc;
+}
+
+int decoder_fwd(ac_handle* h, hipStream_t st, const long long* toks, int B, int N, int K, float* sig, WsPtrs& ws) {
+    const ac_config& c = h->cfg;
+    const bool dbg = h->dbg != nullptr;
+    float* zb = ws.take();
+    int rc = rvq_decode_fwd(h, st, toks, B * N, K, zb);
+    if (rc) return rc;
+    Act z{zb, (long long)N * c.hidden_size, c.hidden_size, N, c.hidden_size};
+    Act2 x, y;
+    rc = conv_fwd(h, st, h->dec_first, z, c.kernel_size, 1, nullptr, Out{ws.take(), nullptr}, (long long)N * h->D, h->D, B, &x);
+    if (rc) return rc;
+    ws.give(zb);
+    capture(h, st, x.raw, B);
+    rc = lstm_fwd(h, st, h->dec_lstm, x.raw, ws.lstm, Out{dbg ? ws.take() : nullptr, ws.take()}, B, &y);
+    if (rc) return rc;
+    ws.give(x);
+    if (dbg) { capture(h, st, y.raw, B); ws.give(y.raw.p); y.raw.p = nullptr; }
+    x = y;
+    for (int i = 0; i < c.num_ratios; ++i) {
+        rc = convtr_fwd(h, st, h->dec_up[i], x.elu, c.upsampling_ratios[i], Out{ws.take(), ws.take()}, B, &y);
+        if (rc) return rc;
+        ws.give(x);
+        x = y;
+        capture(h, st, x.raw, B);
+        float* hb = ws.take();
+        rc = resblock_fwd(h, st, h->dec_rb[i], x, hb, Out{dbg ? ws.take() : nullptr, ws.take()}, B, &y);
+        if (rc) return rc;
+        ws.give(hb);
+        ws.give(x);
+        if (dbg) { capture(h, st, y.raw, B); ws.give(y.raw.p); y.raw.p = nullptr; }
+        x = y;
+    }
+    rc = conv_fwd(h, st, h->dec_head, x.elu, c.last_kernel_size, 1, nullptr, Out{sig, nullptr}, (long long)x.elu.L, 1, B, nullptr);
+    ws.give(x);
+    return rc;
 }
 
 }  // namespace
@@ -858,39 +960,7 @@ int ac_decode(ac_handle* h, const int64_t* toks, int B, int N, int K, float* sig
     WsPtrs p;
     rc = carve(h, plan_ws(h, B, 0, N, false), ws, ws_bytes, &p);
     if (rc) return rc;
-    hipStream_t st = (hipStream_t)stream;
-    const ac_config& c = h->cfg;
-    int cur = 0;
-    rc = rvq_decode_fwd(h, st, reinterpret_cast<const long long*>(toks), B * N, K, p.act[cur]);
-    if (rc) return rc;
-    Act x{p.act[cur], (long long)N * c.hidden_size, c.hidden_size, N, c.hidden_size}, y;
-    int nb = (cur + 1) % 3;
-    rc = conv_fwd(h, st, h->dec_first, x, c.kernel_size, 1, false, nullptr, p.act[nb], (long long)N * h->D, h->D, B, &y);
-    if (rc) return rc;
-    x = y;
-    capture(h, st, x, B);
-    cur = nb;
-    nb = (cur + 1) % 3;
-    rc = lstm_fwd(h, st, h->dec_lstm, x, p.lstm, p.act[nb], B, &y);
-    if (rc) return rc;
-    x = y;
-    capture(h, st, x, B);
-    cur = nb;
-    for (int i = 0; i < c.num_ratios; ++i) {
-        nb = (cur + 1) % 3;
-        rc = convtr_fwd(h, st, h->dec_up[i], x, c.upsampling_ratios[i], p.act[nb], B, &y);
-        if (rc) return rc;
-        x = y;
-        capture(h, st, x, B);
-        cur = nb;
-        const int hb = (cur + 1) % 3, ob = (cur + 2) % 3;
-        rc = resblock_fwd(h, st, h->dec_rb[i], x, p.act[hb], p.act[ob], B, &y);
-        if (rc) return rc;
-        x = y;
-        capture(h, st, x, B);
-        cur = ob;
-    }
-    return conv_fwd(h, st, h->dec_head, x, c.last_kernel_size, 1, true, nullptr, sig, (long long)x.L, 1, B, nullptr);
+    return decoder_fwd(h, (hipStream_t)stream, reinterpret_cast<const long long*>(toks), B, N, K, sig, p);
 }
 
 int ac_embs(ac_handle* h, int K, float* embs, void* stream) {

@@ -16,6 +16,7 @@
 #include "tap_gemm.h"
 #include "tap_gemm2.h"
 #include "tap_gemm3.h"
+#include "tap_gemm4.h"
 
 using namespace ac;
 
@@ -73,6 +74,15 @@ void run_v3(TapGemmParams p, hipStream_t st) {
     hipLaunchKernelGGL((tap_gemm3_kernel<WGM, WGN, WM, WN>), dim3(p.B * p.mtiles * p.ntiles), dim3(Cfg::NT), Cfg::lds_bytes, st, p);
 }
 
+template <int WGM, int WGN, int WM, int WN>
+void run_v4(TapGemmParams p, hipStream_t st) {
+    using Cfg = Tap4Cfg<WGM, WGN, WM, WN>;
+    p.mtiles = (p.M + Cfg::BM - 1) / Cfg::BM; p.ntiles = (p.N + Cfg::BN - 1) / Cfg::BN;
+    static bool once = false;
+    if (!once) { once = true; CK(hipFuncSetAttribute((const void*)tap_gemm4_kernel<WGM, WGN, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::lds_bytes)); }
+    hipLaunchKernelGGL((tap_gemm4_kernel<WGM, WGN, WM, WN>), dim3(p.B * p.mtiles * p.ntiles), dim3(Cfg::NT), Cfg::lds_bytes, st, p);
+}
+
 struct Variant { std::string name; std::function<void(TapGemmParams, hipStream_t)> fn; };
 
 int main(int argc, char** argv) {
@@ -104,14 +114,15 @@ int main(int argc, char** argv) {
         CK(hipMemcpy(dw, hw.data(), nw * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(db, hb.data(), ly.N * 4, hipMemcpyHostToDevice));
         TapGemmParams p{};
         p.nseg = ly.cin2 ? 2 : 1;
-        p.seg[0] = mkseg(dx, ly.L, ly.cin, ly.s, ly.J, ly.reflect, ly.elu, extra, 0);
+        p.seg[0] = mkseg(dx, ly.L, ly.cin, ly.s, ly.J, ly.reflect, 0, extra, 0);
         if (ly.cin2) p.seg[1] = mkseg(dx2, ly.L, ly.cin2, 1, 1, 1, 0, 0, K1);
-        p.w = dw; p.bias = db; p.y = dy; p.y_bs = (long long)M * ly.N; p.y_rs = ly.N; p.B = B; p.M = M; p.N = ly.N; p.Ktot = Ktot;
+        p.w = dw; p.bias = db; p.y = dy; p.y_elu = nullptr; p.y_bs = (long long)M * ly.N; p.y_rs = ly.N; p.B = B; p.M = M; p.N = ly.N; p.Ktot = Ktot;
         std::vector<Variant> vs;
-        if (ly.N <= 16) { vs.push_back({"v1<4,1,2,1>", run_v1<4, 1, 2, 1>}); vs.push_back({"v2<4,1,2,1>", run_v2<4, 1, 2, 1>}); vs.push_back({"v3<4,1,2,1>", run_v3<4, 1, 2, 1>}); }
-        else if (ly.N <= 32) { vs.push_back({"v1<4,1,2,2>", run_v1<4, 1, 2, 2>}); vs.push_back({"v2<4,1,2,2>", run_v2<4, 1, 2, 2>}); vs.push_back({"v3<4,1,2,2>", run_v3<4, 1, 2, 2>}); }
-        else if (ly.N <= 64) { vs.push_back({"v1<2,2,2,2>", run_v1<2, 2, 2, 2>}); vs.push_back({"v2<2,2,2,2>", run_v2<2, 2, 2, 2>}); vs.push_back({"v3<2,2,2,2>", run_v3<2, 2, 2, 2>}); vs.push_back({"v3<4,1,2,4>", run_v3<4, 1, 2, 4>}); }
-        else { vs.push_back({"v1<2,2,4,4>", run_v1<2, 2, 4, 4>}); vs.push_back({"v2<2,2,4,4>", run_v2<2, 2, 4, 4>}); vs.push_back({"v3<2,2,4,4>", run_v3<2, 2, 4, 4>}); vs.push_back({"v3<2,2,2,4>", run_v3<2, 2, 2, 4>}); }
+        const bool fast = (ly.s * ly.cin) % 32 == 0 && (ly.cin2 % 32) == 0 && ly.N % 4 == 0;
+        if (ly.N <= 16) { vs.push_back({"v1<4,1,2,1>", run_v1<4, 1, 2, 1>}); if (fast) vs.push_back({"v4<4,1,2,1>", run_v4<4, 1, 2, 1>}); }
+        else if (ly.N <= 32) { vs.push_back({"v1<4,1,2,2>", run_v1<4, 1, 2, 2>}); if (fast) { vs.push_back({"v4<4,1,2,2>", run_v4<4, 1, 2, 2>}); vs.push_back({"v4<4,1,4,2>", run_v4<4, 1, 4, 2>}); } }
+        else if (ly.N <= 64) { vs.push_back({"v1<2,2,2,2>", run_v1<2, 2, 2, 2>}); if (fast) { vs.push_back({"v4<2,2,2,2>", run_v4<2, 2, 2, 2>}); vs.push_back({"v4<4,1,2,4>", run_v4<4, 1, 2, 4>}); vs.push_back({"v4<2,2,4,2>", run_v4<2, 2, 4, 2>}); } }
+        else { vs.push_back({"v1<2,2,4,4>", run_v1<2, 2, 4, 4>}); vs.push_back({"v4<2,2,4,4>", run_v4<2, 2, 4, 4>}); vs.push_back({"v4<4,2,4,4>", run_v4<4, 2, 4, 4>}); vs.push_back({"v4<2,4,4,4>", run_v4<2, 4, 4, 4>}); vs.push_back({"v4<4,2,2,4>", run_v4<4, 2, 2, 4>}); }
         const double flops = 2.0 * B * (double)M * ly.N * Ktot;
         const double bytes = (double)(nx + (ly.cin2 ? nx2 : 0) + ny + nw) * 4.0;
         std::vector<double> best(vs.size(), 1e30);

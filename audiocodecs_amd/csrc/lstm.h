@@ -25,6 +25,7 @@ struct LstmStepParams {
     const float* wpk;    // packed W_hh: [D/4 unit groups][D/16 ksteps][64 lanes][4]
     const float* skip;   // optional: module input x[b][t][:] (row b at skip + b*skip_bs)
     float* yout;         // optional: yout[b][:] = h + skip (row b at yout + b*y_bs)
+    float* yout_elu;     // optional: ELU(h + skip), same layout (the consumer conv starts with nn.ELU)
     long long skip_bs, y_bs;
     int B, D, first;
 };
@@ -85,7 +86,11 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(const LstmStepParams p) 
             const float hn = og * tanhf(cn);
             p.c[o] = cn;
             p.hnext[o] = hn;
-            if (p.yout) p.yout[(long long)b * p.y_bs + u] = hn + p.skip[(long long)b * p.skip_bs + u];
+            if (p.yout || p.yout_elu) {
+                const float yv = hn + p.skip[(long long)b * p.skip_bs + u];
+                if (p.yout) p.yout[(long long)b * p.y_bs + u] = yv;
+                if (p.yout_elu) p.yout_elu[(long long)b * p.y_bs + u] = elu1(yv);
+            }
         }
     }
 }

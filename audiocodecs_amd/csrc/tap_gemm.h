@@ -53,7 +53,10 @@ struct TapGemmParams {
     int nseg;
     const float* w;     // packed [N][Ktot], K contiguous; k = kofs + j*Cw + c
     const float* bias;  // [N]
-    float* y;           // out[b*y_bs + m*y_rs + n]
+    float* y;           // out[b*y_bs + m*y_rs + n] (may be null when only y_elu is wanted)
+    float* y_elu;       // optional second output ELU(out), same strides: the consumer layers of the
+                        // SEANet stack all start with nn.ELU, so activations are activated ONCE here, in
+                        // the producing layer's epilogue, not on every staged load (profiles/r1_tapgemm_investigation.md)
     long long y_bs, y_rs;
     int B, M, N, Ktot;
     int mtiles, ntiles;
@@ -64,6 +67,11 @@ struct TapGemmParams {
 // <= ~1.2e-7, the same class as the reference's own vectorised expf, at 5 instructions per element
 // instead of ~15 -- staging instruction count bounds the MFMA kernels (profiles/r1_tapgemm_trace.md).
 __device__ __forceinline__ float elu1(float v) { return v > 0.f ? v : (__expf(v) - 1.0f); }
+
+__device__ __forceinline__ f32x4 elu4(f32x4 v) {
+    v.x = elu1(v.x); v.y = elu1(v.y); v.z = elu1(v.z); v.w = elu1(v.w);
+    return v;
+}
 
 constexpr int KC = 32;        // K chunk staged per iteration
 constexpr int KCP = KC + 4;   // LDS pitch (floats): keeps 16-B alignment, spreads banks
@@ -193,7 +201,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void tap_gemm_kernel(const TapGemmPa
         }
     }
     // ---- epilogue: C layout of 16x16x4: col = lane&15, row = (lane>>4)*4 + reg
-    float* yb = p.y + (long long)b * p.y_bs;
+    const long long yoff = (long long)b * p.y_bs;
 #pragma unroll
     for (int a = 0; a < WM; ++a)
 #pragma unroll
@@ -204,7 +212,11 @@ __global__ __launch_bounds__(WGM* WGN * 64) void tap_gemm_kernel(const TapGemmPa
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int m = m0 + (wm * WM + a) * 16 + kq * 4 + r;
-                    if (m < p.M) yb[(long long)m * p.y_rs + n] = acc[a][c][r] + bv;
+                    if (m < p.M) {
+                        const float v = acc[a][c][r] + bv;
+                        if (p.y) p.y[yoff + (long long)m * p.y_rs + n] = v;
+                        if (p.y_elu) p.y_elu[yoff + (long long)m * p.y_rs + n] = elu1(v);
+                    }
                 }
             }
         }

@@ -25,10 +25,6 @@ struct TapCfg {
     static constexpr size_t lds_bytes = main_bytes > epi_bytes ? main_bytes : epi_bytes;
 };
 
-__device__ __forceinline__ f32x4 elu4(f32x4 v) {
-    v.x = elu1(v.x); v.y = elu1(v.y); v.z = elu1(v.z); v.w = elu1(v.w);
-    return v;
-}
 
 template <int WGM, int WGN, int WM, int WN>
 __global__ __launch_bounds__(WGM* WGN * 64) void tap_gemm2_kernel(const TapGemmParams p) {

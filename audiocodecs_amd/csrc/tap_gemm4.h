@@ -1,0 +1,258 @@
+// tap_gemm v4: the fast tap-GEMM (tap_gemm.h documents the conv -> GEMM mapping; the generic kernel
+// there remains the fallback for odd shapes).  Built on this round's measurements
+// (profiles/r1_tapgemm_investigation.md): on gfx950 the fp32-input MFMA shares the fp32 vector
+// lanes, so every VALU instruction -- from any wave of the SIMD -- costs ~4 cycles of matrix time.
+// The main loop therefore carries almost no VALU work:
+//   * inputs arrive already activated (ELU is applied once, in the producing layer's epilogue);
+//   * each thread owns a fixed set of 16-byte staging slots; their global byte offsets and LDS
+//     addresses are computed once per segment; per stage the loads are buffer_load_dwordx4 with
+//     that constant VGPR offset and a scalar (SGPR) chunk offset;
+//   * next stage's loads are issued before the MFMA phase and written to the other LDS buffer
+//     after it: one barrier per stage;
+//   * tiles that touch a clip edge (reflect / zero padding, ragged tail) take a slow, exact path
+//     for their loads only -- two tiles per clip.
+// Requirements (host-checked): every segment has s*cin % 32 == 0, 16-byte aligned bases, no length
+// mask, and contiguous time steps (ts == cin) unless s == 1, where ts is simply the row pitch.
+#pragma once
+#include "tap_gemm.h"
+
+namespace ac {
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+template <int WGM, int WGN, int WM, int WN>
+struct Tap4Cfg {
+    static constexpr int BM = WGM * WM * 16, BN = WGN * WN * 16, NT = WGM * WGN * 64;
+    static constexpr int MAXJ = 8;
+    static constexpr int A_ROWS = BM + MAXJ - 1;
+    static constexpr int A_SLOTS = (A_ROWS * (KC / 4) + NT - 1) / NT;
+    static constexpr int W_SLOTS = (BN * (KC / 4) + NT - 1) / NT;
+    static constexpr int A_FLOATS = A_ROWS * KCP, W_FLOATS = BN * KCP;
+    static constexpr int CP = BN + 4;
+    static constexpr size_t main_bytes = (size_t)(2 * A_FLOATS + 2 * W_FLOATS) * 4;
+    static constexpr size_t epi_bytes = (size_t)BM * CP * 4;
+    static constexpr size_t lds_bytes = main_bytes > epi_bytes ? main_bytes : epi_bytes;
+};
+
+__device__ __forceinline__ f32x4 bufload16(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
+}
+
+#ifdef TAP4_TRACE
+__device__ unsigned long long* g_tap4_trace;   // [slot][wave][stage][5]
+#define TRC4(st, k) do { if (trace_on && lane == 0 && (st) < 64) g_tap4_trace[((trace_slot * 4 + wave) * 64 + (st)) * 5 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define TRC4(st, k) do {} while (0)
+#endif
+
+template <int WGM, int WGN, int WM, int WN>
+__global__ __launch_bounds__(WGM* WGN * 64) void tap_gemm4_kernel(const TapGemmParams p) {
+    using Cfg = Tap4Cfg<WGM, WGN, WM, WN>;
+    constexpr int BM = Cfg::BM, BN = Cfg::BN, NT = Cfg::NT;
+    constexpr int A_SLOTS = Cfg::A_SLOTS, W_SLOTS = Cfg::W_SLOTS;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As0 = smem;
+    float* Ws0 = smem + 2 * Cfg::A_FLOATS;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int li = lane & 15, kq = lane >> 4;
+#ifdef TAP4_TRACE
+    const bool trace_on = g_tap4_trace && (blockIdx.x == 700 || blockIdx.x == 701);
+    const int trace_slot = blockIdx.x - 700;
+    int trc_stage = 0;
+#endif
+
+    int id = blockIdx.x;
+    const int nt = id % p.ntiles; id /= p.ntiles;
+    const int mt = id % p.mtiles;
+    const int b = id / p.mtiles;
+    const int m0 = mt * BM, n0 = nt * BN;
+
+    f32x4 acc[WM][WN];
+#pragma unroll
+    for (int a = 0; a < WM; ++a)
+#pragma unroll
+        for (int c = 0; c < WN; ++c) acc[a][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- per-slot constants
+    int a_lds[A_SLOTS], a_boff[A_SLOTS];
+    int w_lds[W_SLOTS], w_boff[W_SLOTS];
+#pragma unroll
+    for (int i = 0; i < A_SLOTS; ++i) {
+        const int e = tid + i * NT;
+        a_lds[i] = (e / (KC / 4)) < Cfg::A_ROWS ? (e / (KC / 4)) * KCP + 4 * (e % (KC / 4)) : -1;
+    }
+#pragma unroll
+    for (int i = 0; i < W_SLOTS; ++i) {
+        const int e = tid + i * NT;
+        const int n = e / (KC / 4), q = e % (KC / 4);
+        w_lds[i] = n < BN ? n * KCP + 4 * q : -1;
+        const int ng = min(n0 + (n < BN ? n : 0), p.N - 1);   // columns past N: read a valid row, never stored
+        w_boff[i] = (ng * p.Ktot + 4 * q) * 4;
+    }
+    const __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.N * p.Ktot * 4, 0x00020000);
+
+    // ---- segment state (wave-uniform)
+    int si = 0, c0 = 0, j = 0;
+    int seg_J, seg_Cw, seg_kofs;
+    bool seg_interior;
+    __amdgpu_buffer_rsrc_t a_rs;
+    auto enter_segment = [&](int s_) {
+        const TapSeg& sg = p.seg[s_];
+        seg_J = sg.J;
+        seg_Cw = sg.s * sg.cin;
+        seg_kofs = sg.kofs;
+        const long long lo = (long long)(m0 - (sg.J - 1)) * sg.s;
+        const long long hi = (long long)(m0 + BM - 1) * sg.s + (sg.s - 1);
+        seg_interior = lo >= 0 && hi < sg.L;
+        const int pitch = sg.s == 1 ? (int)sg.ts : seg_Cw;   // floats between consecutive reshaped rows
+        a_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(sg.x + (long long)b * sg.bs), 0,
+                                                 (int)(((long long)(sg.L - 1) * sg.ts + sg.cin) * 4), 0x00020000);
+        const int R = BM + sg.J - 1;
+#pragma unroll
+        for (int i = 0; i < A_SLOTS; ++i) {
+            const int e = tid + i * NT;
+            const int row = e / (KC / 4), q = e % (KC / 4);
+            a_boff[i] = ((m0 - (sg.J - 1) + (row < R ? row : sg.J - 1)) * pitch + 4 * q) * 4;   // rows past R: any valid row
+        }
+    };
+    f32x4 ra[A_SLOTS], rw[W_SLOTS];
+    auto load_a = [&](int s_, int c_) {
+        if (seg_interior) {
+#pragma unroll
+            for (int i = 0; i < A_SLOTS; ++i) ra[i] = bufload16(a_rs, a_boff[i], c_ * 4);
+        } else {
+            // exact edge handling ([HF]:139-162 reflect rule, zero pad of the transposed conv, ragged tail)
+            const TapSeg& sg = p.seg[s_];
+            const int R = BM + sg.J - 1;
+            const float* xb = sg.x + (long long)b * sg.bs;
+#pragma unroll
+            for (int i = 0; i < A_SLOTS; ++i) {
+                const int e = tid + i * NT;
+                const int row = e / (KC / 4), q = e % (KC / 4);
+                const int c = c_ + 4 * q;
+                const int tp = sg.cin_shift >= 0 ? (c >> sg.cin_shift) : (c / sg.cin);
+                const long long jj = row < R ? src_index(sg, (m0 - (sg.J - 1) + row) * sg.s + tp) : -1;
+                ra[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (jj >= 0) ra[i] = *reinterpret_cast<const f32x4*>(xb + jj * sg.ts + (c - tp * sg.cin));
+            }
+        }
+    };
+    auto load_w = [&](int c_, int j_) {
+        const int soff = (seg_kofs + j_ * seg_Cw + c_) * 4;
+#pragma unroll
+        for (int i = 0; i < W_SLOTS; ++i) rw[i] = bufload16(w_rs, w_boff[i], soff);
+    };
+    auto store_a = [&](float* dst) {
+#pragma unroll
+        for (int i = 0; i < A_SLOTS; ++i)
+            if (a_lds[i] >= 0) *reinterpret_cast<f32x4*>(&dst[a_lds[i]]) = ra[i];
+    };
+    auto store_w = [&](float* dst) {
+#pragma unroll
+        for (int i = 0; i < W_SLOTS; ++i)
+            if (w_lds[i] >= 0) *reinterpret_cast<f32x4*>(&dst[w_lds[i]]) = rw[i];
+    };
+
+    // ---- prologue: stage 0 into buffers 0
+    enter_segment(0);
+    load_a(0, 0);
+    load_w(0, 0);
+    store_a(As0);
+    store_w(Ws0);
+    __syncthreads();
+    int abuf = 0, wbuf = 0;
+    const int a_frag = (wm * WM * 16 + li) * KCP + 4 * kq;   // + (a*16 + j)*KCP + ks*16
+    const int w_frag = (wn * WN * 16 + li) * KCP + 4 * kq;
+
+    for (;;) {
+        // next stage coordinates (uniform)
+        int nsi = si, nc0 = c0, nj = j + 1;
+        bool new_chunk = false;
+        if (nj == seg_J) {
+            nj = 0;
+            nc0 = c0 + KC;
+            new_chunk = true;
+            if (nc0 >= seg_Cw) { nc0 = 0; nsi = si + 1; }
+        }
+        const bool has_next = nsi < p.nseg;
+        const int cur_j = j;
+        TRC4(trc_stage, 0);
+        if (has_next) {
+            if (nsi != si) enter_segment(nsi);
+            if (new_chunk) load_a(nsi, nc0);
+            load_w(nc0, nj);
+        }
+        TRC4(trc_stage, 1);
+        // ---- MFMA over the current stage.  All fragments of the stage are read up front; the LDS
+        // writes of the NEXT stage's data (other buffers) sit between the two k-steps, so the end
+        // of the stage is just the barrier.
+        const float* Ac = As0 + abuf * Cfg::A_FLOATS + a_frag + cur_j * KCP;
+        const float* Wc = Ws0 + wbuf * Cfg::W_FLOATS + w_frag;
+        f32x4 af[KC / 16][WM], bf[KC / 16][WN];
+#pragma unroll
+        for (int ks = 0; ks < KC / 16; ++ks) {
+#pragma unroll
+            for (int a = 0; a < WM; ++a) af[ks][a] = *reinterpret_cast<const f32x4*>(&Ac[a * 16 * KCP + ks * 16]);
+#pragma unroll
+            for (int c = 0; c < WN; ++c) bf[ks][c] = *reinterpret_cast<const f32x4*>(&Wc[c * 16 * KCP + ks * 16]);
+        }
+#pragma unroll
+        for (int ks = 0; ks < KC / 16; ++ks) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int a = 0; a < WM; ++a)
+#pragma unroll
+                    for (int c = 0; c < WN; ++c)
+                        acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[ks][a][u], bf[ks][c][u], acc[a][c], 0, 0, 0);
+            if (ks == 0 && has_next) {
+                if (new_chunk) {
+                    abuf ^= 1;
+                    store_a(As0 + abuf * Cfg::A_FLOATS);
+                }
+                wbuf ^= 1;
+                store_w(Ws0 + wbuf * Cfg::W_FLOATS);
+            }
+        }
+        TRC4(trc_stage, 2);
+        if (!has_next) break;
+        TRC4(trc_stage, 3);
+        __syncthreads();
+        TRC4(trc_stage, 4);
+#ifdef TAP4_TRACE
+        ++trc_stage;
+#endif
+        si = nsi; c0 = nc0; j = nj;
+    }
+
+    // ---- epilogue through LDS: Cs[m][n] = acc + bias, then row-contiguous 16-byte stores of y / ELU(y)
+    __syncthreads();
+    float* Cs = smem;
+    constexpr int CP = Cfg::CP;
+#pragma unroll
+    for (int a = 0; a < WM; ++a)
+#pragma unroll
+        for (int c = 0; c < WN; ++c) {
+            const int n = (wn * WN + c) * 16 + li;
+            const float bv = (p.bias && n0 + n < p.N) ? p.bias[n0 + n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Cs[((wm * WM + a) * 16 + kq * 4 + r) * CP + n] = acc[a][c][r] + bv;
+        }
+    __syncthreads();
+    const long long yoff = (long long)b * p.y_bs;
+    for (int e = tid; e < BM * (BN / 4); e += NT) {
+        const int row = e / (BN / 4), q = e % (BN / 4);
+        const int m = m0 + row, n = n0 + 4 * q;
+        if (m < p.M && n < p.N) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(&Cs[row * CP + 4 * q]);
+            const long long o = yoff + (long long)m * p.y_rs + n;
+            if (p.y) *reinterpret_cast<f32x4*>(p.y + o) = v;
+            if (p.y_elu) *reinterpret_cast<f32x4*>(p.y_elu + o) = elu4(v);
+        }
+    }
+}
+
+}  // namespace ac
