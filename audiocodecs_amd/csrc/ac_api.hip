@@ -40,7 +40,8 @@ struct ResBlockPlan {
 struct LstmPlan {
     int D, layers;
     std::vector<PackedGemm> ih;     // [4D][D] + (b_ih + b_hh)
-    std::vector<size_t> hh_off;     // packed W_hh per layer
+    std::vector<size_t> hh_off;     // W_hh per layer, MFMA B-fragment order
+    std::vector<size_t> ihpk_off;   // W_ih per layer, same order (used by the in-step projection of layers >= 1)
 };
 
 struct ProfRec {
@@ -293,6 +294,17 @@ struct Packer {
                             blob[off + (((size_t)ug * (D / 16) + ks) * 64 + lane) * 4 + u] = (*whh)[(size_t)row * D + k];
                         }
             lp.hh_off.push_back(off);
+            const size_t off2 = reserve((size_t)4 * D * D);
+            for (int ug = 0; ug < D / 4; ++ug)
+                for (int ks = 0; ks < D / 16; ++ks)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int u = 0; u < 4; ++u) {
+                            const int j = lane & 15, kq = lane >> 4;
+                            const int row = (j >> 2) * D + ug * 4 + (j & 3);
+                            const int k = ks * 16 + 4 * kq + u;
+                            blob[off2 + (((size_t)ug * (D / 16) + ks) * 64 + lane) * 4 + u] = (*wih)[(size_t)row * D + k];
+                        }
+            lp.ihpk_off.push_back(off2);
         }
         return true;
     }
@@ -535,21 +547,21 @@ void capture(ac_handle* h, hipStream_t st, const Act& a, int B) {
 }
 
 struct LstmWs {
-    float *gin, *hseq0, *hseq1, *c;
+    float *gin, *gin1, *hseq0, *hseq1, *c;   // c holds one [B][D] cell state per layer
 };
 
 // x [B][T][D] (standard layout) -> lstm(x) + x as raw and/or ELU'd [B][T][D]
 int lstm_fwd(ac_handle* h, hipStream_t st, const LstmPlan& lp, const Act& x, const LstmWs& ws, Out out, int B, Act2* y) {
-    const int D = lp.D, T = x.L;
-    if (D % 32 != 0) return fail(h, AC_EINVAL, "LSTM width %d must be a multiple of 32", D);
-    Act in = x;
-    for (int l = 0; l < lp.layers; ++l) {
-        // input projection for all t: gin[t][b][4D]
+    const int D = lp.D, T = x.L, L = lp.layers;
+    if (D % 64 != 0 || D > 512) return fail(h, AC_EINVAL, "LSTM width %d unsupported (need 64, 128, 256 or 512)", D);
+    if (L < 1 || L > 2) return fail(h, AC_EINVAL, "%d LSTM layers unsupported (1 or 2)", L);
+    // layer-0 input projection for all t: gin[t][b][4D]
+    {
         TapGemmParams p{};
         p.nseg = 1;
-        p.seg[0] = make_seg(in, 1, 1, false, 0, 0, nullptr);
-        p.w = h->blob + lp.ih[l].w_off;
-        p.bias = h->blob + lp.ih[l].b_off;
+        p.seg[0] = make_seg(x, 1, 1, false, 0, 0, nullptr);
+        p.w = h->blob + lp.ih[0].w_off;
+        p.bias = h->blob + lp.ih[0].b_off;
         p.y = ws.gin;
         p.y_bs = 4LL * D;
         p.y_rs = (long long)B * 4 * D;
@@ -559,35 +571,65 @@ int lstm_fwd(ac_handle* h, hipStream_t st, const LstmPlan& lp, const Act& x, con
         p.Ktot = D;
         int rc = run_tap(h, st, p);
         if (rc) return rc;
-        float* hseq = (l & 1) ? ws.hseq1 : ws.hseq0;
-        const bool last = l == lp.layers - 1;
-        {
-            ProfScope ps(h, st, "lstm_step_kernel", 2.0 * T * (double)B * 4 * D * D,
-                         (double)T * ((double)B * 4 * D * 4 + 4.0 * D * D * 4 + 2.0 * B * D * 4), T);
-            for (int t = 0; t < T; ++t) {
-                LstmStepParams q{};
-                q.gin = ws.gin + (long long)t * B * 4 * D;
-                q.gin_bs = 4LL * D;
-                q.hprev = t ? hseq + (long long)(t - 1) * B * D : nullptr;
-                q.hnext = hseq + (long long)t * B * D;
-                q.c = ws.c;
-                q.wpk = h->blob + lp.hh_off[l];
-                q.B = B;
-                q.D = D;
-                q.first = t == 0;
-                if (last) {
-                    q.skip = x.p + (long long)t * x.ts;
-                    q.skip_bs = x.bs;
-                    q.yout = out.raw ? out.raw + (long long)t * D : nullptr;
-                    q.yout_elu = out.elu ? out.elu + (long long)t * D : nullptr;
-                    q.y_bs = (long long)T * D;
-                }
-                hipLaunchKernelGGL(lstm_step_kernel, dim3(D / 4, cdiv(B, 32)), dim3(256), 0, st, q);
+    }
+    const int nroles = 2 * L - 1, nlaunch = T + 2 * (L - 1);
+    const long long BD = (long long)B * D, B4D = (long long)B * 4 * D;
+    {
+        ProfScope ps(h, st, "lstm_step_kernel", 2.0 * T * (double)B * 4 * D * D * nroles,
+                     (double)T * nroles * ((double)B * 4 * D * 4 + 4.0 * D * D * 4 + 2.0 * B * D * 4), nlaunch);
+        for (int s = 0; s < nlaunch; ++s) {
+            LstmLaunchParams q{};
+            q.B = B;
+            q.D = D;
+            auto fill_last = [&](LstmRole& r, int t) {
+                r.skip = x.p + (long long)t * x.ts;
+                r.skip_bs = x.bs;
+                r.yout = out.raw ? out.raw + (long long)t * D : nullptr;
+                r.yout_elu = out.elu ? out.elu + (long long)t * D : nullptr;
+                r.y_bs = (long long)T * D;
+            };
+            {   // role 0: layer-0 cell step, t = s
+                LstmRole& r = q.role[0];
+                r.active = s < T;
+                r.kind = 0;
+                r.a = s > 0 ? ws.hseq0 + (long long)(s - 1) * BD : nullptr;
+                r.wpk = h->blob + lp.hh_off[0];
+                r.gin = ws.gin + (long long)s * B4D;
+                r.hnext = ws.hseq0 + (long long)s * BD;
+                r.c = ws.c;
+                r.first = s == 0;
+                if (L == 1 && r.active) fill_last(r, s);
+            }
+            if (L == 2) {
+                const int t1 = s - 1, t2 = s - 2;
+                LstmRole& pr = q.role[1];   // layer-1 input projection, t = s-1
+                pr.active = t1 >= 0 && t1 < T;
+                pr.kind = 1;
+                pr.a = ws.hseq0 + (long long)std::max(t1, 0) * BD;
+                pr.wpk = h->blob + lp.ihpk_off[1];
+                pr.bias = h->blob + lp.ih[1].b_off;
+                pr.gout = ws.gin1 + (long long)std::max(t1, 0) * B4D;
+                LstmRole& r = q.role[2];    // layer-1 cell step, t = s-2
+                r.active = t2 >= 0 && t2 < T;
+                r.kind = 0;
+                r.a = t2 > 0 ? ws.hseq1 + (long long)(t2 - 1) * BD : nullptr;
+                r.wpk = h->blob + lp.hh_off[1];
+                r.gin = ws.gin1 + (long long)std::max(t2, 0) * B4D;
+                r.hnext = ws.hseq1 + (long long)std::max(t2, 0) * BD;
+                r.c = ws.c + BD;
+                r.first = t2 == 0;
+                if (r.active) fill_last(r, t2);
+            }
+            const dim3 grid(D / 4, cdiv(B, 32), nroles), block(256);
+            switch (D / 32) {
+                case 2: hipLaunchKernelGGL(lstm_step_kernel<2>, grid, block, 0, st, q); break;
+                case 4: hipLaunchKernelGGL(lstm_step_kernel<4>, grid, block, 0, st, q); break;
+                case 8: hipLaunchKernelGGL(lstm_step_kernel<8>, grid, block, 0, st, q); break;
+                default: hipLaunchKernelGGL(lstm_step_kernel<16>, grid, block, 0, st, q); break;
             }
         }
-        HIPCHK(h, hipGetLastError());
-        in = Act{hseq, (long long)D, (long long)B * D, T, D};
     }
+    HIPCHK(h, hipGetLastError());
     y->raw = Act{out.raw, (long long)T * D, D, T, D};
     y->elu = Act{out.elu, (long long)T * D, D, T, D};
     return AC_OK;
@@ -677,8 +719,8 @@ Workspace plan_ws(const ac_handle* h, int B, int T_in /*samples, encoder*/, int 
     w.act_floats = align_up(mx * B, 64);
     w.gin = align_up((size_t)N * B * 4 * h->D, 64);
     w.hseq = align_up((size_t)N * B * h->D, 64);
-    w.c = align_up((size_t)B * h->D, 64);
-    w.total_bytes = (NACT * w.act_floats + w.gin + 2 * w.hseq + w.c) * sizeof(float) + 256;
+    w.c = align_up((size_t)2 * B * h->D, 64);
+    w.total_bytes = (NACT * w.act_floats + 2 * w.gin + 2 * w.hseq + w.c) * sizeof(float) + 256;
     return w;
 }
 
@@ -704,6 +746,7 @@ int carve(ac_handle* h, const Workspace& w, void* ws, size_t ws_bytes, WsPtrs* o
     float* p = reinterpret_cast<float*>(align_up(reinterpret_cast<uintptr_t>(ws), 256));
     for (int i = 0; i < NACT; ++i) { o->act[i] = p; o->used[i] = false; p += w.act_floats; }
     o->lstm.gin = p; p += w.gin;
+    o->lstm.gin1 = p; p += w.gin;
     o->lstm.hseq0 = p; p += w.hseq;
     o->lstm.hseq1 = p; p += w.hseq;
     o->lstm.c = p;
@@ -808,7 +851,7 @@ int ac_create(const ac_config* cfg, ac_handle** out) {
     *out = nullptr;
     if (cfg->struct_size != (int32_t)sizeof(ac_config)) return AC_EINVAL;
     if (cfg->num_ratios < 1 || cfg->num_ratios > AC_MAX_RATIOS || cfg->num_filters < 1 || cfg->hidden_size < 16 ||
-        cfg->hidden_size % 16 || cfg->compress < 1 || cfg->num_lstm_layers < 1 || cfg->codebook_size % 16 ||
+        cfg->hidden_size % 16 || cfg->compress < 1 || cfg->num_lstm_layers < 1 || cfg->num_lstm_layers > 2 || cfg->codebook_size % 16 ||
         cfg->codebook_size < 16 || cfg->num_quantizers < 1 || cfg->kernel_size < 1 || cfg->kernel_size > 8 ||
         cfg->last_kernel_size < 1 || cfg->last_kernel_size > 8 || cfg->residual_kernel_size < 1 || cfg->residual_kernel_size > 8)
         return AC_EINVAL;

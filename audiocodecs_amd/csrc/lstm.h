@@ -1,96 +1,132 @@
 // LSTM recurrence of [HF] EncodecLSTM (:236-249): nn.LSTM(D, D, num_layers) over [T,B,D], zero
 // initial state, gate order i,f,g,o, followed by the module's skip connection (out + in).
 //
-// The input projection x_t * W_ih^T + (b_ih + b_hh) for ALL t is one tap_gemm (the 1-tap case)
-// written as gin[t][b][4D].  What is left is inherently sequential in t: one launch per time step
-// (a dependent kernel boundary costs ~1.5 us on MI355X -- cheaper than an in-kernel grid barrier).
+// The input projection of layer 0, x_t * W_ih^T + (b_ih + b_hh) for ALL t, is one tap_gemm (the 1-tap
+// case) written as gin[t][b][4D].  What is left is inherently sequential in t.  One launch per time
+// step (a dependent kernel boundary costs ~1.5-4 us on MI355X, no more than an in-kernel grid barrier
+// and without its residency hazards); the layers are pipelined ACROSS launches ("wavefront"): launch s
+// runs, as independent workgroup roles,
+//     role 0: layer-0 cell step            t = s
+//     role 1: layer-1 input projection     t = s-1   (W_ih1 * h0[t], needs only launch s-1's result)
+//     role 2: layer-1 cell step            t = s-2
+// so a 2-layer LSTM over T steps takes T+2 launches instead of 2T (+ no separate projection GEMM).
 //
-// Decomposition per step: workgroup = 32 clips x 4 hidden units (= 16 gate columns: 4 gates x 4
-// units, so the cell update is local to the workgroup).  4 waves = 2 clip sub-tiles x 2 K-halves;
-// each wave runs v_mfma_f32_16x16x4_f32 over its half of K = D with the A operand (h_{t-1}) and
-// the B operand (W_hh slice, pre-packed in fragment order) loaded straight from L2 into registers
-// as 16-byte vectors; the two K-halves meet in LDS, then 128 threads finish the cell.
+// Per role and step: workgroup = 32 clips x 4 hidden units (= 16 gate columns: 4 gates x 4 units, so
+// the cell update is local to the workgroup).  4 waves = 2 clip sub-tiles x 2 K-halves; each wave
+// runs v_mfma_f32_16x16x4_f32 over its half of K = D with the A operand (h_{t-1} or h0[t]) and the B
+// operand (weight slice, pre-packed in fragment order) loaded straight from L2 into registers as
+// 16-byte vectors -- all loads of the step issued up front; the K-halves meet in LDS, then 128
+// threads finish the cell (their gin / c / skip operands were prefetched before the MFMAs).
 #pragma once
 #include <hip/hip_runtime.h>
 #include "tap_gemm.h"
 
 namespace ac {
 
-struct LstmStepParams {
-    const float* gin;    // [B][4D] slice for this t (row b at gin + b*gin_bs)
-    long long gin_bs;
-    const float* hprev;  // [B][D] or nullptr (t == 0: h = 0)
-    float* hnext;        // [B][D]
-    float* c;            // [B][D] cell state (zeroed before t == 0)
-    const float* wpk;    // packed W_hh: [D/4 unit groups][D/16 ksteps][64 lanes][4]
-    const float* skip;   // optional: module input x[b][t][:] (row b at skip + b*skip_bs)
-    float* yout;         // optional: yout[b][:] = h + skip (row b at yout + b*y_bs)
-    float* yout_elu;     // optional: ELU(h + skip), same layout (the consumer conv starts with nn.ELU)
+struct LstmRole {
+    int active;          // 0: this role idles in this launch
+    int kind;            // 0: cell step, 1: input projection (writes gin of the next layer)
+    const float* a;      // [B][D] A operand rows (h_{t-1} for a step, lower layer's h_t for a projection); null: zero
+    const float* wpk;    // packed weights: [D/4 unit groups][D/16 ksteps][64 lanes][4]
+    const float* bias;   // projection only: [4D] (b_ih + b_hh)
+    const float* gin;    // step: [B][4D] pre-activations from the projection (row b at gin + b*4D)
+    float* gout;         // projection: [B][4D] destination
+    float* hnext;        // step: [B][D]
+    float* c;            // step: [B][D] cell state
+    int first;           // step: t == 0 (no recurrent term, c = 0)
+    const float* skip;   // last layer: module input row (row b at skip + b*skip_bs)
+    float* yout;         // last layer: h + skip            (row b at yout + b*y_bs)
+    float* yout_elu;     // last layer: ELU(h + skip), the flavour the following conv reads
     long long skip_bs, y_bs;
-    int B, D, first;
+};
+
+struct LstmLaunchParams {
+    LstmRole role[3];
+    int B, D;
 };
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-__global__ __launch_bounds__(256) void lstm_step_kernel(const LstmStepParams p) {
+template <int KS>   // 16-wide k-steps per K-half: D = 32 * KS
+__global__ __launch_bounds__(256) void lstm_step_kernel(const LstmLaunchParams p) {
     __shared__ float red[2][2][16][17];
+    const LstmRole& R = p.role[blockIdx.z];
+    if (!R.active) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int msub = wave & 1, khalf = wave >> 1;
     const int li = lane & 15, kq = lane >> 4;
     const int ug = blockIdx.x;
     const int b0 = blockIdx.y * 32;
-    const int D = p.D;
+    constexpr int D = 32 * KS;
+    const bool step = R.kind == 0;
+
+    // ---- epilogue operands first (128 threads: clip bl, unit ul), so their latency hides under the MFMAs
+    const int bl = tid >> 2, ul = tid & 3;
+    const int eb = b0 + bl, eu = ug * 4 + ul;
+    const bool ethread = tid < 128 && eb < p.B;
+    float gpre[4] = {0.f, 0.f, 0.f, 0.f}, cprev = 0.f, skipv = 0.f;
+    if (ethread) {
+        if (step) {
+            const float* g = R.gin + (long long)eb * (4 * D);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) gpre[q] = g[q * D + eu];
+            if (!R.first) cprev = R.c[(long long)eb * D + eu];
+            if (R.skip) skipv = R.skip[(long long)eb * R.skip_bs + eu];
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) gpre[q] = R.bias[q * D + eu];
+        }
+    }
 
     f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
-    if (!p.first) {
-        const int ksteps = D / 32;                 // per K-half
+    if (R.a && !(step && R.first)) {
         const int brow = b0 + msub * 16 + li;
         const bool valid = brow < p.B;
-        const float* hrow = p.hprev + (long long)(valid ? brow : 0) * D + khalf * (D / 2) + 4 * kq;
-        const float* wrow = p.wpk + ((long long)ug * (D / 16) + (long long)khalf * ksteps) * 256 + lane * 4;
-        for (int k0 = 0; k0 < ksteps; k0 += 4) {
-            f32x4 a[4], w[4];
+        const float* hrow = R.a + (long long)(valid ? brow : 0) * D + khalf * (D / 2) + 4 * kq;
+        const float* wrow = R.wpk + ((long long)ug * (D / 16) + (long long)khalf * KS) * 256 + lane * 4;
+        f32x4 a[KS], w[KS];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const bool in = k0 + i < ksteps;
-                a[i] = (valid && in) ? *reinterpret_cast<const f32x4*>(hrow + (k0 + i) * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
-                w[i] = in ? *reinterpret_cast<const f32x4*>(wrow + (long long)(k0 + i) * 256) : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < KS; ++i) {
+            a[i] = *reinterpret_cast<const f32x4*>(hrow + i * 16);
+            w[i] = *reinterpret_cast<const f32x4*>(wrow + (long long)i * 256);
+        }
+        // keep ALL loads of the step in flight before the first MFMA (hipcc otherwise re-serialises
+        // them behind the MFMAs to save registers: ~8 dependent L2 round trips per step)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < KS; ++i) {
+            if (!valid) a[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < 4; u += 2) {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][u], w[i][u], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][u + 1], w[i][u + 1], acc1, 0, 0, 0);
             }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int u = 0; u < 4; u += 2) {
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][u], w[i][u], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][u + 1], w[i][u + 1], acc1, 0, 0, 0);
-                }
         }
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) red[khalf][msub][kq * 4 + r][li] = acc0[r] + acc1[r];
     __syncthreads();
-    if (tid < 128) {
-        const int bl = tid >> 2, ul = tid & 3;
-        const int b = b0 + bl;
-        if (b < p.B) {
-            const int ms = bl >> 4, row = bl & 15;
-            const int u = ug * 4 + ul;
-            const float* g = p.gin + (long long)b * p.gin_bs;
-            float pre[4];
+    if (ethread) {
+        const int ms = bl >> 4, row = bl & 15;
+        float pre[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                pre[q] = g[q * D + u] + (red[0][ms][row][q * 4 + ul] + red[1][ms][row][q * 4 + ul]);
+        for (int q = 0; q < 4; ++q) pre[q] = gpre[q] + (red[0][ms][row][q * 4 + ul] + red[1][ms][row][q * 4 + ul]);
+        if (step) {
             const float ig = sigmoidf_(pre[0]), fg = sigmoidf_(pre[1]), gg = tanhf(pre[2]), og = sigmoidf_(pre[3]);
-            const long long o = (long long)b * D + u;
-            const float cprev = p.first ? 0.f : p.c[o];
+            const long long o = (long long)eb * D + eu;
             const float cn = fg * cprev + ig * gg;
             const float hn = og * tanhf(cn);
-            p.c[o] = cn;
-            p.hnext[o] = hn;
-            if (p.yout || p.yout_elu) {
-                const float yv = hn + p.skip[(long long)b * p.skip_bs + u];
-                if (p.yout) p.yout[(long long)b * p.y_bs + u] = yv;
-                if (p.yout_elu) p.yout_elu[(long long)b * p.y_bs + u] = elu1(yv);
+            R.c[o] = cn;
+            R.hnext[o] = hn;
+            if (R.yout || R.yout_elu) {
+                const float yv = hn + skipv;
+                if (R.yout) R.yout[(long long)eb * R.y_bs + eu] = yv;
+                if (R.yout_elu) R.yout_elu[(long long)eb * R.y_bs + eu] = elu1(yv);
             }
+        } else {
+            float* g = R.gout + (long long)eb * (4 * D);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) g[q * D + eu] = pre[q];
         }
     }
 }
