@@ -87,8 +87,16 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(const LstmLaunchParams p
         f32x4 a[KS], w[KS];
 #pragma unroll
         for (int i = 0; i < KS; ++i) {
+#if defined(LSTM_DBG_SKIP) && (LSTM_DBG_SKIP & 2)
+            a[i] = f32x4{1.f, 2.f, 3.f, (float)i};
+#else
             a[i] = *reinterpret_cast<const f32x4*>(hrow + i * 16);
+#endif
+#if defined(LSTM_DBG_SKIP) && (LSTM_DBG_SKIP & 1)
+            w[i] = f32x4{1.f, 2.f, 3.f, (float)i};
+#else
             w[i] = *reinterpret_cast<const f32x4*>(wrow + (long long)i * 256);
+#endif
         }
         // keep ALL loads of the step in flight before the first MFMA (hipcc otherwise re-serialises
         // them behind the MFMAs to save registers: ~8 dependent L2 round trips per step)
