@@ -16,6 +16,8 @@
 #include "rvq.h"
 #include "tap_gemm.h"
 #include "tap_gemm4.h"
+#include "thin.h"
+#include "rb_fused.h"
 
 using namespace ac;
 
@@ -513,8 +515,53 @@ int convtr_fwd(ac_handle* h, hipStream_t st, const PackedGemm& g, const Act& x, 
     return run_tap(h, st, p);
 }
 
+template <int C, int BM>
+int launch_rb_fused(ac_handle* h, hipStream_t st, const ResBlockPlan& rb, const Act2& x, Out out, int B) {
+    using Cfg = RbCfg<C, BM>;
+    RbFusedParams p{};
+    p.xe = x.elu.p;
+    p.xr = x.raw.p;
+    p.w3 = h->blob + rb.c3.w_off;
+    p.b3 = h->blob + rb.c3.b_off;
+    p.wf = h->blob + rb.fused.w_off;
+    p.bf = h->blob + rb.fused.b_off;
+    p.y = out.raw;
+    p.y_elu = out.elu;
+    p.B = B;
+    p.L = x.raw.L;
+    p.Lp = x.raw.L > 2 ? x.raw.L : 3;
+    p.ntiles = cdiv(x.raw.L, BM);
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(rb_fused_kernel<C, BM>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::lds_bytes));
+        attr_set = true;
+    }
+    const long long total = (long long)B * p.ntiles;
+    const int grid = (int)std::min<long long>(total, 256);
+    const size_t lds = Cfg::lds_bytes;
+    const double L = x.raw.L;
+    ProfScope ps(h, st, C == 32 ? "rb_fused_kernel<32, 128>" : "rb_fused_kernel<64, 64>",
+                 2.0 * B * L * ((double)(C / 2) * 3 * C + (double)C * (C / 2 + C)),
+                 (double)B * L * C * 4.0 * (2 + (out.raw ? 1 : 0) + (out.elu ? 1 : 0)));
+    hipLaunchKernelGGL((rb_fused_kernel<C, BM>), dim3(grid), dim3(256), lds, st, p);
+    return AC_OK;
+}
+
 // ResBlock: hbuf = ELU(conv3(ELU(x)));  out = [hbuf | x] * [W1; Ws] + (b1 + bs)
 int resblock_fwd(ac_handle* h, hipStream_t st, const ResBlockPlan& rb, const Act2& x, float* hbuf, Out out, int B, Act2* y) {
+    // thin stages: one fused kernel, hidden activation never leaves the CU
+    if ((rb.C == 32 || rb.C == 64) && h->cfg.residual_kernel_size == 3 && h->cfg.compress == 2 && x.raw.ts == rb.C &&
+        x.elu.ts == rb.C && x.raw.bs == (long long)x.raw.L * rb.C && x.elu.bs == x.raw.bs && aligned16(x.raw.p) &&
+        aligned16(x.elu.p)) {
+        int rc = rb.C == 32 ? launch_rb_fused<32, 128>(h, st, rb, x, out, B) : launch_rb_fused<64, 64>(h, st, rb, x, out, B);
+        if (rc) return rc;
+        HIPCHK(h, hipGetLastError());
+        const long long bs = (long long)x.raw.L * rb.C;
+        y->raw = Act{out.raw, bs, rb.C, x.raw.L, rb.C};
+        y->elu = Act{out.elu, bs, rb.C, x.raw.L, rb.C};
+        return AC_OK;
+    }
     Act2 hv;
     int rc = conv_fwd(h, st, rb.c3, x.elu, h->cfg.residual_kernel_size, 1, nullptr, Out{nullptr, hbuf},
                       (long long)x.elu.L * rb.c3.N, rb.c3.N, B, &hv);
@@ -536,6 +583,62 @@ int resblock_fwd(ac_handle* h, hipStream_t st, const ResBlockPlan& rb, const Act
     y->raw = Act{out.raw, p.y_bs, p.y_rs, x.raw.L, rb.C};
     y->elu = Act{out.elu, p.y_bs, p.y_rs, x.raw.L, rb.C};
     return run_tap(h, st, p);
+}
+
+// stem / head: dedicated HBM-bound kernels when the shape allows, tap-GEMM otherwise
+bool thin_ok(const ac_config& c, int k) { return c.num_filters % 4 == 0 && c.num_filters <= 64 && k <= THIN_MAXK; }
+
+int stem_fwd(ac_handle* h, hipStream_t st, const float* sig, const float* rel_len, int B, int T, Out out, Act2* y) {
+    const ac_config& c = h->cfg;
+    const int F = c.num_filters;
+    ThinParams p{};
+    p.x = sig;
+    p.w = h->blob + h->enc_stem.w_off;
+    p.bias = h->blob + h->enc_stem.b_off;
+    p.rel_len = rel_len;
+    p.y = out.raw;
+    p.y_elu = out.elu;
+    p.B = B;
+    p.T = T;
+    p.F = F;
+    p.k = c.kernel_size;
+    p.Lp = T > c.kernel_size - 1 ? T : c.kernel_size;
+    {
+        ProfScope ps(h, st, "stem_kernel", 2.0 * B * (double)T * F * c.kernel_size,
+                     (double)B * T * 4.0 * (1 + F * ((out.raw ? 1 : 0) + (out.elu ? 1 : 0))));
+        hipLaunchKernelGGL(stem_kernel, dim3(cdiv(T, STEM_TT), B), dim3(256), 0, st, p);
+    }
+    HIPCHK(h, hipGetLastError());
+    y->raw = Act{out.raw, (long long)T * F, F, T, F};
+    y->elu = Act{out.elu, (long long)T * F, F, T, F};
+    return AC_OK;
+}
+
+int head_fwd(ac_handle* h, hipStream_t st, const Act& x, int B, float* sig) {
+    const ac_config& c = h->cfg;
+    const int F = c.num_filters;
+    ThinParams p{};
+    p.x = x.p;
+    p.w = h->blob + h->dec_head.w_off;
+    p.bias = h->blob + h->dec_head.b_off;
+    p.y = sig;
+    p.B = B;
+    p.T = x.L;
+    p.F = F;
+    p.k = c.last_kernel_size;
+    p.Lp = x.L > c.last_kernel_size - 1 ? x.L : c.last_kernel_size;
+    const size_t lds = ((size_t)(HEAD_TT + THIN_MAXK) * (F + 4) + (size_t)THIN_MAXK * F) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set && lds > 48 * 1024) {
+        HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(head_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    {
+        ProfScope ps(h, st, "head_kernel", 2.0 * B * (double)x.L * F * c.last_kernel_size, (double)B * x.L * 4.0 * (F + 1));
+        hipLaunchKernelGGL(head_kernel, dim3(cdiv(x.L, HEAD_TT), B), dim3(256), lds, st, p);
+    }
+    HIPCHK(h, hipGetLastError());
+    return AC_OK;
 }
 
 void capture(ac_handle* h, hipStream_t st, const Act& a, int B) {
@@ -768,7 +871,11 @@ int encoder_fwd(ac_handle* h, hipStream_t st, const float* sig, const float* rel
     const bool dbg = h->dbg != nullptr;
     Act xin{sig, (long long)T, 1, T, 1};
     Act2 x, y;
-    int rc = conv_fwd(h, st, h->enc_stem, xin, c.kernel_size, 1, rel_len, Out{ws.take(), ws.take()},
+    int rc;
+    if (thin_ok(c, c.kernel_size))
+        rc = stem_fwd(h, st, sig, rel_len, B, T, Out{ws.take(), ws.take()}, &x);
+    else
+        rc = conv_fwd(h, st, h->enc_stem, xin, c.kernel_size, 1, rel_len, Out{ws.take(), ws.take()},
                       (long long)T * c.num_filters, c.num_filters, B, &x);
     if (rc) return rc;
     capture(h, st, x.raw, B);
@@ -832,7 +939,10 @@ int decoder_fwd(ac_handle* h, hipStream_t st, const long long* toks, int B, int 
         if (dbg) { capture(h, st, y.raw, B); ws.give(y.raw.p); y.raw.p = nullptr; }
         x = y;
     }
-    rc = conv_fwd(h, st, h->dec_head, x.elu, c.last_kernel_size, 1, nullptr, Out{sig, nullptr}, (long long)x.elu.L, 1, B, nullptr);
+    if (thin_ok(c, c.last_kernel_size) && x.elu.ts == c.num_filters)
+        rc = head_fwd(h, st, x.elu, B, sig);
+    else
+        rc = conv_fwd(h, st, h->dec_head, x.elu, c.last_kernel_size, 1, nullptr, Out{sig, nullptr}, (long long)x.elu.L, 1, B, nullptr);
     ws.give(x);
     return rc;
 }

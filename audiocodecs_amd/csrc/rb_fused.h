@@ -1,0 +1,208 @@
+// Fused SEANet residual block for the thin (32/64-channel) stages, where the unfused version is HBM-bound:
+//     y = shortcut_1x1(x) + conv_1x1(ELU(conv_k3(ELU(x))))            ([HF] EncodecResnetBlock :252-282)
+// One kernel reads the block input once per flavour (ELU'd rows for the k3 conv, raw rows for the
+// shortcut), keeps the hidden activation (C/2 channels) in LDS and writes ELU(y) (what the next conv
+// reads) -- the hidden tensor's HBM round trip and one re-read of x disappear:
+//     unfused  (C=32, per time step): 128 r + 64 w | 64 r + 128 r + 128 w  = 512 B
+//     fused                         : 128 r + 128 r + 128 w               = 384 B
+// Persistent workgroups walk the (clip, time-tile) list; the next tile's rows are loaded into
+// registers while the current tile is in the MFMA phases (v_mfma_f32_16x16x4_f32, K order as in
+// tap_gemm.h: taps ascending, channels in 16-wide steps).  Weights sit in LDS for the whole kernel.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "tap_gemm.h"
+
+namespace ac {
+
+struct RbFusedParams {
+    const float* xe;    // [B][L][C] ELU'd input
+    const float* xr;    // [B][L][C] raw input
+    const float* w3;    // packed [C/2][3C]   (k = tap*C + ci)
+    const float* b3;    // [C/2]
+    const float* wf;    // packed [C][C/2 + C] (k < C/2: 1x1 over the hidden; then the shortcut over x)
+    const float* bf;    // [C]  (b_1x1 + b_shortcut)
+    float* y;           // optional raw output [B][L][C]
+    float* y_elu;       // optional ELU'd output
+    int B, L, Lp;       // Lp: reflect base length (L, or 3 when L <= 2: [HF]:148-155)
+    int ntiles;         // tiles per clip
+};
+
+template <int C, int BM>
+struct RbCfg {
+    static constexpr int HC = C / 2, CP = C + 4, HP = HC + 4;
+    static constexpr int K3 = 3 * C, K3P = K3 + 4, KF = HC + C, KFP = KF + 4;
+    static constexpr int XE_ROWS = BM + 2;
+    static constexpr int XE_FLOATS = XE_ROWS * CP, XR_FLOATS = BM * CP, H_FLOATS = BM * HP;
+    static constexpr int W3_FLOATS = HC * K3P, WF_FLOATS = C * KFP;
+    static constexpr int XE_SLOTS = (XE_ROWS * (C / 4) + 255) / 256, XR_SLOTS = (BM * (C / 4) + 255) / 256;
+    static constexpr size_t lds_bytes = (size_t)(2 * (XE_FLOATS + XR_FLOATS) + H_FLOATS + W3_FLOATS + WF_FLOATS) * 4;
+};
+
+template <int C, int BM>
+__global__ __launch_bounds__(256) void rb_fused_kernel(const RbFusedParams p) {
+    using Cfg = RbCfg<C, BM>;
+    constexpr int HC = Cfg::HC, CP = Cfg::CP, HP = Cfg::HP, K3P = Cfg::K3P, KFP = Cfg::KFP;
+    constexpr int MS = BM / 64;            // 16-row sub-tiles per wave
+    constexpr int NA = HC / 16, NB = C / 16;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Xe0 = smem;                                         // [2][XE_ROWS][CP]
+    float* Xr0 = Xe0 + 2 * Cfg::XE_FLOATS;                     // [2][BM][CP]
+    float* Hs = Xr0 + 2 * Cfg::XR_FLOATS;                      // [BM][HP]
+    float* W3s = Hs + Cfg::H_FLOATS;                           // [HC][K3P]
+    float* Wfs = W3s + Cfg::W3_FLOATS;                         // [C][KFP]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, kq = lane >> 4;
+    const int total = p.B * p.ntiles;
+
+    // ---- weights -> LDS (once)
+    for (int e = tid; e < HC * (Cfg::K3 / 4); e += 256) {
+        const int n = e / (Cfg::K3 / 4), q = e % (Cfg::K3 / 4);
+        *reinterpret_cast<f32x4*>(&W3s[n * K3P + 4 * q]) = *reinterpret_cast<const f32x4*>(p.w3 + (long long)n * Cfg::K3 + 4 * q);
+    }
+    for (int e = tid; e < C * (Cfg::KF / 4); e += 256) {
+        const int n = e / (Cfg::KF / 4), q = e % (Cfg::KF / 4);
+        *reinterpret_cast<f32x4*>(&Wfs[n * KFP + 4 * q]) = *reinterpret_cast<const f32x4*>(p.wf + (long long)n * Cfg::KF + 4 * q);
+    }
+    float b3v[NA], bfv[NB];
+#pragma unroll
+    for (int c = 0; c < NA; ++c) b3v[c] = p.b3[c * 16 + li];
+#pragma unroll
+    for (int c = 0; c < NB; ++c) bfv[c] = p.bf[c * 16 + li];
+
+    f32x4 re[Cfg::XE_SLOTS], rr[Cfg::XR_SLOTS];
+    auto load_tile = [&](int tile) {
+        const int b = tile / p.ntiles, t0 = (tile % p.ntiles) * BM;
+        const float* xe = p.xe + (long long)b * p.L * C;
+        const float* xr = p.xr + (long long)b * p.L * C;
+#pragma unroll
+        for (int i = 0; i < Cfg::XE_SLOTS; ++i) {
+            const int e = tid + i * 256;
+            const int row = e / (C / 4), q = e % (C / 4);
+            re[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (row < Cfg::XE_ROWS) {
+                int j = t0 - 2 + row;                            // causal reflect pad of 2 ([HF]:157-176)
+                j = j < 0 ? -j : (j >= p.Lp ? 2 * (p.Lp - 1) - j : j);
+                if (j >= 0 && j < p.L) re[i] = *reinterpret_cast<const f32x4*>(xe + (long long)j * C + 4 * q);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < Cfg::XR_SLOTS; ++i) {
+            const int e = tid + i * 256;
+            const int row = e / (C / 4), q = e % (C / 4);
+            rr[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (row < BM && t0 + row < p.L) rr[i] = *reinterpret_cast<const f32x4*>(xr + (long long)(t0 + row) * C + 4 * q);
+        }
+    };
+    auto store_tile = [&](int buf) {
+        float* xe = Xe0 + buf * Cfg::XE_FLOATS;
+        float* xr = Xr0 + buf * Cfg::XR_FLOATS;
+#pragma unroll
+        for (int i = 0; i < Cfg::XE_SLOTS; ++i) {
+            const int e = tid + i * 256;
+            const int row = e / (C / 4), q = e % (C / 4);
+            if (row < Cfg::XE_ROWS) *reinterpret_cast<f32x4*>(&xe[row * CP + 4 * q]) = re[i];
+        }
+#pragma unroll
+        for (int i = 0; i < Cfg::XR_SLOTS; ++i) {
+            const int e = tid + i * 256;
+            const int row = e / (C / 4), q = e % (C / 4);
+            if (row < BM) *reinterpret_cast<f32x4*>(&xr[row * CP + 4 * q]) = rr[i];
+        }
+    };
+
+    int tile = blockIdx.x;
+    if (tile >= total) return;
+    load_tile(tile);
+    store_tile(0);
+    __syncthreads();
+    int buf = 0;
+    for (; tile < total; tile += gridDim.x) {
+        const int next = tile + gridDim.x;
+        if (next < total) load_tile(next);
+        const float* Xe = Xe0 + buf * Cfg::XE_FLOATS;
+        float* Xr = Xr0 + buf * Cfg::XR_FLOATS;
+        const int r0 = wave * (BM / 4);                         // this wave's first row in the tile
+        // ---- stage A: hidden = ELU(conv_k3(xe) + b3) -> Hs (each wave its own rows)
+        {
+            f32x4 acc[MS][NA];
+#pragma unroll
+            for (int a = 0; a < MS; ++a)
+#pragma unroll
+                for (int c = 0; c < NA; ++c) acc[a][c] = f32x4{b3v[c], b3v[c], b3v[c], b3v[c]};
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int ks = 0; ks < C / 16; ++ks) {
+                    f32x4 af[MS], bf[NA];
+#pragma unroll
+                    for (int a = 0; a < MS; ++a) af[a] = *reinterpret_cast<const f32x4*>(&Xe[(r0 + a * 16 + li + j) * CP + ks * 16 + 4 * kq]);
+#pragma unroll
+                    for (int c = 0; c < NA; ++c) bf[c] = *reinterpret_cast<const f32x4*>(&W3s[(c * 16 + li) * K3P + j * C + ks * 16 + 4 * kq]);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int a = 0; a < MS; ++a)
+#pragma unroll
+                            for (int c = 0; c < NA; ++c)
+                                acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a][u], bf[c][u], acc[a][c], 0, 0, 0);
+                }
+#pragma unroll
+            for (int a = 0; a < MS; ++a)
+#pragma unroll
+                for (int c = 0; c < NA; ++c)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) Hs[(r0 + a * 16 + kq * 4 + r) * HP + c * 16 + li] = elu1(acc[a][c][r]);
+        }
+        __syncthreads();
+        // ---- stage B: y = [hidden | xr] * [W1; Ws] + bf
+        f32x4 acc[MS][NB];
+#pragma unroll
+        for (int a = 0; a < MS; ++a)
+#pragma unroll
+            for (int c = 0; c < NB; ++c) acc[a][c] = f32x4{bfv[c], bfv[c], bfv[c], bfv[c]};
+#pragma unroll
+        for (int ks = 0; ks < (HC + C) / 16; ++ks) {
+            f32x4 af[MS], bf[NB];
+#pragma unroll
+            for (int a = 0; a < MS; ++a)
+                af[a] = ks < HC / 16 ? *reinterpret_cast<const f32x4*>(&Hs[(r0 + a * 16 + li) * HP + ks * 16 + 4 * kq])
+                                     : *reinterpret_cast<const f32x4*>(&Xr[(r0 + a * 16 + li) * CP + (ks - HC / 16) * 16 + 4 * kq]);
+#pragma unroll
+            for (int c = 0; c < NB; ++c) bf[c] = *reinterpret_cast<const f32x4*>(&Wfs[(c * 16 + li) * KFP + ks * 16 + 4 * kq]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int a = 0; a < MS; ++a)
+#pragma unroll
+                    for (int c = 0; c < NB; ++c)
+                        acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a][u], bf[c][u], acc[a][c], 0, 0, 0);
+        }
+        __syncthreads();                                        // all reads of Xr[buf] done: reuse it as the output tile
+#pragma unroll
+        for (int a = 0; a < MS; ++a)
+#pragma unroll
+            for (int c = 0; c < NB; ++c)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Xr[(r0 + a * 16 + kq * 4 + r) * CP + c * 16 + li] = acc[a][c][r];
+        __syncthreads();
+        {
+            const int b = tile / p.ntiles, t0 = (tile % p.ntiles) * BM;
+            const long long ob = (long long)b * p.L * C;
+            for (int e = tid; e < BM * (C / 4); e += 256) {
+                const int row = e / (C / 4), q = e % (C / 4);
+                if (t0 + row < p.L) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(&Xr[row * CP + 4 * q]);
+                    const long long o = ob + (long long)(t0 + row) * C + 4 * q;
+                    if (p.y) *reinterpret_cast<f32x4*>(p.y + o) = v;
+                    if (p.y_elu) *reinterpret_cast<f32x4*>(p.y_elu + o) = elu4(v);
+                }
+            }
+        }
+        if (next < total) store_tile(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+}
+
+}  // namespace ac

@@ -1,0 +1,112 @@
+// HBM-bound ends of the SEANet stack, where one side of the layer has 1 channel and a GEMM tile would
+// be almost empty:
+//   stem_kernel : [HF] EncodecEncoder.layers[0]  Conv1d(1, F, k)  sig[B][T] -> x[B][T][F] (raw and ELU'd)
+//   head_kernel : [HF] EncodecDecoder.layers[-1] Conv1d(F, 1, k)  ELU'd y[B][T][F] -> sig[B][T]
+// Both are causal with reflect padding ([HF] modeling_encodec.py:157-176, small-input rule :148-155),
+// the stem also applies the length mask (audiocodecs/encodec.py:84-92, [HF]:589-590).
+// Algorithmic bytes: stem 4*T*(1 + F*flavours), head 4*T*(F + 1) per clip; plain fp32 FMAs (the
+// arithmetic is ~1 flop/B).  Accumulation order: bias first, then taps (and channels) ascending.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "tap_gemm.h"
+
+namespace ac {
+
+struct ThinParams {
+    const float* x;        // stem: [B][T]; head: [B][T][F]
+    const float* w;        // stem: [F][k] (HF layout [F][1][k]); head: [k][F] (re-packed from [1][F][k])
+    const float* bias;     // stem: [F]; head: [1]
+    const float* rel_len;  // stem only, optional [B]
+    float* y;              // stem: raw [B][T][F] (may be null); head: [B][T]
+    float* y_elu;          // stem: ELU'd [B][T][F] (may be null)
+    int B, T, F, k;
+    int Lp;                // reflect base length: T if T > k-1 else k ([HF]:148-155)
+};
+
+__device__ __forceinline__ int reflect_src(int i, int T, int Lp) {
+    int j = i < 0 ? -i : (i >= Lp ? 2 * (Lp - 1) - i : i);
+    return (j >= 0 && j < T) ? j : -1;
+}
+
+constexpr int STEM_TT = 2048;   // time steps per workgroup
+constexpr int THIN_MAXK = 8;
+
+// F must be a multiple of 4 (<= 64): thread = (time step, 4 channels); k <= 8.
+__global__ __launch_bounds__(256) void stem_kernel(const ThinParams p) {
+    __shared__ float xs[STEM_TT + THIN_MAXK];
+    const int b = blockIdx.y, t0 = blockIdx.x * STEM_TT, tid = threadIdx.x;
+    const float* xb = p.x + (long long)b * p.T;
+    float alen = 3.0e38f;
+    if (p.rel_len) alen = (float)p.T * p.rel_len[b];
+    const int pad = p.k - 1;
+    for (int e = tid; e < STEM_TT + pad; e += 256) {
+        const int j = reflect_src(t0 - pad + e, p.T, p.Lp);
+        xs[e] = (j >= 0 && (float)j < alen) ? xb[j] : 0.f;
+    }
+    const int cq = p.F / 4;                 // float4 groups per time step
+    const int c4 = (tid % cq) * 4;
+    float w[4][THIN_MAXK], bv[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        bv[c] = p.bias[c4 + c];
+#pragma unroll
+        for (int j = 0; j < THIN_MAXK; ++j) w[c][j] = j < p.k ? p.w[(c4 + c) * p.k + j] : 0.f;
+    }
+    __syncthreads();
+    const int tstep = 256 / cq;
+    const long long ob = (long long)b * p.T * p.F;
+    for (int tl = tid / cq; tl < STEM_TT; tl += tstep) {
+        const int t = t0 + tl;
+        if (t >= p.T) break;
+        f32x4 acc = f32x4{bv[0], bv[1], bv[2], bv[3]};
+#pragma unroll
+        for (int j = 0; j < THIN_MAXK; ++j) {
+            if (j < p.k) {
+                const float xv = xs[tl + j];
+                acc.x = fmaf(w[0][j], xv, acc.x); acc.y = fmaf(w[1][j], xv, acc.y);
+                acc.z = fmaf(w[2][j], xv, acc.z); acc.w = fmaf(w[3][j], xv, acc.w);
+            }
+        }
+        const long long o = ob + (long long)t * p.F + c4;
+        if (p.y) *reinterpret_cast<f32x4*>(p.y + o) = acc;
+        if (p.y_elu) *reinterpret_cast<f32x4*>(p.y_elu + o) = elu4(acc);
+    }
+}
+
+constexpr int HEAD_TT = 256;    // outputs per workgroup (one per thread)
+
+// F multiple of 4, F <= 64, k <= 8.  LDS: (HEAD_TT + k - 1) rows of F (+4 pad) floats + the weights.
+__global__ __launch_bounds__(256) void head_kernel(const ThinParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int F = p.F, FP = F + 4;
+    float* xs = smem;                                   // [(HEAD_TT + pad)][FP]
+    float* ws = smem + (HEAD_TT + THIN_MAXK) * FP;      // [k][F]
+    const int b = blockIdx.y, t0 = blockIdx.x * HEAD_TT, tid = threadIdx.x;
+    const int pad = p.k - 1, fq = F / 4;
+    const float* xb = p.x + (long long)b * p.T * F;
+    for (int e = tid; e < (HEAD_TT + pad) * fq; e += 256) {
+        const int row = e / fq, q = e % fq;
+        const int j = reflect_src(t0 - pad + row, p.T, p.Lp);
+        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (j >= 0) v = *reinterpret_cast<const f32x4*>(xb + (long long)j * F + 4 * q);
+        *reinterpret_cast<f32x4*>(&xs[row * FP + 4 * q]) = v;
+    }
+    for (int e = tid; e < p.k * F; e += 256) ws[e] = p.w[e];
+    __syncthreads();
+    const int t = t0 + tid;
+    if (t >= p.T) return;
+    float acc = p.bias[0];
+    for (int j = 0; j < p.k; ++j) {
+        const float* xr = &xs[(tid + j) * FP];
+        const float* wr = &ws[j * F];
+        for (int q = 0; q < fq; ++q) {
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(xr + 4 * q);
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(wr + 4 * q);
+            acc = fmaf(wv.x, xv.x, acc); acc = fmaf(wv.y, xv.y, acc);
+            acc = fmaf(wv.z, xv.z, acc); acc = fmaf(wv.w, xv.w, acc);
+        }
+    }
+    p.y[(long long)b * p.T + t] = acc;
+}
+
+}  // namespace ac
