@@ -676,7 +676,7 @@ int lstm_fwd(ac_handle* h, hipStream_t st, const LstmPlan& lp, const Act& x, con
         if (rc) return rc;
     }
     const int nroles = 2 * L - 1, nlaunch = T + 2 * (L - 1);
-    const long long BD = (long long)B * D, B4D = (long long)B * 4 * D;
+    const long long BD = (long long)((B + 31) / 32 * 32) * D, B4D = (long long)B * 4 * D;   // h lives in A-fragment tiles of 16 clips
     {
         ProfScope ps(h, st, "lstm_step_kernel", 2.0 * T * (double)B * 4 * D * D * nroles,
                      (double)T * nroles * ((double)B * 4 * D * 4 + 4.0 * D * D * 4 + 2.0 * B * D * 4), nlaunch);
@@ -719,7 +719,7 @@ int lstm_fwd(ac_handle* h, hipStream_t st, const LstmPlan& lp, const Act& x, con
                 r.wpk = h->blob + lp.hh_off[1];
                 r.gin = ws.gin1 + (long long)std::max(t2, 0) * B4D;
                 r.hnext = ws.hseq1 + (long long)std::max(t2, 0) * BD;
-                r.c = ws.c + BD;
+                r.c = ws.c + (long long)B * D;
                 r.first = t2 == 0;
                 if (r.active) fill_last(r, t2);
             }
@@ -821,7 +821,7 @@ Workspace plan_ws(const ac_handle* h, int B, int T_in /*samples, encoder*/, int 
     mx = std::max(mx, (size_t)N * std::max(h->D, c.hidden_size));
     w.act_floats = align_up(mx * B, 64);
     w.gin = align_up((size_t)N * B * 4 * h->D, 64);
-    w.hseq = align_up((size_t)N * B * h->D, 64);
+    w.hseq = align_up((size_t)N * ((B + 31) / 32 * 32) * h->D, 64);   // clips padded to the 32-clip workgroup tile
     w.c = align_up((size_t)2 * B * h->D, 64);
     w.total_bytes = (NACT * w.act_floats + 2 * w.gin + 2 * w.hseq + w.c) * sizeof(float) + 256;
     return w;

@@ -26,12 +26,13 @@ namespace ac {
 struct LstmRole {
     int active;          // 0: this role idles in this launch
     int kind;            // 0: cell step, 1: input projection (writes gin of the next layer)
-    const float* a;      // [B][D] A operand rows (h_{t-1} for a step, lower layer's h_t for a projection); null: zero
+    const float* a;      // A operand (h_{t-1} for a step, lower layer's h_t for a projection) in MFMA A-fragment
+                         // order [ceil(B/16)][D/16 ksteps][64 lanes][4] (see hfrag_index); null: zero
     const float* wpk;    // packed weights: [D/4 unit groups][D/16 ksteps][64 lanes][4]
     const float* bias;   // projection only: [4D] (b_ih + b_hh)
     const float* gin;    // step: [B][4D] pre-activations from the projection (row b at gin + b*4D)
     float* gout;         // projection: [B][4D] destination
-    float* hnext;        // step: [B][D]
+    float* hnext;        // step: h_t, written in the same A-fragment order
     float* c;            // step: [B][D] cell state
     int first;           // step: t == 0 (no recurrent term, c = 0)
     const float* skip;   // last layer: module input row (row b at skip + b*skip_bs)
@@ -46,6 +47,14 @@ struct LstmLaunchParams {
 };
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// h is only ever read back as the A operand of the next launch, so it is STORED in A-fragment order:
+// element (clip b, unit k) lives where lane (b%16, (k%16)/4) of k-step k/16 loads its 16-byte vector.
+// A wave's A loads are then 1 KiB contiguous each (measured: row-major h cost 4.2 of 13 us per launch
+// as 16 x 64-byte segments per load instruction).
+__device__ __forceinline__ long long hfrag_index(int b, int k, int D) {
+    return ((((long long)(b >> 4) * (D >> 4) + (k >> 4)) * 64 + (((k & 15) >> 2) << 4) + (b & 15)) << 2) + (k & 3);
+}
 
 template <int KS>   // 16-wide k-steps per K-half: D = 32 * KS
 __global__ __launch_bounds__(256) void lstm_step_kernel(const LstmLaunchParams p) {
@@ -80,9 +89,7 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(const LstmLaunchParams p
 
     f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
     if (R.a && !(step && R.first)) {
-        const int brow = b0 + msub * 16 + li;
-        const bool valid = brow < p.B;
-        const float* hrow = R.a + (long long)(valid ? brow : 0) * D + khalf * (D / 2) + 4 * kq;
+        const float* hrow = R.a + (((long long)((b0 >> 4) + msub) * (D / 16) + (long long)khalf * KS) * 64 + lane) * 4;
         const float* wrow = R.wpk + ((long long)ug * (D / 16) + (long long)khalf * KS) * 256 + lane * 4;
         f32x4 a[KS], w[KS];
 #pragma unroll
@@ -90,7 +97,7 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(const LstmLaunchParams p
 #if defined(LSTM_DBG_SKIP) && (LSTM_DBG_SKIP & 2)
             a[i] = f32x4{1.f, 2.f, 3.f, (float)i};
 #else
-            a[i] = *reinterpret_cast<const f32x4*>(hrow + i * 16);
+            a[i] = *reinterpret_cast<const f32x4*>(hrow + (long long)i * 256);
 #endif
 #if defined(LSTM_DBG_SKIP) && (LSTM_DBG_SKIP & 1)
             w[i] = f32x4{1.f, 2.f, 3.f, (float)i};
@@ -103,7 +110,6 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(const LstmLaunchParams p
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < KS; ++i) {
-            if (!valid) a[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int u = 0; u < 4; u += 2) {
                 acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][u], w[i][u], acc0, 0, 0, 0);
@@ -125,7 +131,7 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(const LstmLaunchParams p
             const float cn = fg * cprev + ig * gg;
             const float hn = og * tanhf(cn);
             R.c[o] = cn;
-            R.hnext[o] = hn;
+            R.hnext[hfrag_index(eb, eu, D)] = hn;
             if (R.yout || R.yout_elu) {
                 const float yv = hn + skipv;
                 if (R.yout) R.yout[(long long)eb * R.y_bs + eu] = yv;
