@@ -65,6 +65,22 @@ def cpu_baseline(cfg, sd, sig_cpu, clips=8):
     }
 
 
+def measured_traffic(kernel_name, unit):
+    """HBM bytes per launch of `kernel_name` from the committed PMC summary (rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE in separate passes, gfx950 FETCH x2 correction: tools/collect_traffic.py).  bench.py cannot
+    run the profiler on itself, so the newest profiles/r*_traffic.json is quoted; null if absent."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+    if not files:
+        return None
+    try:
+        k = json.load(open(files[-1]))["kernels"].get(kernel_name)
+        return None if not k or k["hbm_bytes_per_launch"] is None else round(k["hbm_bytes_per_launch"])
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -145,7 +161,7 @@ def main():
         else:
             roof = {"bound": "hbm", "achieved": round(nbytes / (tot_ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s"}
         roof["frac"] = round(roof["achieved"] / roof["peak"], 4)
-        roof["traffic"] = None
+        roof["traffic"] = measured_traffic(name, roof["unit"])
         roof["kernel"] = name
         roof["launches_per_step"] = launches / args.steps
         roof["avg_launch_us"] = round(avg_us, 2)
