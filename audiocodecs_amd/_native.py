@@ -69,6 +69,7 @@ EXPORTS = {
     "ac_quantize": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "ac_dequantize": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "ac_embs": (_i, [_vp, _i, _vp, _vp]),
+    "ac_resample": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
     "ac_profile_begin": (_i, [_vp]),
     "ac_profile_end": (_i, [_vp, C.POINTER(AcKernelStat), _i]),
     "ac_debug_capture": (_i, [_vp, _vp, _sz]),

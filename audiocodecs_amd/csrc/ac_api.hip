@@ -1168,6 +1168,13 @@ int ac_profile_end(ac_handle* h, ac_kernel_stat* out, int cap) {
     return n;
 }
 
+int ac_resample(const float* x, int B, int L, const float* kern, int n, int o, int taps, int width, float* y, int L_out, void* stream) {
+    if (!x || !kern || !y || B < 1 || L < 1 || n < 1 || o < 1 || taps < 1 || width < 0 || L_out < 1) return AC_EINVAL;
+    ResampleParams p{x, kern, y, B, L, L_out, n, o, taps, width};
+    hipLaunchKernelGGL(resample_kernel, dim3((unsigned)((L_out + 255) / 256), B), dim3(256), 0, (hipStream_t)stream, p);
+    return hipGetLastError() == hipSuccess ? AC_OK : AC_EHIP;
+}
+
 const char* ac_last_error(const ac_handle* h) { return h ? h->err.c_str() : "null handle"; }
 
 void ac_destroy(ac_handle* h) {

@@ -109,4 +109,31 @@ __global__ __launch_bounds__(256) void head_kernel(const ThinParams p) {
     p.y[(long long)b * p.T + t] = acc;
 }
 
+// Polyphase windowed-sinc sample-rate conversion: what torchaudio.functional.resample applies at the
+// Codec boundary (audiocodecs/codec.py:59-63,95-99): zero-pad (width, width + o), conv1d with the
+// [n phases][taps] kernel at stride o, interleave the phases, truncate.  out[i*n + ph] =
+// sum_k kern[ph][k] * x[i*o + k - width].  One thread per output sample; HBM-bound (4*(L + L_out) B/clip).
+struct ResampleParams {
+    const float* x;      // [B][L]
+    const float* kern;   // [n][taps]
+    float* y;            // [B][L_out]
+    int B, L, L_out, n, o, taps, width;
+};
+
+__global__ __launch_bounds__(256) void resample_kernel(const ResampleParams p) {
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.y;
+    if (gid >= p.L_out) return;
+    const int i = (int)(gid / p.n), ph = (int)(gid % p.n);
+    const float* xb = p.x + (long long)b * p.L;
+    const float* kr = p.kern + (long long)ph * p.taps;
+    const int base = i * p.o - p.width;
+    float acc = 0.f;
+    for (int k = 0; k < p.taps; ++k) {
+        const int m = base + k;
+        if (m >= 0 && m < p.L) acc = fmaf(kr[k], xb[m], acc);
+    }
+    p.y[(long long)b * p.L_out + gid] = acc;
+}
+
 }  // namespace ac

@@ -121,6 +121,13 @@ int ac_dequantize(ac_handle* h, const int64_t* toks_dev, int B, int N, int K, fl
 /* Copy the first K codebooks to embs_dev [K, codebook_size, H] fp32 (encodec.py:74-79). */
 int ac_embs(ac_handle* h, int K, float* embs_dev, void* stream);
 
+/* Sample-rate conversion at the Codec boundary (audiocodecs/codec.py:59-63,95-99 call
+ * torchaudio.functional.resample): polyphase windowed-sinc FIR.  kern_dev [n][taps] is the filter
+ * bank (n = new_rate/gcd phases, stride o = orig_rate/gcd, `width` zero samples of left padding);
+ * y[b][i*n + ph] = sum_k kern[ph][k] * x[b][i*o + k - width], L_out = ceil(n*L/o).  Handle-free. */
+int ac_resample(const float* x_dev, int B, int L, const float* kern_dev, int n, int o, int taps, int width,
+                float* y_dev, int L_out, void* stream);
+
 /* Optional per-kernel timing with HIP events on the caller's stream (bench.py's roofline leg).
  * ac_profile_begin arms it; every launch made by subsequent calls is bracketed by events.
  * ac_profile_end synchronises those events and writes up to `cap` records; returns the count. */
