@@ -515,11 +515,11 @@ int convtr_fwd(ac_handle* h, hipStream_t st, const PackedGemm& g, const Act& x, 
     return run_tap(h, st, p);
 }
 
-template <int C, int BM>
+template <int C, int BM, int NSPLIT>
 int launch_rb_fused(ac_handle* h, hipStream_t st, const ResBlockPlan& rb, const Act2& x, Out out, int B) {
-    using Cfg = RbCfg<C, BM>;
+    using Cfg = RbCfg<C, BM, NSPLIT>;
     RbFusedParams p{};
-    p.xe = x.elu.p;
+    p.xe = x.elu.p;   // may be null: the kernel then activates the raw rows itself
     p.xr = x.raw.p;
     p.w3 = h->blob + rb.c3.w_off;
     p.b3 = h->blob + rb.c3.b_off;
@@ -533,18 +533,18 @@ int launch_rb_fused(ac_handle* h, hipStream_t st, const ResBlockPlan& rb, const 
     p.ntiles = cdiv(x.raw.L, BM);
     static bool attr_set = false;
     if (!attr_set) {
-        HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(rb_fused_kernel<C, BM>),
+        HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(rb_fused_kernel<C, BM, NSPLIT>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::lds_bytes));
         attr_set = true;
     }
     const long long total = (long long)B * p.ntiles;
-    const int grid = (int)std::min<long long>(total, 256);
+    const int grid = (int)std::min<long long>(total, 512);   // two workgroups per CU (VGPR-limited), persistent
     const size_t lds = Cfg::lds_bytes;
     const double L = x.raw.L;
-    ProfScope ps(h, st, C == 32 ? "rb_fused_kernel<32, 128>" : "rb_fused_kernel<64, 64>",
+    ProfScope ps(h, st, C == 32 ? "rb_fused_kernel<32, 128, 1>" : "rb_fused_kernel<64, 64, 2>",
                  2.0 * B * L * ((double)(C / 2) * 3 * C + (double)C * (C / 2 + C)),
                  (double)B * L * C * 4.0 * (2 + (out.raw ? 1 : 0) + (out.elu ? 1 : 0)));
-    hipLaunchKernelGGL((rb_fused_kernel<C, BM>), dim3(grid), dim3(256), lds, st, p);
+    hipLaunchKernelGGL((rb_fused_kernel<C, BM, NSPLIT>), dim3(grid), dim3(256), lds, st, p);
     return AC_OK;
 }
 
@@ -552,9 +552,9 @@ int launch_rb_fused(ac_handle* h, hipStream_t st, const ResBlockPlan& rb, const 
 int resblock_fwd(ac_handle* h, hipStream_t st, const ResBlockPlan& rb, const Act2& x, float* hbuf, Out out, int B, Act2* y) {
     // thin stages: one fused kernel, hidden activation never leaves the CU
     if ((rb.C == 32 || rb.C == 64) && h->cfg.residual_kernel_size == 3 && h->cfg.compress == 2 && x.raw.ts == rb.C &&
-        x.elu.ts == rb.C && x.raw.bs == (long long)x.raw.L * rb.C && x.elu.bs == x.raw.bs && aligned16(x.raw.p) &&
-        aligned16(x.elu.p)) {
-        int rc = rb.C == 32 ? launch_rb_fused<32, 128>(h, st, rb, x, out, B) : launch_rb_fused<64, 64>(h, st, rb, x, out, B);
+        x.raw.bs == (long long)x.raw.L * rb.C && aligned16(x.raw.p) &&
+        (!x.elu.p || (x.elu.ts == rb.C && x.elu.bs == x.raw.bs && aligned16(x.elu.p)))) {
+        int rc = rb.C == 32 ? launch_rb_fused<32, 128, 1>(h, st, rb, x, out, B) : launch_rb_fused<64, 64, 2>(h, st, rb, x, out, B);   // <C, rows per tile, column split>
         if (rc) return rc;
         HIPCHK(h, hipGetLastError());
         const long long bs = (long long)x.raw.L * rb.C;
@@ -872,8 +872,10 @@ int encoder_fwd(ac_handle* h, hipStream_t st, const float* sig, const float* rel
     Act xin{sig, (long long)T, 1, T, 1};
     Act2 x, y;
     int rc;
+    // a 32-channel ResBlock activates its raw input itself (rb_fused.h): no ELU'd flavour needed in HBM
+    auto rb_self_elu = [&](int C) { return C == 32 && c.residual_kernel_size == 3 && c.compress == 2; };
     if (thin_ok(c, c.kernel_size))
-        rc = stem_fwd(h, st, sig, rel_len, B, T, Out{ws.take(), ws.take()}, &x);
+        rc = stem_fwd(h, st, sig, rel_len, B, T, Out{ws.take(), rb_self_elu(c.num_filters) ? nullptr : ws.take()}, &x);
     else
         rc = conv_fwd(h, st, h->enc_stem, xin, c.kernel_size, 1, rel_len, Out{ws.take(), ws.take()},
                       (long long)T * c.num_filters, c.num_filters, B, &x);
@@ -890,7 +892,8 @@ int encoder_fwd(ac_handle* h, hipStream_t st, const float* sig, const float* rel
         x = y;
         const int M = cdiv(x.elu.L, ratio);
         const bool last = i == c.num_ratios - 1;    // the last down-sampler feeds the LSTM: raw only
-        rc = conv_fwd(h, st, h->enc_down[i], x.elu, 2 * ratio, ratio, nullptr, Out{ws.take(), last ? nullptr : ws.take()},
+        rc = conv_fwd(h, st, h->enc_down[i], x.elu, 2 * ratio, ratio, nullptr,
+                      Out{ws.take(), (last || rb_self_elu(h->enc_down[i].N)) ? nullptr : ws.take()},
                       (long long)M * h->enc_down[i].N, h->enc_down[i].N, B, &y);
         if (rc) return rc;
         ws.give(x);
@@ -926,7 +929,9 @@ int decoder_fwd(ac_handle* h, hipStream_t st, const long long* toks, int B, int 
     if (dbg) { capture(h, st, y.raw, B); ws.give(y.raw.p); y.raw.p = nullptr; }
     x = y;
     for (int i = 0; i < c.num_ratios; ++i) {
-        rc = convtr_fwd(h, st, h->dec_up[i], x.elu, c.upsampling_ratios[i], Out{ws.take(), ws.take()}, B, &y);
+        const int cup = h->dec_up[i].N / c.upsampling_ratios[i];
+        const bool self_elu = cup == 32 && c.residual_kernel_size == 3 && c.compress == 2;   // rb_fused.h activates raw rows itself
+        rc = convtr_fwd(h, st, h->dec_up[i], x.elu, c.upsampling_ratios[i], Out{ws.take(), self_elu ? nullptr : ws.take()}, B, &y);
         if (rc) return rc;
         ws.give(x);
         x = y;

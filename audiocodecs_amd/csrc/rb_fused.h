@@ -7,7 +7,9 @@
 //     fused                         : 128 r + 128 r + 128 w               = 384 B
 // Persistent workgroups walk the (clip, time-tile) list; the next tile's rows are loaded into
 // registers while the current tile is in the MFMA phases (v_mfma_f32_16x16x4_f32, K order as in
-// tap_gemm.h: taps ascending, channels in 16-wide steps).  Weights sit in LDS for the whole kernel.
+// tap_gemm.h: taps ascending, channels in 16-wide steps).  Weights live in REGISTERS as MFMA B fragments for
+// the whole kernel (waves split the output columns NSPLIT ways so a wave's share fits), which keeps LDS at
+// ~45 KB per workgroup: two to three workgroups per CU hide each other's load / barrier phases.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "tap_gemm.h"
@@ -15,7 +17,8 @@
 namespace ac {
 
 struct RbFusedParams {
-    const float* xe;    // [B][L][C] ELU'd input
+    const float* xe;    // [B][L][C] ELU'd input, or null: ELU is applied to the raw rows while staging (the
+                        // C=32 block is HBM-bound, so a second flavour of x in HBM costs more than the VALU work)
     const float* xr;    // [B][L][C] raw input
     const float* w3;    // packed [C/2][3C]   (k = tap*C + ci)
     const float* b3;    // [C/2]
@@ -27,53 +30,61 @@ struct RbFusedParams {
     int ntiles;         // tiles per clip
 };
 
-template <int C, int BM>
+template <int C, int BM, int NSPLIT>
 struct RbCfg {
     static constexpr int HC = C / 2, CP = C + 4, HP = HC + 4;
-    static constexpr int K3 = 3 * C, K3P = K3 + 4, KF = HC + C, KFP = KF + 4;
+    static constexpr int K3 = 3 * C, KF = HC + C;
     static constexpr int XE_ROWS = BM + 2;
     static constexpr int XE_FLOATS = XE_ROWS * CP, XR_FLOATS = BM * CP, H_FLOATS = BM * HP;
-    static constexpr int W3_FLOATS = HC * K3P, WF_FLOATS = C * KFP;
     static constexpr int XE_SLOTS = (XE_ROWS * (C / 4) + 255) / 256, XR_SLOTS = (BM * (C / 4) + 255) / 256;
-    static constexpr size_t lds_bytes = (size_t)(2 * (XE_FLOATS + XR_FLOATS) + H_FLOATS + W3_FLOATS + WF_FLOATS) * 4;
+    static constexpr int MW = 4 / NSPLIT;                    // wave groups along time
+    static constexpr int MS = BM / MW / 16;                  // 16-row sub-tiles per wave
+    static constexpr int NA = HC / NSPLIT / 16, NB = C / NSPLIT / 16;   // 16-column sub-tiles per wave (stage A / B)
+    static constexpr size_t lds_bytes = (size_t)(XE_FLOATS + XR_FLOATS + H_FLOATS) * 4;
 };
 
-template <int C, int BM>
+template <int C, int BM, int NSPLIT>
 __global__ __launch_bounds__(256) void rb_fused_kernel(const RbFusedParams p) {
-    using Cfg = RbCfg<C, BM>;
-    constexpr int HC = Cfg::HC, CP = Cfg::CP, HP = Cfg::HP, K3P = Cfg::K3P, KFP = Cfg::KFP;
-    constexpr int MS = BM / 64;            // 16-row sub-tiles per wave
-    constexpr int NA = HC / 16, NB = C / 16;
+    using Cfg = RbCfg<C, BM, NSPLIT>;
+    constexpr int HC = Cfg::HC, CP = Cfg::CP, HP = Cfg::HP, K3 = Cfg::K3, KF = Cfg::KF;
+    constexpr int MS = Cfg::MS, NA = Cfg::NA, NB = Cfg::NB;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Xe0 = smem;                                         // [2][XE_ROWS][CP]
-    float* Xr0 = Xe0 + 2 * Cfg::XE_FLOATS;                     // [2][BM][CP]
-    float* Hs = Xr0 + 2 * Cfg::XR_FLOATS;                      // [BM][HP]
-    float* W3s = Hs + Cfg::H_FLOATS;                           // [HC][K3P]
-    float* Wfs = W3s + Cfg::W3_FLOATS;                         // [C][KFP]
+    float* Xe = smem;                                          // [XE_ROWS][CP]
+    float* Xr = Xe + Cfg::XE_FLOATS;                           // [BM][CP]  (reused as the output tile)
+    float* Hs = Xr + Cfg::XR_FLOATS;                           // [BM][HP]
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int mg = wave / NSPLIT, ng = wave % NSPLIT;
     const int li = lane & 15, kq = lane >> 4;
     const int total = p.B * p.ntiles;
+    const int r0 = mg * (BM / Cfg::MW);                        // this wave's first row in the tile
+    const int na0 = ng * NA * 16, nb0 = ng * NB * 16;          // this wave's first output column (stage A / B)
 
-    // ---- weights -> LDS (once)
-    for (int e = tid; e < HC * (Cfg::K3 / 4); e += 256) {
-        const int n = e / (Cfg::K3 / 4), q = e % (Cfg::K3 / 4);
-        *reinterpret_cast<f32x4*>(&W3s[n * K3P + 4 * q]) = *reinterpret_cast<const f32x4*>(p.w3 + (long long)n * Cfg::K3 + 4 * q);
-    }
-    for (int e = tid; e < C * (Cfg::KF / 4); e += 256) {
-        const int n = e / (Cfg::KF / 4), q = e % (Cfg::KF / 4);
-        *reinterpret_cast<f32x4*>(&Wfs[n * KFP + 4 * q]) = *reinterpret_cast<const f32x4*>(p.wf + (long long)n * Cfg::KF + 4 * q);
-    }
+    // ---- this wave's weight fragments -> registers (once): lane (li, kq) holds W[n0 + 16c + li][16ks + 4kq .. +3]
+    f32x4 w3r[3][C / 16][NA], wfr[KF / 16][NB];
     float b3v[NA], bfv[NB];
 #pragma unroll
-    for (int c = 0; c < NA; ++c) b3v[c] = p.b3[c * 16 + li];
+    for (int c = 0; c < NA; ++c) {
+        b3v[c] = p.b3[na0 + c * 16 + li];
 #pragma unroll
-    for (int c = 0; c < NB; ++c) bfv[c] = p.bf[c * 16 + li];
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int ks = 0; ks < C / 16; ++ks)
+                w3r[j][ks][c] = *reinterpret_cast<const f32x4*>(p.w3 + (long long)(na0 + c * 16 + li) * K3 + j * C + ks * 16 + 4 * kq);
+    }
+#pragma unroll
+    for (int c = 0; c < NB; ++c) {
+        bfv[c] = p.bf[nb0 + c * 16 + li];
+#pragma unroll
+        for (int ks = 0; ks < KF / 16; ++ks)
+            wfr[ks][c] = *reinterpret_cast<const f32x4*>(p.wf + (long long)(nb0 + c * 16 + li) * KF + ks * 16 + 4 * kq);
+    }
 
     f32x4 re[Cfg::XE_SLOTS], rr[Cfg::XR_SLOTS];
     auto load_tile = [&](int tile) {
         const int b = tile / p.ntiles, t0 = (tile % p.ntiles) * BM;
-        const float* xe = p.xe + (long long)b * p.L * C;
+        const float* xe = (p.xe ? p.xe : p.xr) + (long long)b * p.L * C;
         const float* xr = p.xr + (long long)b * p.L * C;
 #pragma unroll
         for (int i = 0; i < Cfg::XE_SLOTS; ++i) {
@@ -94,36 +105,30 @@ __global__ __launch_bounds__(256) void rb_fused_kernel(const RbFusedParams p) {
             if (row < BM && t0 + row < p.L) rr[i] = *reinterpret_cast<const f32x4*>(xr + (long long)(t0 + row) * C + 4 * q);
         }
     };
-    auto store_tile = [&](int buf) {
-        float* xe = Xe0 + buf * Cfg::XE_FLOATS;
-        float* xr = Xr0 + buf * Cfg::XR_FLOATS;
+    auto store_tile = [&]() {
 #pragma unroll
         for (int i = 0; i < Cfg::XE_SLOTS; ++i) {
             const int e = tid + i * 256;
             const int row = e / (C / 4), q = e % (C / 4);
-            if (row < Cfg::XE_ROWS) *reinterpret_cast<f32x4*>(&xe[row * CP + 4 * q]) = re[i];
+            if (row < Cfg::XE_ROWS) *reinterpret_cast<f32x4*>(&Xe[row * CP + 4 * q]) = p.xe ? re[i] : elu4(re[i]);
         }
 #pragma unroll
         for (int i = 0; i < Cfg::XR_SLOTS; ++i) {
             const int e = tid + i * 256;
             const int row = e / (C / 4), q = e % (C / 4);
-            if (row < BM) *reinterpret_cast<f32x4*>(&xr[row * CP + 4 * q]) = rr[i];
+            if (row < BM) *reinterpret_cast<f32x4*>(&Xr[row * CP + 4 * q]) = rr[i];
         }
     };
 
     int tile = blockIdx.x;
     if (tile >= total) return;
     load_tile(tile);
-    store_tile(0);
+    store_tile();
     __syncthreads();
-    int buf = 0;
     for (; tile < total; tile += gridDim.x) {
         const int next = tile + gridDim.x;
-        if (next < total) load_tile(next);
-        const float* Xe = Xe0 + buf * Cfg::XE_FLOATS;
-        float* Xr = Xr0 + buf * Cfg::XR_FLOATS;
-        const int r0 = wave * (BM / 4);                         // this wave's first row in the tile
-        // ---- stage A: hidden = ELU(conv_k3(xe) + b3) -> Hs (each wave its own rows)
+        if (next < total) load_tile(next);                      // in flight during both MFMA stages
+        // ---- stage A: hidden = ELU(conv_k3(xe) + b3) -> Hs
         {
             f32x4 acc[MS][NA];
 #pragma unroll
@@ -134,25 +139,23 @@ __global__ __launch_bounds__(256) void rb_fused_kernel(const RbFusedParams p) {
             for (int j = 0; j < 3; ++j)
 #pragma unroll
                 for (int ks = 0; ks < C / 16; ++ks) {
-                    f32x4 af[MS], bf[NA];
+                    f32x4 af[MS];
 #pragma unroll
                     for (int a = 0; a < MS; ++a) af[a] = *reinterpret_cast<const f32x4*>(&Xe[(r0 + a * 16 + li + j) * CP + ks * 16 + 4 * kq]);
-#pragma unroll
-                    for (int c = 0; c < NA; ++c) bf[c] = *reinterpret_cast<const f32x4*>(&W3s[(c * 16 + li) * K3P + j * C + ks * 16 + 4 * kq]);
 #pragma unroll
                     for (int u = 0; u < 4; ++u)
 #pragma unroll
                         for (int a = 0; a < MS; ++a)
 #pragma unroll
                             for (int c = 0; c < NA; ++c)
-                                acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a][u], bf[c][u], acc[a][c], 0, 0, 0);
+                                acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a][u], w3r[j][ks][c][u], acc[a][c], 0, 0, 0);
                 }
 #pragma unroll
             for (int a = 0; a < MS; ++a)
 #pragma unroll
                 for (int c = 0; c < NA; ++c)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) Hs[(r0 + a * 16 + kq * 4 + r) * HP + c * 16 + li] = elu1(acc[a][c][r]);
+                    for (int r = 0; r < 4; ++r) Hs[(r0 + a * 16 + kq * 4 + r) * HP + na0 + c * 16 + li] = elu1(acc[a][c][r]);
         }
         __syncthreads();
         // ---- stage B: y = [hidden | xr] * [W1; Ws] + bf
@@ -162,29 +165,27 @@ __global__ __launch_bounds__(256) void rb_fused_kernel(const RbFusedParams p) {
 #pragma unroll
             for (int c = 0; c < NB; ++c) acc[a][c] = f32x4{bfv[c], bfv[c], bfv[c], bfv[c]};
 #pragma unroll
-        for (int ks = 0; ks < (HC + C) / 16; ++ks) {
-            f32x4 af[MS], bf[NB];
+        for (int ks = 0; ks < KF / 16; ++ks) {
+            f32x4 af[MS];
 #pragma unroll
             for (int a = 0; a < MS; ++a)
                 af[a] = ks < HC / 16 ? *reinterpret_cast<const f32x4*>(&Hs[(r0 + a * 16 + li) * HP + ks * 16 + 4 * kq])
                                      : *reinterpret_cast<const f32x4*>(&Xr[(r0 + a * 16 + li) * CP + (ks - HC / 16) * 16 + 4 * kq]);
-#pragma unroll
-            for (int c = 0; c < NB; ++c) bf[c] = *reinterpret_cast<const f32x4*>(&Wfs[(c * 16 + li) * KFP + ks * 16 + 4 * kq]);
 #pragma unroll
             for (int u = 0; u < 4; ++u)
 #pragma unroll
                 for (int a = 0; a < MS; ++a)
 #pragma unroll
                     for (int c = 0; c < NB; ++c)
-                        acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a][u], bf[c][u], acc[a][c], 0, 0, 0);
+                        acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a][u], wfr[ks][c][u], acc[a][c], 0, 0, 0);
         }
-        __syncthreads();                                        // all reads of Xr[buf] done: reuse it as the output tile
+        __syncthreads();                                        // every wave is done reading Xr: reuse it as the output tile
 #pragma unroll
         for (int a = 0; a < MS; ++a)
 #pragma unroll
             for (int c = 0; c < NB; ++c)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) Xr[(r0 + a * 16 + kq * 4 + r) * CP + c * 16 + li] = acc[a][c][r];
+                for (int r = 0; r < 4; ++r) Xr[(r0 + a * 16 + kq * 4 + r) * CP + nb0 + c * 16 + li] = acc[a][c][r];
         __syncthreads();
         {
             const int b = tile / p.ntiles, t0 = (tile % p.ntiles) * BM;
@@ -199,9 +200,9 @@ __global__ __launch_bounds__(256) void rb_fused_kernel(const RbFusedParams p) {
                 }
             }
         }
-        if (next < total) store_tile(buf ^ 1);
+        __syncthreads();                                        // output tile drained before the slabs are refilled
+        if (next < total) store_tile();
         __syncthreads();
-        buf ^= 1;
     }
 }
 
