@@ -23,10 +23,13 @@ int main() {
     p.w = dw; p.bias = db; p.y = dy; p.y_elu = nullptr; p.y_bs = (long long)M * N; p.y_rs = N; p.B = B; p.M = M; p.N = N; p.Ktot = K;
     using Cfg = Tap4Cfg<2, 2, 4, 4>;
     p.mtiles = (M + Cfg::BM - 1) / Cfg::BM; p.ntiles = 1;
-    CK(hipFuncSetAttribute((const void*)tap_gemm4_kernel<2, 2, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::lds_bytes));
-    for (int it = 0; it < 2; ++it) {
-        hipLaunchKernelGGL((tap_gemm4_kernel<2, 2, 4, 4>), dim3(B * p.mtiles), dim3(Cfg::NT), Cfg::lds_bytes, 0, p);
-        CK(hipDeviceSynchronize());
+    CK(hipFuncSetAttribute((const void*)tap_gemm4_kernel<2, 2, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int it = 0; it < 3; ++it) {
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL((tap_gemm4_kernel<2, 2, 4, 4>), dim3(B * p.mtiles), dim3(Cfg::NT), getenv("ONE_PER_CU") ? 120 * 1024 : Cfg::lds_bytes, 0, p);
+        CK(hipEventRecord(e1)); CK(hipDeviceSynchronize());
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1)); printf("kernel %.1f us  (%.1f TF/s)\n", ms * 1e3, 2.0 * B * M * N * K / ms / 1e9);
     }
     std::vector<unsigned long long> t(NTR);
     CK(hipMemcpy(t.data(), dtr, NTR * 8, hipMemcpyDeviceToHost));
