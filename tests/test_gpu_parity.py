@@ -149,6 +149,27 @@ def test_against_oracle_on_fresh_inputs(codecs, checkpoints):
     assert torch.equal(rec2, codec.toks_to_sig(toks))
 
 
+@pytest.mark.parametrize("B,T", [(33, 6400), (1, 48000), (5, 3333)])
+def test_odd_batches_against_oracle(B, T, codecs, checkpoints):
+    """Batch sizes that leave the 32-clip LSTM tile / 16-frame RVQ tile partially filled."""
+    from oracle import encodec_oracle as O
+
+    cfg, sd = checkpoints("full", 0)
+    codec = codecs("full", 0)
+    W = O.fold_weight_norm(sd)
+    W64 = O.fold_weight_norm(sd, torch.float64)
+    sig = noise(1000 + B, B, T)
+    with torch.no_grad():
+        otoks = O.sig_to_toks(cfg, W, sig)
+        _, m64 = O.sig_to_toks(cfg, W64, sig.double(), None, 8, True)
+        orec = O.toks_to_sig(cfg, W, otoks)
+    toks = codec.sig_to_toks(sig.cuda())
+    n, bad, excused = tokens_match_up_to_ties(toks.cpu().numpy(), otoks.numpy(), m64.numpy())
+    assert bad == 0 and float((toks.cpu() == otoks).float().mean()) > 0.995
+    rec = codec.toks_to_sig(otoks.cuda()).cpu()
+    assert rms((rec - orec).numpy()) < 1e-5
+
+
 def test_rest_of_codec_api(codecs, checkpoints):
     from oracle import encodec_oracle as O
 
