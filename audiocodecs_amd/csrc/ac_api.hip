@@ -77,6 +77,8 @@ struct ac_handle {
     // test hook: copy every layer output (standard [B][L][C] layout) into a caller buffer
     float* dbg = nullptr;
     size_t dbg_cap = 0, dbg_used = 0;
+    // kernels that already got their > 64 KB dynamic-LDS opt-in on this handle's device
+    std::vector<const void*> lds_opted;
     // profiling
     bool prof = false;
     std::vector<ProfRec> recs;
@@ -104,6 +106,16 @@ int fail(ac_handle* h, int code, const char* fmt, ...) {
     } while (0)
 
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// More than 64 KB of dynamic LDS must be opted into per kernel (and per device): once per handle.
+int ensure_lds(ac_handle* h, const void* func, size_t bytes) {
+    if (bytes <= 64 * 1024) return AC_OK;
+    for (const void* f : h->lds_opted)
+        if (f == func) return AC_OK;
+    HIPCHK(h, hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    h->lds_opted.push_back(func);
+    return AC_OK;
+}
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // ---------------------------------------------------------------------------------------------
@@ -377,12 +389,7 @@ int launch_tap4(ac_handle* h, const TapGemmParams& p0, hipStream_t st) {
     TapGemmParams p = p0;
     p.mtiles = cdiv(p.M, Cfg::BM);
     p.ntiles = cdiv(p.N, Cfg::BN);
-    static bool attr_set = false;   // > 64 KB of dynamic LDS must be opted into once per kernel
-    if (!attr_set) {
-        HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(tap_gemm4_kernel<WGM, WGN, WM, WN>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::lds_bytes));
-        attr_set = true;
-    }
+    if (int rc = ensure_lds(h, reinterpret_cast<const void*>(tap_gemm4_kernel<WGM, WGN, WM, WN>), Cfg::lds_bytes)) return rc;
     const long long blocks = (long long)p.B * p.mtiles * p.ntiles;
     const size_t lds = Cfg::lds_bytes;
     hipLaunchKernelGGL((tap_gemm4_kernel<WGM, WGN, WM, WN>), dim3((unsigned)blocks), dim3(Cfg::NT), lds, st, p);
@@ -531,12 +538,7 @@ int launch_rb_fused(ac_handle* h, hipStream_t st, const ResBlockPlan& rb, const 
     p.L = x.raw.L;
     p.Lp = x.raw.L > 2 ? x.raw.L : 3;
     p.ntiles = cdiv(x.raw.L, BM);
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(rb_fused_kernel<C, BM, NSPLIT>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::lds_bytes));
-        attr_set = true;
-    }
+    if (int rc = ensure_lds(h, reinterpret_cast<const void*>(rb_fused_kernel<C, BM, NSPLIT>), Cfg::lds_bytes)) return rc;
     const long long total = (long long)B * p.ntiles;
     const int grid = (int)std::min<long long>(total, 512);   // two workgroups per CU (VGPR-limited), persistent
     const size_t lds = Cfg::lds_bytes;
@@ -628,11 +630,7 @@ int head_fwd(ac_handle* h, hipStream_t st, const Act& x, int B, float* sig) {
     p.k = c.last_kernel_size;
     p.Lp = x.L > c.last_kernel_size - 1 ? x.L : c.last_kernel_size;
     const size_t lds = ((size_t)(HEAD_TT + THIN_MAXK) * (F + 4) + (size_t)THIN_MAXK * F) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set && lds > 48 * 1024) {
-        HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(head_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    if (int rc = ensure_lds(h, reinterpret_cast<const void*>(head_kernel), lds)) return rc;
     {
         ProfScope ps(h, st, "head_kernel", 2.0 * B * (double)x.L * F * c.last_kernel_size, (double)B * x.L * 4.0 * (F + 1));
         hipLaunchKernelGGL(head_kernel, dim3(cdiv(x.L, HEAD_TT), B), dim3(256), lds, st, p);

@@ -105,7 +105,8 @@ __global__ __launch_bounds__(WGM* WGN * 64) void tap_gemm4_kernel(const TapGemmP
     // ---- segment state (wave-uniform)
     int si = 0, c0 = 0, j = 0;
     int seg_J, seg_Cw, seg_kofs;
-    bool seg_interior;
+    bool seg_interior;      // fast loads: per-slot constant row offsets (+ a zero mask on clip-edge tiles)
+    unsigned a_zero = 0;    // bit i: slot i is padding that reads as zero (edge tiles of stride-1 segments)
     __amdgpu_buffer_rsrc_t a_rs;
     auto enter_segment = [&](int s_) {
         const TapSeg& sg = p.seg[s_];
@@ -114,7 +115,11 @@ __global__ __launch_bounds__(WGM* WGN * 64) void tap_gemm4_kernel(const TapGemmP
         seg_kofs = sg.kofs;
         const long long lo = (long long)(m0 - (sg.J - 1)) * sg.s;
         const long long hi = (long long)(m0 + BM - 1) * sg.s + (sg.s - 1);
-        seg_interior = lo >= 0 && hi < sg.L;
+        const bool inside = lo >= 0 && hi < sg.L;
+        // stride-1 segments: a slot's source row does not depend on the chunk, so even clip-edge tiles
+        // (reflect / zero rows, ragged tail; 2 of 6 tiles at 750 frames) keep the constant-offset loads
+        seg_interior = inside || sg.s == 1;
+        a_zero = 0;
         const int pitch = sg.s == 1 ? (int)sg.ts : seg_Cw;   // floats between consecutive reshaped rows
         a_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(sg.x + (long long)b * sg.bs), 0,
                                                  (int)(((long long)(sg.L - 1) * sg.ts + sg.cin) * 4), 0x00020000);
@@ -123,7 +128,13 @@ __global__ __launch_bounds__(WGM* WGN * 64) void tap_gemm4_kernel(const TapGemmP
         for (int i = 0; i < A_SLOTS; ++i) {
             const int e = tid + i * NT;
             const int row = e / (KC / 4), q = e % (KC / 4);
-            a_boff[i] = ((m0 - (sg.J - 1) + (row < R ? row : sg.J - 1)) * pitch + 4 * q) * 4;   // rows past R: any valid row
+            int srow = m0 - (sg.J - 1) + (row < R ? row : sg.J - 1);                     // rows past R: any valid row
+            if (!inside && sg.s == 1) {
+                const long long jj = row < R ? src_index(sg, srow) : 0;                   // [HF]:139-162 reflect / zero rule
+                if (jj < 0) a_zero |= 1u << i;
+                srow = jj < 0 ? 0 : (int)jj;
+            }
+            a_boff[i] = (srow * pitch + 4 * q) * 4;
         }
     };
     f32x4 ra[A_SLOTS], rw[W_SLOTS];
@@ -131,6 +142,11 @@ __global__ __launch_bounds__(WGM* WGN * 64) void tap_gemm4_kernel(const TapGemmP
         if (seg_interior) {
 #pragma unroll
             for (int i = 0; i < A_SLOTS; ++i) ra[i] = bufload16(a_rs, a_boff[i], c_ * 4);
+            if (a_zero) {
+#pragma unroll
+                for (int i = 0; i < A_SLOTS; ++i)
+                    if (a_zero & (1u << i)) ra[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
         } else {
             // exact edge handling ([HF]:139-162 reflect rule, zero pad of the transposed conv, ragged tail)
             const TapSeg& sg = p.seg[s_];

@@ -19,6 +19,7 @@
  *  - return 0 on success, a negative AC_E* code on failure; never throws across the ABI;
  *    ac_last_error() returns a human-readable message for the last failure on that handle;
  *  - a handle is not thread-safe; one handle per process/GPU like the reference's one codec/rank;
+ *    the handle's device (ac_config.device) must be the current HIP device when its entry points run;
  *  - activations are fp32 ("parity mode": fp32 MFMA v_mfma_f32_16x16x4_f32, exact fp32 products and
  *    accumulation); tokens are int64 like the reference's.
  */
