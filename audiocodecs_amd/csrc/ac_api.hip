@@ -748,17 +748,25 @@ int rvq_encode_fwd(ac_handle* h, hipStream_t st, const float* feats, int F, int 
     p.C = h->cfg.codebook_size;
     p.K = K;
     const int HV = p.H / 16;
-    const dim3 grid(cdiv(F, 16)), block(64);
+    // frames per wave: 48 once there are enough frames to fill every SIMD (1024) with one wave
+    const int MS = (HV <= 8 && F >= 1024 * 32) ? 3 : 1;
+    const dim3 grid(cdiv(F, 16 * MS)), block(64);
     ProfScope ps(h, st, "rvq_encode_kernel", 2.0 * F * (double)p.C * p.H * K,
                  (double)F * p.H * 4 + (double)F * K * 8 + (double)K * p.C * p.H * 4);
-    switch (HV) {
-        case 1: hipLaunchKernelGGL(rvq_encode_kernel<1>, grid, block, 0, st, p); break;
-        case 2: hipLaunchKernelGGL(rvq_encode_kernel<2>, grid, block, 0, st, p); break;
-        case 4: hipLaunchKernelGGL(rvq_encode_kernel<4>, grid, block, 0, st, p); break;
-        case 8: hipLaunchKernelGGL(rvq_encode_kernel<8>, grid, block, 0, st, p); break;
-        case 16: hipLaunchKernelGGL(rvq_encode_kernel<16>, grid, block, 0, st, p); break;
+#define RVQ_CASE(HV_, MS_) hipLaunchKernelGGL((rvq_encode_kernel<HV_, MS_>), grid, block, 0, st, p)
+    switch (HV * 10 + MS) {
+        case 11: RVQ_CASE(1, 1); break;
+        case 13: RVQ_CASE(1, 3); break;
+        case 21: RVQ_CASE(2, 1); break;
+        case 23: RVQ_CASE(2, 3); break;
+        case 41: RVQ_CASE(4, 1); break;
+        case 43: RVQ_CASE(4, 3); break;
+        case 81: RVQ_CASE(8, 1); break;
+        case 83: RVQ_CASE(8, 3); break;
+        case 161: RVQ_CASE(16, 1); break;
         default: return fail(h, AC_EINVAL, "hidden_size %d unsupported by the RVQ kernel (need 16*{1,2,4,8,16})", p.H);
     }
+#undef RVQ_CASE
     HIPCHK(h, hipGetLastError());
     return AC_OK;
 }
@@ -964,7 +972,7 @@ int ac_create(const ac_config* cfg, ac_handle** out) {
     *out = nullptr;
     if (cfg->struct_size != (int32_t)sizeof(ac_config)) return AC_EINVAL;
     if (cfg->num_ratios < 1 || cfg->num_ratios > AC_MAX_RATIOS || cfg->num_filters < 1 || cfg->hidden_size < 16 ||
-        cfg->hidden_size % 16 || cfg->compress < 1 || cfg->num_lstm_layers < 1 || cfg->num_lstm_layers > 2 || cfg->codebook_size % 16 ||
+        cfg->hidden_size % 16 || cfg->compress < 1 || cfg->num_lstm_layers < 1 || cfg->num_lstm_layers > 2 || cfg->codebook_size % 32 ||
         cfg->codebook_size < 16 || cfg->num_quantizers < 1 || cfg->kernel_size < 1 || cfg->kernel_size > 8 ||
         cfg->last_kernel_size < 1 || cfg->last_kernel_size > 8 || cfg->residual_kernel_size < 1 || cfg->residual_kernel_size > 8)
         return AC_EINVAL;
