@@ -1,7 +1,7 @@
 // Developer micro-benchmark (not part of the product): times tap_gemm variants on the layer shapes
 // of BASELINE.json config 2 (EnCodec-24k, 64 x 10 s; batch reduced with -b) with interleaved A/B
 // rounds in ONE process, and checks the variants against each other.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 dev_bench.hip -o dev_bench && ./dev_bench -b 8
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/ubench/dev_bench.hip -o dev_bench_bin && ./dev_bench_bin -b 64
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -13,10 +13,8 @@
 #include <string>
 #include <vector>
 
-#include "tap_gemm.h"
-#include "tap_gemm2.h"
-#include "tap_gemm3.h"
-#include "tap_gemm4.h"
+#include "../../audiocodecs_amd/csrc/tap_gemm.h"
+#include "../../audiocodecs_amd/csrc/tap_gemm4.h"
 
 using namespace ac;
 
@@ -56,24 +54,6 @@ void run_v1(TapGemmParams p, hipStream_t st) {
     const size_t lds = tap_gemm_lds_bytes<WGM, WGN, WM, WN>();
     hipLaunchKernelGGL((tap_gemm_kernel<WGM, WGN, WM, WN, true>), dim3(p.B * p.mtiles * p.ntiles), dim3(WGM * WGN * 64), lds, st, p);
 }
-template <int WGM, int WGN, int WM, int WN>
-void run_v2(TapGemmParams p, hipStream_t st) {
-    using Cfg = TapCfg<WGM, WGN, WM, WN>;
-    p.mtiles = (p.M + Cfg::BM - 1) / Cfg::BM; p.ntiles = (p.N + Cfg::BN - 1) / Cfg::BN;
-    static bool once = false;
-    if (!once) { once = true; CK(hipFuncSetAttribute((const void*)tap_gemm2_kernel<WGM, WGN, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::lds_bytes)); }
-    hipLaunchKernelGGL((tap_gemm2_kernel<WGM, WGN, WM, WN>), dim3(p.B * p.mtiles * p.ntiles), dim3(Cfg::NT), Cfg::lds_bytes, st, p);
-}
-
-template <int WGM, int WGN, int WM, int WN>
-void run_v3(TapGemmParams p, hipStream_t st) {
-    using Cfg = Tap3Cfg<WGM, WGN, WM, WN>;
-    p.mtiles = (p.M + Cfg::BM - 1) / Cfg::BM; p.ntiles = (p.N + Cfg::BN - 1) / Cfg::BN;
-    static bool once = false;
-    if (!once) { once = true; CK(hipFuncSetAttribute((const void*)tap_gemm3_kernel<WGM, WGN, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::lds_bytes)); }
-    hipLaunchKernelGGL((tap_gemm3_kernel<WGM, WGN, WM, WN>), dim3(p.B * p.mtiles * p.ntiles), dim3(Cfg::NT), Cfg::lds_bytes, st, p);
-}
-
 template <int WGM, int WGN, int WM, int WN>
 void run_v4(TapGemmParams p, hipStream_t st) {
     using Cfg = Tap4Cfg<WGM, WGN, WM, WN>;
