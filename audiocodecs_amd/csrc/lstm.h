@@ -46,7 +46,15 @@ struct LstmLaunchParams {
     int B, D;
 };
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+// Gate non-linearities on the hardware exp2 / rcp units (v_exp_f32, v_rcp_f32: ~1 ulp each): absolute
+// error ~1e-7, the same class as the reference's vectorised CPU kernels; they sit on the critical path
+// of every one of the 1504 dependent launches.
+__device__ __forceinline__ float sigmoidf_(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) {
+    const float a = fminf(fabsf(x), 15.0f);                 // tanh(15) == 1 in fp32; avoids exp overflow
+    const float t = 1.0f - 2.0f * __frcp_rn(1.0f + __expf(2.0f * a));
+    return copysignf(t, x);
+}
 
 // h is only ever read back as the A operand of the next launch, so it is STORED in A-fragment order:
 // element (clip b, unit k) lives where lane (b%16, (k%16)/4) of k-step k/16 loads its 16-byte vector.
@@ -126,10 +134,10 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(const LstmLaunchParams p
 #pragma unroll
         for (int q = 0; q < 4; ++q) pre[q] = gpre[q] + (red[0][ms][row][q * 4 + ul] + red[1][ms][row][q * 4 + ul]);
         if (step) {
-            const float ig = sigmoidf_(pre[0]), fg = sigmoidf_(pre[1]), gg = tanhf(pre[2]), og = sigmoidf_(pre[3]);
+            const float ig = sigmoidf_(pre[0]), fg = sigmoidf_(pre[1]), gg = tanhf_(pre[2]), og = sigmoidf_(pre[3]);
             const long long o = (long long)eb * D + eu;
             const float cn = fg * cprev + ig * gg;
-            const float hn = og * tanhf(cn);
+            const float hn = og * tanhf_(cn);
             R.c[o] = cn;
             R.hnext[hfrag_index(eb, eu, D)] = hn;
             if (R.yout || R.yout_elu) {
