@@ -27,7 +27,7 @@ import torch
 from . import prng
 from .config import EncodecConfig
 
-__all__ = ["conv_specs", "synthetic_state_dict", "fold_weight_norm"]
+__all__ = ["conv_specs", "synthetic_state_dict", "fold_weight_norm", "mimi_conv_specs", "synthetic_mimi_state_dict", "mimi_codebook"]
 
 CODEBOOK_S0 = 0.10
 CODEBOOK_RHO = 0.94
@@ -141,3 +141,100 @@ def fold_weight_norm(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
         else:
             out[k] = v.detach().cpu().contiguous()
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# Mimi: key/shape layout of the third-party HF ``MimiModel.state_dict()`` the
+# reference wrapper loads (/root/reference/audiocodecs/mimi.py:45).  No weight-norm in this model.
+# ---------------------------------------------------------------------------------------------
+MIMI_CODEBOOK_S0 = 0.20
+MIMI_CODEBOOK_RHO = 0.97
+
+
+def mimi_conv_specs(cfg) -> List[Tuple[str, str, int, int, int, int, bool]]:
+    """(key prefix, kind, Cin, Cout, kernel, stride, has_bias) for every conv of the Mimi SEANet
+    encoder/decoder plus the stride-2 down/up-sample pair ([HF] mimi/modeling_mimi.py:462-484,
+    :934-955, :1194-1216).  ResBlocks have no shortcut conv (use_conv_shortcut=False)."""
+    F, H = cfg.num_filters, cfg.hidden_size
+    specs: List[Tuple[str, str, int, int, int, int, bool]] = []
+
+    def resblock(prefix: str, dim: int):
+        hid = dim // cfg.compress
+        specs.append((f"{prefix}.block.1.conv", "conv", dim, hid, cfg.residual_kernel_size, 1, True))
+        specs.append((f"{prefix}.block.3.conv", "conv", hid, dim, 1, 1, True))
+
+    specs.append(("encoder.layers.0.conv", "conv", 1, F, cfg.kernel_size, 1, True))
+    i, c = 1, F
+    for r in reversed(cfg.upsampling_ratios):
+        resblock(f"encoder.layers.{i}", c)
+        specs.append((f"encoder.layers.{i + 2}.conv", "conv", c, 2 * c, 2 * r, r, True))
+        i, c = i + 3, 2 * c
+    specs.append((f"encoder.layers.{i + 1}.conv", "conv", c, H, cfg.last_kernel_size, 1, True))
+    rs = cfg.resample_stride
+    specs.append(("downsample.conv", "conv", H, H, 2 * rs, rs, False))
+    specs.append(("upsample.conv", "convtr_dw", H, H, 2 * rs, rs, False))
+    specs.append(("decoder.layers.0.conv", "conv", H, c, cfg.kernel_size, 1, True))
+    i = 1
+    for r in cfg.upsampling_ratios:
+        specs.append((f"decoder.layers.{i + 1}.conv", "convtr", c, c // 2, 2 * r, r, True))
+        resblock(f"decoder.layers.{i + 2}", c // 2)
+        i, c = i + 3, c // 2
+    specs.append((f"decoder.layers.{i + 1}.conv", "conv", c, 1, cfg.last_kernel_size, 1, True))
+    return specs
+
+
+def synthetic_mimi_state_dict(cfg, seed: int = 0) -> Dict[str, torch.Tensor]:
+    """Seeded HF-format Mimi checkpoint (platform-exact draws from :mod:`prng`).
+
+    convs as for EnCodec (no weight-norm); linear layers ~ N(0, 1/in); LayerNorm weight ~ U(0.8, 1.2),
+    bias ~ N(0, 0.02^2); LayerScale ~ U(0.1, 0.4) (the trained model's scales are O(0.1-1), the 0.01
+    init would make the transformers near-identity and untested); codebooks stored the way the
+    model holds them, as ``embed_sum`` and ``cluster_usage`` with usage ~ U(0.5, 2):
+    ``embed = embed_sum / clamp(cluster_usage, 1e-5)`` ([HF] :980-983)."""
+    sd: Dict[str, torch.Tensor] = {}
+    for prefix, kind, cin, cout, k, s, has_bias in mimi_conv_specs(cfg):
+        if kind == "conv":
+            shape, fan_in = (cout, cin, k), cin * k
+        elif kind == "convtr":
+            shape, fan_in = (cin, cout, k), cin * k / s
+        else:  # depthwise transposed conv: groups == channels, weight [C, 1, k]
+            shape, fan_in = (cin, 1, k), k / s
+        w = prng.normal(seed, prefix + ".w", shape) * (1.0 / np.sqrt(fan_in))
+        w = w * prng.uniform(seed, prefix + ".g", (shape[0], 1, 1), 0.9, 1.1)
+        sd[f"{prefix}.weight"] = _f32(w)
+        if has_bias:
+            sd[f"{prefix}.bias"] = _f32(prng.normal(seed, prefix + ".b", (cout,)) * 0.02)
+    H, I = cfg.hidden_size, cfg.intermediate_size
+    A = cfg.num_attention_heads * cfg.head_dim
+    for part in ("encoder_transformer", "decoder_transformer"):
+        for l in range(cfg.num_hidden_layers):
+            p = f"{part}.layers.{l}"
+            for nm, (o, i_) in {"self_attn.q_proj": (A, H), "self_attn.k_proj": (A, H), "self_attn.v_proj": (A, H),
+                                "self_attn.o_proj": (H, A), "mlp.fc1": (I, H), "mlp.fc2": (H, I)}.items():
+                sd[f"{p}.{nm}.weight"] = _f32(prng.normal(seed, f"{p}.{nm}", (o, i_)) / np.sqrt(i_))
+            for nm in ("input_layernorm", "post_attention_layernorm"):
+                sd[f"{p}.{nm}.weight"] = _f32(prng.uniform(seed, f"{p}.{nm}.w", (H,), 0.8, 1.2))
+                sd[f"{p}.{nm}.bias"] = _f32(prng.normal(seed, f"{p}.{nm}.b", (H,)) * 0.02)
+            for nm in ("self_attn_layer_scale", "mlp_layer_scale"):
+                sd[f"{p}.{nm}.scale"] = _f32(prng.uniform(seed, f"{p}.{nm}", (H,), 0.1, 0.4))
+    Dq = cfg.codebook_dim
+    nsem = cfg.num_semantic_quantizers
+    for part, nq, q0 in (("semantic", nsem, 0), ("acoustic", cfg.num_quantizers - nsem, 1)):
+        base = f"quantizer.{part}_residual_vector_quantizer"
+        sd[f"{base}.input_proj.weight"] = _f32(prng.normal(seed, f"{base}.in", (Dq, H, 1)) / np.sqrt(H))
+        sd[f"{base}.output_proj.weight"] = _f32(prng.normal(seed, f"{base}.out", (H, Dq, 1)) / np.sqrt(Dq))
+        for q in range(nq):
+            scale = MIMI_CODEBOOK_S0 * MIMI_CODEBOOK_RHO ** (q + q0 - (1 if part == "acoustic" else 0))
+            usage = prng.uniform(seed, f"{base}.{q}.usage", (cfg.codebook_size,), 0.5, 2.0)
+            e = prng.normal(seed, f"{base}.{q}.embed", (cfg.codebook_size, Dq)) * scale
+            cb = f"{base}.layers.{q}.codebook"
+            sd[f"{cb}.initialized"] = torch.tensor([1.0])
+            sd[f"{cb}.cluster_usage"] = _f32(usage)
+            sd[f"{cb}.embed_sum"] = _f32(e * usage[:, None])
+    return sd
+
+
+def mimi_codebook(sd: Dict[str, torch.Tensor], part: str, q: int) -> torch.Tensor:
+    """embed = embed_sum / clamp(cluster_usage, 1e-5)[:, None]  ([HF] mimi :980-983), fp32."""
+    cb = f"quantizer.{part}_residual_vector_quantizer.layers.{q}.codebook"
+    return sd[f"{cb}.embed_sum"].float() / sd[f"{cb}.cluster_usage"].float().clamp(min=1e-5)[:, None]

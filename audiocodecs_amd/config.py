@@ -12,7 +12,7 @@ import math
 from dataclasses import dataclass, field
 from typing import Tuple
 
-__all__ = ["EncodecConfig", "TINY", "ENCODEC_24KHZ"]
+__all__ = ["EncodecConfig", "TINY", "ENCODEC_24KHZ", "MimiConfig", "MIMI_24KHZ", "MIMI_TINY"]
 
 
 @dataclass(frozen=True)
@@ -58,3 +58,59 @@ ENCODEC_24KHZ = EncodecConfig()
 # Same topology, 234 942 parameters: small enough that every activation fits a fixture
 # (SURVEY.md Appendix A.5).  codebook_size stays 1024 so the wrapper's bandwidth mapping holds.
 TINY = EncodecConfig(num_filters=4, hidden_size=16)
+
+
+@dataclass(frozen=True)
+class MimiConfig:
+    """Fields of the third-party ``transformers.MimiConfig`` the Mimi path depends on (defaults =
+    ``kyutai/mimi``, what /root/reference/audiocodecs/mimi.py:45 loads).
+    Causal convs with constant (zero) padding, identity ResBlock shortcuts, no weight-norm, MHA
+    (num_key_value_heads == num_attention_heads), RoPE "default", exact-erf GELU."""
+
+    sampling_rate: int = 24000
+    num_filters: int = 64
+    hidden_size: int = 512
+    upsampling_ratios: Tuple[int, ...] = (8, 6, 5, 4)
+    kernel_size: int = 7
+    last_kernel_size: int = 3
+    residual_kernel_size: int = 3
+    compress: int = 2
+    codebook_size: int = 2048
+    codebook_dim: int = 256  # == vector_quantization_hidden_dimension
+    num_quantizers: int = 32
+    num_semantic_quantizers: int = 1
+    num_hidden_layers: int = 8
+    num_attention_heads: int = 8
+    head_dim: int = 64
+    intermediate_size: int = 2048
+    sliding_window: int = 250
+    rope_theta: float = 10000.0
+    norm_eps: float = 1e-5
+    resample_stride: int = 2  # encodec_frame_rate / frame_rate: the stride-2 down/up-sample pair
+
+    @property
+    def hop_length(self) -> int:
+        return int(math.prod(self.upsampling_ratios)) * self.resample_stride
+
+    @property
+    def frame_rate(self) -> float:
+        return self.sampling_rate / self.hop_length
+
+    @property
+    def seanet_dim(self) -> int:
+        return self.num_filters * 2 ** len(self.upsampling_ratios)
+
+    def num_frames(self, num_samples: int) -> int:
+        """ceil at every strided conv, then at the stride-2 down-sampler ([HF] mimi :1264-1275)."""
+        n = num_samples
+        for r in reversed(self.upsampling_ratios):
+            n = -(-n // r)
+        return -(-n // self.resample_stride)
+
+
+MIMI_24KHZ = MimiConfig()
+# Same topology at 1/8 width and 2 transformer layers: every activation fits a fixture.
+MIMI_TINY = MimiConfig(
+    num_filters=8, hidden_size=64, codebook_dim=32, num_hidden_layers=2, num_attention_heads=4, head_dim=16,
+    intermediate_size=128, sliding_window=6,
+)

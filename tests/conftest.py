@@ -41,3 +41,29 @@ def checkpoints():
         return _CKPT[key]
 
     return get
+
+
+@pytest.fixture(scope="session")
+def mimi_golden():
+    z = np.load(os.path.join(GOLDEN_DIR, "mimi_golden.npz"))
+    meta = json.loads(bytes(z["meta_json"]).decode())
+    return z, meta
+
+
+_MIMI_CKPT = {}
+
+
+@pytest.fixture(scope="session")
+def mimi_checkpoints():
+    """(cfg_name, seed) -> (MimiConfig, HF-format synthetic Mimi state dict); cached for the session."""
+    from audiocodecs_amd import checkpoint
+    from audiocodecs_amd.config import MIMI_24KHZ, MIMI_TINY
+
+    def get(cfg_name, seed):
+        key = (cfg_name, seed)
+        if key not in _MIMI_CKPT:
+            cfg = {"full": MIMI_24KHZ, "tiny": MIMI_TINY}[cfg_name]
+            _MIMI_CKPT[key] = (cfg, checkpoint.synthetic_mimi_state_dict(cfg, seed=seed))
+        return _MIMI_CKPT[key]
+
+    return get
