@@ -12,7 +12,7 @@ import os
 
 import torch  # noqa: F401  (loads libamdhip64 first)
 
-__all__ = ["lib", "lib_path", "AcConfig", "AcKernelStat", "NativeError", "check", "EXPORTS"]
+__all__ = ["lib", "lib_path", "AcConfig", "AcMimiConfig", "AcKernelStat", "NativeError", "check", "EXPORTS"]
 
 AC_MAX_RATIOS = 8
 lib_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libaudiocodecs_amd.so")
@@ -41,6 +41,34 @@ class AcConfig(C.Structure):
     ]
 
 
+class AcMimiConfig(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_int32),
+        ("sampling_rate", C.c_int32),
+        ("num_filters", C.c_int32),
+        ("hidden_size", C.c_int32),
+        ("num_ratios", C.c_int32),
+        ("upsampling_ratios", C.c_int32 * AC_MAX_RATIOS),
+        ("kernel_size", C.c_int32),
+        ("last_kernel_size", C.c_int32),
+        ("residual_kernel_size", C.c_int32),
+        ("compress", C.c_int32),
+        ("codebook_size", C.c_int32),
+        ("codebook_dim", C.c_int32),
+        ("num_quantizers", C.c_int32),
+        ("num_semantic_quantizers", C.c_int32),
+        ("num_hidden_layers", C.c_int32),
+        ("num_attention_heads", C.c_int32),
+        ("head_dim", C.c_int32),
+        ("intermediate_size", C.c_int32),
+        ("sliding_window", C.c_int32),
+        ("resample_stride", C.c_int32),
+        ("device", C.c_int32),
+        ("rope_theta", C.c_float),
+        ("norm_eps", C.c_float),
+    ]
+
+
 class AcKernelStat(C.Structure):
     _fields_ = [
         ("name", C.c_char * 48),
@@ -56,11 +84,13 @@ _vp, _i, _sz = C.c_void_p, C.c_int, C.c_size_t
 EXPORTS = {
     "ac_version": (_i, []),
     "ac_create": (_i, [C.POINTER(AcConfig), C.POINTER(_vp)]),
+    "ac_mimi_create": (_i, [C.POINTER(AcMimiConfig), C.POINTER(_vp)]),
     "ac_load_weights": (_i, [_vp, C.c_char_p, _vp, _sz]),
     "ac_finalize": (_i, [_vp]),
     "ac_num_frames": (_i, [_vp, _i]),
     "ac_hop_length": (_i, [_vp]),
     "ac_hidden_size": (_i, [_vp]),
+    "ac_codebook_dim": (_i, [_vp]),
     "ac_encode_workspace_bytes": (_sz, [_vp, _i, _i]),
     "ac_decode_workspace_bytes": (_sz, [_vp, _i, _i]),
     "ac_encode": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
@@ -68,7 +98,11 @@ EXPORTS = {
     "ac_decode": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "ac_quantize": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "ac_dequantize": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    "ac_quantizer_workspace_bytes": (_sz, [_vp, _i, _i]),
+    "ac_quantize_ws": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "ac_dequantize_ws": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "ac_embs": (_i, [_vp, _i, _vp, _vp]),
+    "ac_embs_projected": (_i, [_vp, _i, _vp, _vp]),
     "ac_resample": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
     "ac_profile_begin": (_i, [_vp]),
     "ac_profile_end": (_i, [_vp, C.POINTER(AcKernelStat), _i]),

@@ -18,6 +18,7 @@
 #include "tap_gemm4.h"
 #include "thin.h"
 #include "rb_fused.h"
+#include "mimi.h"
 
 using namespace ac;
 
@@ -31,6 +32,7 @@ struct ConvSpec {
 struct PackedGemm {      // one tap_gemm launch worth of weights
     size_t w_off = 0, b_off = 0;  // float offsets into the device blob
     int N = 0, Ktot = 0;
+    bool has_bias = true;
 };
 
 struct ResBlockPlan {
@@ -46,6 +48,25 @@ struct LstmPlan {
     std::vector<size_t> ihpk_off;   // W_ih per layer, same order (used by the in-step projection of layers >= 1)
 };
 
+struct MimiTfLayer {
+    PackedGemm qkv, o, fc1, fc2;                       // [3A][H], [H][A], [I][H], [H][I]; no biases
+    size_t ln1_w = 0, ln1_b = 0, ln2_w = 0, ln2_b = 0, sc_a = 0, sc_m = 0;
+};
+
+struct MimiPlan {
+    PackedGemm enc_stem, enc_final, down, dec_first, dec_head;
+    std::vector<ResBlockPlan> enc_rb, dec_rb;          // fused = the k1 conv alone (identity shortcut)
+    std::vector<PackedGemm> enc_down, dec_up;
+    std::vector<MimiTfLayer> enc_tf, dec_tf;
+    size_t up_w = 0;                                   // depthwise transposed conv [H][2*stride]
+    PackedGemm in_proj;                                // [2*Dq][H]: semantic rows, then acoustic rows
+    PackedGemm out_proj;                               // [H][2*Dq]: semantic | acoustic columns
+    size_t cb_plain = 0, cb_packed = 0, cb_ee = 0;     // [Q][C][Dq] in wrapper order (semantic first)
+    size_t rope_cos = 0, rope_sin = 0;                 // [rope_T][head_dim]
+    int rope_T = 0;
+    int D = 0;                                         // SEANet width at the bottleneck
+};
+
 struct ProfRec {
     int name_id;
     int count;
@@ -55,8 +76,13 @@ struct ProfRec {
 
 }  // namespace
 
+enum { ARCH_ENCODEC = 0, ARCH_MIMI = 1 };
+
 struct ac_handle {
+    int arch = ARCH_ENCODEC;
     ac_config cfg{};
+    ac_mimi_config mcfg{};
+    MimiPlan mimi;
     std::string err;
     std::map<std::string, std::vector<float>> host;
     bool finalized = false;
@@ -221,11 +247,12 @@ struct Packer {
         return off;
     }
     // plain conv (stride 1 or k = 2*stride): packed[n][tap*cin + ci] = w[n][ci][tap]
-    bool conv(const ConvSpec& s, PackedGemm& g) {
+    bool conv(const ConvSpec& s, PackedGemm& g, bool bias = true) {
         std::vector<float> w;
         if (!weight(s, w)) return false;
-        const std::vector<float>* b = get(s.prefix + ".bias", s.cout);
-        if (!b) return false;
+        const std::vector<float>* b = bias ? get(s.prefix + ".bias", s.cout) : nullptr;
+        if (bias && !b) return false;
+        g.has_bias = bias;
         g.N = s.cout;
         g.Ktot = s.k * s.cin;
         g.w_off = reserve((size_t)g.N * g.Ktot);
@@ -233,8 +260,10 @@ struct Packer {
             for (int ci = 0; ci < s.cin; ++ci)
                 for (int t = 0; t < s.k; ++t)
                     blob[g.w_off + (size_t)n * g.Ktot + (size_t)t * s.cin + ci] = w[((size_t)n * s.cin + ci) * s.k + t];
-        g.b_off = reserve(g.N);
-        std::copy(b->begin(), b->end(), blob.begin() + g.b_off);
+        if (bias) {
+            g.b_off = reserve(g.N);
+            std::copy(b->begin(), b->end(), blob.begin() + g.b_off);
+        }
         return true;
     }
     // transposed conv, k = 2*s: out row m = [x[m-1] | x[m]] * Wp,  n = p*cout + co,
@@ -398,7 +427,7 @@ int launch_tap4(ac_handle* h, const TapGemmParams& p0, hipStream_t st) {
 
 // One segment of the A operand for a conv reading `x` (time steps of C channels).  Inputs are
 // already activated by their producer (TapGemmParams::y_elu), so no segment carries ELU.
-TapSeg make_seg(const Act& x, int s, int J, bool reflect, int extra, int kofs, const float* rel_len) {
+TapSeg make_seg(const Act& x, int s, int J, int pad /*PAD_**/, int extra, int kofs, const float* rel_len) {
     TapSeg g{};
     g.x = x.p;
     g.bs = x.bs;
@@ -413,9 +442,9 @@ TapSeg make_seg(const Act& x, int s, int J, bool reflect, int extra, int kofs, c
     g.J = J;
     const int pad_left = (J - 1) * s;
     const int max_pad = std::max(pad_left, extra);
-    g.Lp = (reflect && x.L <= max_pad) ? max_pad + 1 : x.L;
-    g.lim = reflect ? x.L + extra : x.L;
-    g.reflect = reflect ? 1 : 0;
+    g.Lp = (pad == PAD_REFLECT && x.L <= max_pad) ? max_pad + 1 : x.L;
+    g.lim = pad != PAD_ZERO ? x.L + extra : x.L;
+    g.reflect = pad;
     g.elu = 0;
     g.kofs = kofs;
     return g;
@@ -484,9 +513,9 @@ int conv_fwd(ac_handle* h, hipStream_t st, const PackedGemm& g, const Act& x, in
     TapGemmParams p{};
     p.nseg = 1;
     if (s != 1 && k != 2 * s) return fail(h, AC_EINVAL, "strided conv needs kernel == 2*stride (got k=%d, s=%d)", k, s);
-    p.seg[0] = make_seg(x, s, s == 1 ? k : 2, true, extra, 0, rel_len);
+    p.seg[0] = make_seg(x, s, s == 1 ? k : 2, PAD_REFLECT, extra, 0, rel_len);
     p.w = h->blob + g.w_off;
-    p.bias = h->blob + g.b_off;
+    p.bias = g.has_bias ? h->blob + g.b_off : nullptr;
     p.y = out.raw;
     p.y_elu = out.elu;
     p.y_bs = out_bs;
@@ -506,7 +535,7 @@ int convtr_fwd(ac_handle* h, hipStream_t st, const PackedGemm& g, const Act& x, 
     const int cout = g.N / s;
     TapGemmParams p{};
     p.nseg = 1;
-    p.seg[0] = make_seg(x, 1, 2, false, 0, 0, nullptr);
+    p.seg[0] = make_seg(x, 1, 2, PAD_ZERO, 0, 0, nullptr);
     p.w = h->blob + g.w_off;
     p.bias = h->blob + g.b_off;
     p.y = out.raw;
@@ -522,9 +551,9 @@ int convtr_fwd(ac_handle* h, hipStream_t st, const PackedGemm& g, const Act& x, 
     return run_tap(h, st, p);
 }
 
-template <int C, int BM, int NSPLIT>
-int launch_rb_fused(ac_handle* h, hipStream_t st, const ResBlockPlan& rb, const Act2& x, Out out, int B) {
-    using Cfg = RbCfg<C, BM, NSPLIT>;
+template <int C, int BM, int NSPLIT, bool SC = true>
+int launch_rb_fused(ac_handle* h, hipStream_t st, const ResBlockPlan& rb, const Act2& x, Out out, int B, int pad = PAD_REFLECT) {
+    using Cfg = RbCfg<C, BM, NSPLIT, SC>;
     RbFusedParams p{};
     p.xe = x.elu.p;   // may be null: the kernel then activates the raw rows itself
     p.xr = x.raw.p;
@@ -538,15 +567,16 @@ int launch_rb_fused(ac_handle* h, hipStream_t st, const ResBlockPlan& rb, const 
     p.L = x.raw.L;
     p.Lp = x.raw.L > 2 ? x.raw.L : 3;
     p.ntiles = cdiv(x.raw.L, BM);
-    if (int rc = ensure_lds(h, reinterpret_cast<const void*>(rb_fused_kernel<C, BM, NSPLIT>), Cfg::lds_bytes)) return rc;
+    p.pad = pad;
+    if (int rc = ensure_lds(h, reinterpret_cast<const void*>(rb_fused_kernel<C, BM, NSPLIT, SC>), Cfg::lds_bytes)) return rc;
     const long long total = (long long)B * p.ntiles;
     const int grid = (int)std::min<long long>(total, 512);   // two workgroups per CU (VGPR-limited), persistent
     const size_t lds = Cfg::lds_bytes;
     const double L = x.raw.L;
-    ProfScope ps(h, st, C == 32 ? "rb_fused_kernel<32, 128, 1>" : "rb_fused_kernel<64, 64, 2>",
-                 2.0 * B * L * ((double)(C / 2) * 3 * C + (double)C * (C / 2 + C)),
-                 (double)B * L * C * 4.0 * (2 + (out.raw ? 1 : 0) + (out.elu ? 1 : 0)));
-    hipLaunchKernelGGL((rb_fused_kernel<C, BM, NSPLIT>), dim3(grid), dim3(256), lds, st, p);
+    ProfScope ps(h, st, !SC ? "rb_fused_kernel<64, 64, 2, false>" : C == 32 ? "rb_fused_kernel<32, 128, 1>" : "rb_fused_kernel<64, 64, 2>",
+                 2.0 * B * L * ((double)(C / 2) * 3 * C + (double)C * Cfg::KF),
+                 (double)B * L * C * 4.0 * ((x.elu.p ? 2 : 1) + (out.raw ? 1 : 0) + (out.elu ? 1 : 0)));
+    hipLaunchKernelGGL((rb_fused_kernel<C, BM, NSPLIT, SC>), dim3(grid), dim3(256), lds, st, p);
     return AC_OK;
 }
 
@@ -570,8 +600,8 @@ int resblock_fwd(ac_handle* h, hipStream_t st, const ResBlockPlan& rb, const Act
     if (rc) return rc;
     TapGemmParams p{};
     p.nseg = 2;
-    p.seg[0] = make_seg(hv.elu, 1, 1, true, 0, 0, nullptr);
-    p.seg[1] = make_seg(x.raw, 1, 1, true, 0, hv.elu.C, nullptr);
+    p.seg[0] = make_seg(hv.elu, 1, 1, PAD_REFLECT, 0, 0, nullptr);
+    p.seg[1] = make_seg(x.raw, 1, 1, PAD_REFLECT, 0, hv.elu.C, nullptr);
     p.w = h->blob + rb.fused.w_off;
     p.bias = h->blob + rb.fused.b_off;
     p.y = out.raw;
@@ -590,23 +620,23 @@ int resblock_fwd(ac_handle* h, hipStream_t st, const ResBlockPlan& rb, const Act
 // stem / head: dedicated HBM-bound kernels when the shape allows, tap-GEMM otherwise
 bool thin_ok(const ac_config& c, int k) { return c.num_filters % 4 == 0 && c.num_filters <= 64 && k <= THIN_MAXK; }
 
-int stem_fwd(ac_handle* h, hipStream_t st, const float* sig, const float* rel_len, int B, int T, Out out, Act2* y) {
-    const ac_config& c = h->cfg;
-    const int F = c.num_filters;
+int thin_stem(ac_handle* h, hipStream_t st, const PackedGemm& g, int F, int k, int pad, const float* sig, const float* rel_len, int B, int T,
+              Out out, Act2* y) {
     ThinParams p{};
     p.x = sig;
-    p.w = h->blob + h->enc_stem.w_off;
-    p.bias = h->blob + h->enc_stem.b_off;
+    p.w = h->blob + g.w_off;
+    p.bias = h->blob + g.b_off;
     p.rel_len = rel_len;
     p.y = out.raw;
     p.y_elu = out.elu;
     p.B = B;
     p.T = T;
     p.F = F;
-    p.k = c.kernel_size;
-    p.Lp = T > c.kernel_size - 1 ? T : c.kernel_size;
+    p.k = k;
+    p.Lp = T > k - 1 ? T : k;
+    p.pad = pad;
     {
-        ProfScope ps(h, st, "stem_kernel", 2.0 * B * (double)T * F * c.kernel_size,
+        ProfScope ps(h, st, "stem_kernel", 2.0 * B * (double)T * F * k,
                      (double)B * T * 4.0 * (1 + F * ((out.raw ? 1 : 0) + (out.elu ? 1 : 0))));
         hipLaunchKernelGGL(stem_kernel, dim3(cdiv(T, STEM_TT), B), dim3(256), 0, st, p);
     }
@@ -616,27 +646,34 @@ int stem_fwd(ac_handle* h, hipStream_t st, const float* sig, const float* rel_le
     return AC_OK;
 }
 
-int head_fwd(ac_handle* h, hipStream_t st, const Act& x, int B, float* sig) {
-    const ac_config& c = h->cfg;
-    const int F = c.num_filters;
+int stem_fwd(ac_handle* h, hipStream_t st, const float* sig, const float* rel_len, int B, int T, Out out, Act2* y) {
+    return thin_stem(h, st, h->enc_stem, h->cfg.num_filters, h->cfg.kernel_size, PAD_REFLECT, sig, rel_len, B, T, out, y);
+}
+
+int thin_head(ac_handle* h, hipStream_t st, const PackedGemm& g, int F, int k, int pad, const Act& x, int B, float* sig) {
     ThinParams p{};
     p.x = x.p;
-    p.w = h->blob + h->dec_head.w_off;
-    p.bias = h->blob + h->dec_head.b_off;
+    p.w = h->blob + g.w_off;
+    p.bias = h->blob + g.b_off;
     p.y = sig;
     p.B = B;
     p.T = x.L;
     p.F = F;
-    p.k = c.last_kernel_size;
-    p.Lp = x.L > c.last_kernel_size - 1 ? x.L : c.last_kernel_size;
+    p.k = k;
+    p.Lp = x.L > k - 1 ? x.L : k;
+    p.pad = pad;
     const size_t lds = ((size_t)(HEAD_TT + THIN_MAXK) * (F + 4) + (size_t)THIN_MAXK * F) * sizeof(float);
     if (int rc = ensure_lds(h, reinterpret_cast<const void*>(head_kernel), lds)) return rc;
     {
-        ProfScope ps(h, st, "head_kernel", 2.0 * B * (double)x.L * F * c.last_kernel_size, (double)B * x.L * 4.0 * (F + 1));
+        ProfScope ps(h, st, "head_kernel", 2.0 * B * (double)x.L * F * k, (double)B * x.L * 4.0 * (F + 1));
         hipLaunchKernelGGL(head_kernel, dim3(cdiv(x.L, HEAD_TT), B), dim3(256), lds, st, p);
     }
     HIPCHK(h, hipGetLastError());
     return AC_OK;
+}
+
+int head_fwd(ac_handle* h, hipStream_t st, const Act& x, int B, float* sig) {
+    return thin_head(h, st, h->dec_head, h->cfg.num_filters, h->cfg.last_kernel_size, PAD_REFLECT, x, B, sig);
 }
 
 void capture(ac_handle* h, hipStream_t st, const Act& a, int B) {
@@ -660,7 +697,7 @@ int lstm_fwd(ac_handle* h, hipStream_t st, const LstmPlan& lp, const Act& x, con
     {
         TapGemmParams p{};
         p.nseg = 1;
-        p.seg[0] = make_seg(x, 1, 1, false, 0, 0, nullptr);
+        p.seg[0] = make_seg(x, 1, 1, PAD_ZERO, 0, 0, nullptr);
         p.w = h->blob + lp.ih[0].w_off;
         p.bias = h->blob + lp.ih[0].b_off;
         p.y = ws.gin;
@@ -747,13 +784,16 @@ int rvq_encode_fwd(ac_handle* h, hipStream_t st, const float* feats, int F, int 
     p.H = h->cfg.hidden_size;
     p.C = h->cfg.codebook_size;
     p.K = K;
+    p.xs = p.H;
+    p.tK = K;
+    p.tk0 = 0;
     const int HV = p.H / 16;
     // frames per wave: 48 once there are enough frames to fill every SIMD (1024) with one wave
     const int MS = (HV <= 8 && F >= 1024 * 32) ? 3 : 1;
     const dim3 grid(cdiv(F, 16 * MS)), block(64);
     ProfScope ps(h, st, "rvq_encode_kernel", 2.0 * F * (double)p.C * p.H * K,
                  (double)F * p.H * 4 + (double)F * K * 8 + (double)K * p.C * p.H * 4);
-#define RVQ_CASE(HV_, MS_) hipLaunchKernelGGL((rvq_encode_kernel<HV_, MS_>), grid, block, 0, st, p)
+#define RVQ_CASE(HV_, MS_) hipLaunchKernelGGL((rvq_encode_kernel<HV_, MS_, false>), grid, block, 0, st, p)
     switch (HV * 10 + MS) {
         case 11: RVQ_CASE(1, 1); break;
         case 13: RVQ_CASE(1, 3); break;
@@ -780,6 +820,9 @@ int rvq_decode_fwd(ac_handle* h, hipStream_t st, const long long* toks, int F, i
     p.H = h->cfg.hidden_size;
     p.C = h->cfg.codebook_size;
     p.K = K;
+    p.tK = K;
+    p.tk0 = 0;
+    p.os = p.H;
     const long long n = (long long)F * (p.H / 4);
     ProfScope ps(h, st, "rvq_decode_kernel", (double)F * p.H * K, (double)F * K * 8 + (double)F * p.H * 4 * (K + 1));
     hipLaunchKernelGGL(rvq_decode_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p);
@@ -958,6 +1001,8 @@ int decoder_fwd(ac_handle* h, hipStream_t st, const long long* toks, int B, int 
     return rc;
 }
 
+#include "mimi_path.h"
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
@@ -965,7 +1010,7 @@ int decoder_fwd(ac_handle* h, hipStream_t st, const long long* toks, int B, int 
 // ---------------------------------------------------------------------------------------------
 extern "C" {
 
-int ac_version(void) { return 100; }
+int ac_version(void) { return 200; }
 
 int ac_create(const ac_config* cfg, ac_handle** out) {
     if (!cfg || !out) return AC_EINVAL;
@@ -988,6 +1033,34 @@ int ac_create(const ac_config* cfg, ac_handle** out) {
     return AC_OK;
 }
 
+int ac_mimi_create(const ac_mimi_config* cfg, ac_handle** out) {
+    if (!cfg || !out) return AC_EINVAL;
+    *out = nullptr;
+    if (cfg->struct_size != (int32_t)sizeof(ac_mimi_config)) return AC_EINVAL;
+    const ac_mimi_config& c = *cfg;
+    if (c.num_ratios < 1 || c.num_ratios > AC_MAX_RATIOS || c.num_filters < 1 || c.hidden_size < 16 || c.hidden_size % 16 ||
+        c.hidden_size > 64 * LN_MAXV || c.compress < 1 || c.codebook_size % 32 || c.codebook_size < 32 || c.codebook_dim < 16 ||
+        c.codebook_dim % 16 || c.codebook_dim > 256 || c.num_quantizers < 1 || c.num_semantic_quantizers < 1 ||
+        c.num_semantic_quantizers > c.num_quantizers || c.kernel_size < 1 || c.kernel_size > 8 || c.last_kernel_size < 1 ||
+        c.last_kernel_size > 8 || c.residual_kernel_size < 1 || c.residual_kernel_size > 8 || c.num_hidden_layers < 0 ||
+        c.num_attention_heads < 1 || (c.head_dim != 16 && c.head_dim != 32 && c.head_dim != 64) || c.intermediate_size < 16 ||
+        c.intermediate_size % 4 || c.sliding_window < 1 || c.resample_stride < 1 || c.resample_stride > 4 || !(c.norm_eps > 0.f) ||
+        !(c.rope_theta > 0.f))
+        return AC_EINVAL;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= c.device || c.device < 0) return AC_ENODEV;
+    ac_handle* h = new (std::nothrow) ac_handle();
+    if (!h) return AC_ENOMEM;
+    h->arch = ARCH_MIMI;
+    h->mcfg = c;
+    h->hop = c.resample_stride;
+    for (int i = 0; i < c.num_ratios; ++i) h->hop *= c.upsampling_ratios[i];
+    h->D = c.num_filters << c.num_ratios;
+    h->mimi.D = h->D;
+    *out = h;
+    return AC_OK;
+}
+
 int ac_load_weights(ac_handle* h, const char* name, const void* host_ptr, size_t bytes) {
     if (!h || !name || !host_ptr) return h ? fail(h, AC_EINVAL, "null argument") : AC_EINVAL;
     if (h->finalized) return fail(h, AC_ESTATE, "handle already finalized");
@@ -997,9 +1070,28 @@ int ac_load_weights(ac_handle* h, const char* name, const void* host_ptr, size_t
     return AC_OK;
 }
 
+static int upload_blob(ac_handle* h, Packer& pk, int device) {
+    HIPCHK(h, hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCHK(h, hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(h, AC_ENODEV, "device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
+    h->blob_floats = pk.blob.size();
+    HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&h->blob), h->blob_floats * sizeof(float)));
+    HIPCHK(h, hipMemcpy(h->blob, pk.blob.data(), h->blob_floats * sizeof(float), hipMemcpyHostToDevice));
+    h->host.clear();
+    h->finalized = true;
+    return AC_OK;
+}
+
 int ac_finalize(ac_handle* h) {
     if (!h) return AC_EINVAL;
     if (h->finalized) return fail(h, AC_ESTATE, "handle already finalized");
+    if (h->arch == ARCH_MIMI) {
+        Packer pk{h};
+        if (int rc = mimi_finalize(h, pk)) return rc;
+        return upload_blob(h, pk, h->mcfg.device);
+    }
     const ac_config& c = h->cfg;
     Arch a = make_arch(c);
     Packer pk{h};
@@ -1044,35 +1136,37 @@ int ac_finalize(ac_handle* h) {
                         pk.blob[h->cb_packed + (size_t)q * C * H + (((size_t)ct * HV + v) * 64 + lane) * 4 + u] =
                             (*e)[(size_t)(ct * 16 + (lane & 15)) * H + v * 16 + 4 * (lane >> 4) + u];
     }
-    HIPCHK(h, hipSetDevice(c.device));
-    hipDeviceProp_t prop;
-    HIPCHK(h, hipGetDeviceProperties(&prop, c.device));
-    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
-        return fail(h, AC_ENODEV, "device %d is %s; this library is built for gfx950 only", c.device, prop.gcnArchName);
-    h->blob_floats = pk.blob.size();
-    HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&h->blob), h->blob_floats * sizeof(float)));
-    HIPCHK(h, hipMemcpy(h->blob, pk.blob.data(), h->blob_floats * sizeof(float), hipMemcpyHostToDevice));
-    h->host.clear();
-    h->finalized = true;
-    return AC_OK;
+    return upload_blob(h, pk, c.device);
 }
 
 int ac_num_frames(const ac_handle* h, int T) {
     if (!h || T < 1) return AC_EINVAL;
+    if (h->arch == ARCH_MIMI) return cdiv(mimi_num_frames25(h->mcfg, T), h->mcfg.resample_stride);
     long long L = T;
     for (int r = h->cfg.num_ratios - 1; r >= 0; --r) L = (L + h->cfg.upsampling_ratios[r] - 1) / h->cfg.upsampling_ratios[r];
     return (int)L;
 }
 int ac_hop_length(const ac_handle* h) { return h ? h->hop : AC_EINVAL; }
-int ac_hidden_size(const ac_handle* h) { return h ? h->cfg.hidden_size : AC_EINVAL; }
+int ac_hidden_size(const ac_handle* h) { return h ? (h->arch == ARCH_MIMI ? h->mcfg.hidden_size : h->cfg.hidden_size) : AC_EINVAL; }
+int ac_codebook_dim(const ac_handle* h) { return h ? (h->arch == ARCH_MIMI ? h->mcfg.codebook_dim : h->cfg.hidden_size) : AC_EINVAL; }
+
+static int num_q(const ac_handle* h) { return h->arch == ARCH_MIMI ? h->mcfg.num_quantizers : h->cfg.num_quantizers; }
+
+static Workspace any_plan_ws(const ac_handle* h, int B, int T, int N, bool enc) {
+    return h->arch == ARCH_MIMI ? mimi_plan_ws(h, B, T, N, enc) : plan_ws(h, B, T, N, enc);
+}
 
 size_t ac_encode_workspace_bytes(const ac_handle* h, int B, int T) {
     if (!h || B < 1 || T < 1) return 0;
-    return plan_ws(h, B, T, 0, true).total_bytes;
+    return any_plan_ws(h, B, T, 0, true).total_bytes;
 }
 size_t ac_decode_workspace_bytes(const ac_handle* h, int B, int N) {
     if (!h || B < 1 || N < 1) return 0;
-    return plan_ws(h, B, 0, N, false).total_bytes;
+    return any_plan_ws(h, B, 0, N, false).total_bytes;
+}
+size_t ac_quantizer_workspace_bytes(const ac_handle* h, int B, int N) {
+    if (!h || B < 1 || N < 1 || h->arch != ARCH_MIMI) return 0;
+    return (size_t)B * N * 2 * h->mcfg.codebook_dim * sizeof(float) + 256;
 }
 
 int ac_encode_feats(ac_handle* h, const float* sig, const float* rel_len, int B, int T, float* feats, void* ws, size_t ws_bytes, void* stream) {
@@ -1080,8 +1174,9 @@ int ac_encode_feats(ac_handle* h, const float* sig, const float* rel_len, int B,
     if (rc) return rc;
     if (!sig || !feats || B < 1 || T < 1) return fail(h, AC_EINVAL, "ac_encode_feats: bad argument (B=%d, T=%d)", B, T);
     WsPtrs p;
-    rc = carve(h, plan_ws(h, B, T, 0, true), ws, ws_bytes, &p);
+    rc = carve(h, any_plan_ws(h, B, T, 0, true), ws, ws_bytes, &p);
     if (rc) return rc;
+    if (h->arch == ARCH_MIMI) return mimi_encoder_fwd(h, (hipStream_t)stream, sig, B, T, feats, p);   // no sample mask in Mimi ([HF] mimi :1245-1247)
     return encoder_fwd(h, (hipStream_t)stream, sig, rel_len, B, T, feats, p);
 }
 
@@ -1089,12 +1184,23 @@ int ac_encode(ac_handle* h, const float* sig, const float* rel_len, int B, int T
     int rc = check_ready(h);
     if (rc) return rc;
     if (!sig || !toks || B < 1 || T < 1) return fail(h, AC_EINVAL, "ac_encode: bad argument (B=%d, T=%d)", B, T);
-    if (K < 1 || K > h->cfg.num_quantizers) return fail(h, AC_EINVAL, "ac_encode: K=%d outside [1, %d]", K, h->cfg.num_quantizers);
+    if (K < 1 || K > num_q(h)) return fail(h, AC_EINVAL, "ac_encode: K=%d outside [1, %d]", K, num_q(h));
     WsPtrs p;
-    rc = carve(h, plan_ws(h, B, T, 0, true), ws, ws_bytes, &p);
+    rc = carve(h, any_plan_ws(h, B, T, 0, true), ws, ws_bytes, &p);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     const int N = ac_num_frames(h, T);
+    if (h->arch == ARCH_MIMI) {
+        const ac_mimi_config& c = h->mcfg;
+        float* feats = p.act[NACT - 1];   // the encoder never has more than 5 buffers live
+        p.used[NACT - 1] = true;
+        rc = mimi_encoder_fwd(h, st, sig, B, T, feats, p);
+        if (rc) return rc;
+        float* proj = p.take();
+        rc = mimi_linear(h, st, h->mimi.in_proj, feats, (long long)B * N, c.hidden_size, c.hidden_size, 0, proj, 2 * c.codebook_dim);
+        if (rc) return rc;
+        return mimi_rvq_encode(h, st, proj, B * N, K, reinterpret_cast<long long*>(toks));
+    }
     // feats land in the activation buffer the encoder's last conv does not read from
     float* feats = p.lstm.gin;  // free again once the LSTM is done
     rc = encoder_fwd(h, st, sig, rel_len, B, T, feats, p);
@@ -1102,37 +1208,88 @@ int ac_encode(ac_handle* h, const float* sig, const float* rel_len, int B, int T
     return rvq_encode_fwd(h, st, feats, B * N, K, reinterpret_cast<long long*>(toks));
 }
 
-int ac_quantize(ac_handle* h, const float* feats, int B, int N, int K, int64_t* toks, void* stream) {
+int ac_quantize_ws(ac_handle* h, const float* feats, int B, int N, int K, int64_t* toks, void* ws, size_t ws_bytes, void* stream) {
     int rc = check_ready(h);
     if (rc) return rc;
-    if (!feats || !toks || B < 1 || N < 1 || K < 1 || K > h->cfg.num_quantizers) return fail(h, AC_EINVAL, "ac_quantize: bad argument");
+    if (!feats || !toks || B < 1 || N < 1 || K < 1 || K > num_q(h)) return fail(h, AC_EINVAL, "ac_quantize: bad argument");
+    if (h->arch == ARCH_MIMI) {
+        const ac_mimi_config& c = h->mcfg;
+        if (!ws || ws_bytes < ac_quantizer_workspace_bytes(h, B, N)) return fail(h, AC_ENOMEM, "ac_quantize: workspace missing or too small");
+        float* proj = reinterpret_cast<float*>(align_up(reinterpret_cast<uintptr_t>(ws), 256));
+        rc = mimi_linear(h, (hipStream_t)stream, h->mimi.in_proj, feats, (long long)B * N, c.hidden_size, c.hidden_size, 0, proj, 2 * c.codebook_dim);
+        if (rc) return rc;
+        return mimi_rvq_encode(h, (hipStream_t)stream, proj, B * N, K, reinterpret_cast<long long*>(toks));
+    }
     return rvq_encode_fwd(h, (hipStream_t)stream, feats, B * N, K, reinterpret_cast<long long*>(toks));
 }
 
-int ac_dequantize(ac_handle* h, const int64_t* toks, int B, int N, int K, float* qfeats, void* stream) {
+int ac_quantize(ac_handle* h, const float* feats, int B, int N, int K, int64_t* toks, void* stream) {
+    if (h && h->arch == ARCH_MIMI) return fail(h, AC_EINVAL, "ac_quantize: Mimi handles need scratch, call ac_quantize_ws");
+    return ac_quantize_ws(h, feats, B, N, K, toks, nullptr, 0, stream);
+}
+
+int ac_dequantize_ws(ac_handle* h, const int64_t* toks, int B, int N, int K, float* qfeats, void* ws, size_t ws_bytes, void* stream) {
     int rc = check_ready(h);
     if (rc) return rc;
-    if (!qfeats || !toks || B < 1 || N < 1 || K < 1 || K > h->cfg.num_quantizers) return fail(h, AC_EINVAL, "ac_dequantize: bad argument");
+    if (!qfeats || !toks || B < 1 || N < 1 || K < 1 || K > num_q(h)) return fail(h, AC_EINVAL, "ac_dequantize: bad argument");
+    if (h->arch == ARCH_MIMI) {
+        if (!ws || ws_bytes < ac_quantizer_workspace_bytes(h, B, N)) return fail(h, AC_ENOMEM, "ac_dequantize: workspace missing or too small");
+        float* qsum = reinterpret_cast<float*>(align_up(reinterpret_cast<uintptr_t>(ws), 256));
+        return mimi_rvq_decode(h, (hipStream_t)stream, reinterpret_cast<const long long*>(toks), B * N, K, qsum, qfeats);
+    }
     return rvq_decode_fwd(h, (hipStream_t)stream, reinterpret_cast<const long long*>(toks), B * N, K, qfeats);
+}
+
+int ac_dequantize(ac_handle* h, const int64_t* toks, int B, int N, int K, float* qfeats, void* stream) {
+    if (h && h->arch == ARCH_MIMI) return fail(h, AC_EINVAL, "ac_dequantize: Mimi handles need scratch, call ac_dequantize_ws");
+    return ac_dequantize_ws(h, toks, B, N, K, qfeats, nullptr, 0, stream);
 }
 
 int ac_decode(ac_handle* h, const int64_t* toks, int B, int N, int K, float* sig, void* ws, size_t ws_bytes, void* stream) {
     int rc = check_ready(h);
     if (rc) return rc;
     if (!sig || !toks || B < 1 || N < 1) return fail(h, AC_EINVAL, "ac_decode: bad argument (B=%d, N=%d)", B, N);
-    if (K < 1 || K > h->cfg.num_quantizers) return fail(h, AC_EINVAL, "ac_decode: K=%d outside [1, %d]", K, h->cfg.num_quantizers);
+    if (K < 1 || K > num_q(h)) return fail(h, AC_EINVAL, "ac_decode: K=%d outside [1, %d]", K, num_q(h));
     WsPtrs p;
-    rc = carve(h, plan_ws(h, B, 0, N, false), ws, ws_bytes, &p);
+    rc = carve(h, any_plan_ws(h, B, 0, N, false), ws, ws_bytes, &p);
     if (rc) return rc;
+    if (h->arch == ARCH_MIMI) {
+        hipStream_t st = (hipStream_t)stream;
+        float* qsum = p.take();
+        float* qf = p.take();
+        rc = mimi_rvq_decode(h, st, reinterpret_cast<const long long*>(toks), B * N, K, qsum, qf);
+        if (rc) return rc;
+        p.give(qsum);
+        capture(h, st, Act{qf, (long long)N * h->mcfg.hidden_size, h->mcfg.hidden_size, N, h->mcfg.hidden_size}, B);
+        // qf stays taken while the up-sampler reads it; the decoder needs at most 5 more buffers
+        return mimi_decoder_fwd(h, st, qf, B, N, sig, p);
+    }
     return decoder_fwd(h, (hipStream_t)stream, reinterpret_cast<const long long*>(toks), B, N, K, sig, p);
 }
 
 int ac_embs(ac_handle* h, int K, float* embs, void* stream) {
     int rc = check_ready(h);
     if (rc) return rc;
-    if (!embs || K < 1 || K > h->cfg.num_quantizers) return fail(h, AC_EINVAL, "ac_embs: bad argument");
-    const size_t n = (size_t)K * h->cfg.codebook_size * h->cfg.hidden_size * sizeof(float);
-    HIPCHK(h, hipMemcpyAsync(embs, h->blob + h->cb_plain, n, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    if (!embs || K < 1 || K > num_q(h)) return fail(h, AC_EINVAL, "ac_embs: bad argument");
+    const bool mimi = h->arch == ARCH_MIMI;
+    const size_t n = mimi ? (size_t)K * h->mcfg.codebook_size * h->mcfg.codebook_dim : (size_t)K * h->cfg.codebook_size * h->cfg.hidden_size;
+    HIPCHK(h, hipMemcpyAsync(embs, h->blob + (mimi ? h->mimi.cb_plain : h->cb_plain), n * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return AC_OK;
+}
+
+int ac_embs_projected(ac_handle* h, int K, float* embs, void* stream) {
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (h->arch != ARCH_MIMI) return fail(h, AC_EINVAL, "ac_embs_projected: only Mimi has an output projection");
+    const ac_mimi_config& c = h->mcfg;
+    if (!embs || K < 1 || K > c.num_quantizers) return fail(h, AC_EINVAL, "ac_embs_projected: bad argument");
+    for (int q = 0; q < K; ++q) {
+        const int part = q < c.num_semantic_quantizers ? 0 : 1;
+        rc = mimi_linear(h, (hipStream_t)stream, h->mimi.out_proj, h->blob + h->mimi.cb_plain + (size_t)q * c.codebook_size * c.codebook_dim,
+                         c.codebook_size, c.codebook_dim, c.codebook_dim, part * c.codebook_dim,
+                         embs + (size_t)q * c.codebook_size * c.hidden_size, c.hidden_size);
+        if (rc) return rc;
+    }
     return AC_OK;
 }
 

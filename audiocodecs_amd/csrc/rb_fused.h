@@ -28,12 +28,15 @@ struct RbFusedParams {
     float* y_elu;       // optional ELU'd output
     int B, L, Lp;       // Lp: reflect base length (L, or 3 when L <= 2: [HF]:148-155)
     int ntiles;         // tiles per clip
+    int pad;            // PAD_REFLECT (EnCodec) / PAD_ZERO (Mimi)
 };
 
-template <int C, int BM, int NSPLIT>
+// SC: the shortcut is a 1x1 conv fused as extra K columns (EnCodec); !SC: identity shortcut (Mimi,
+// [HF] mimi :421-424), added from the raw slab after the MFMA phase.
+template <int C, int BM, int NSPLIT, bool SC = true>
 struct RbCfg {
     static constexpr int HC = C / 2, CP = C + 4, HP = HC + 4;
-    static constexpr int K3 = 3 * C, KF = HC + C;
+    static constexpr int K3 = 3 * C, KF = SC ? HC + C : HC;
     static constexpr int XE_ROWS = BM + 2;
     static constexpr int XE_FLOATS = XE_ROWS * CP, XR_FLOATS = BM * CP, H_FLOATS = BM * HP;
     static constexpr int XE_SLOTS = (XE_ROWS * (C / 4) + 255) / 256, XR_SLOTS = (BM * (C / 4) + 255) / 256;
@@ -43,9 +46,9 @@ struct RbCfg {
     static constexpr size_t lds_bytes = (size_t)(XE_FLOATS + XR_FLOATS + H_FLOATS) * 4;
 };
 
-template <int C, int BM, int NSPLIT>
+template <int C, int BM, int NSPLIT, bool SC = true>
 __global__ __launch_bounds__(256) void rb_fused_kernel(const RbFusedParams p) {
-    using Cfg = RbCfg<C, BM, NSPLIT>;
+    using Cfg = RbCfg<C, BM, NSPLIT, SC>;
     constexpr int HC = Cfg::HC, CP = Cfg::CP, HP = Cfg::HP, K3 = Cfg::K3, KF = Cfg::KF;
     constexpr int MS = Cfg::MS, NA = Cfg::NA, NB = Cfg::NB;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -92,8 +95,8 @@ __global__ __launch_bounds__(256) void rb_fused_kernel(const RbFusedParams p) {
             const int row = e / (C / 4), q = e % (C / 4);
             re[i] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (row < Cfg::XE_ROWS) {
-                int j = t0 - 2 + row;                            // causal reflect pad of 2 ([HF]:157-176)
-                j = j < 0 ? -j : (j >= p.Lp ? 2 * (p.Lp - 1) - j : j);
+                int j = t0 - 2 + row;                            // causal pad of 2: reflect ([HF]:157-176) or zeros
+                if (p.pad == PAD_REFLECT) j = j < 0 ? -j : (j >= p.Lp ? 2 * (p.Lp - 1) - j : j);
                 if (j >= 0 && j < p.L) re[i] = *reinterpret_cast<const f32x4*>(xe + (long long)j * C + 4 * q);
             }
         }
@@ -185,7 +188,10 @@ __global__ __launch_bounds__(256) void rb_fused_kernel(const RbFusedParams p) {
 #pragma unroll
             for (int c = 0; c < NB; ++c)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) Xr[(r0 + a * 16 + kq * 4 + r) * CP + nb0 + c * 16 + li] = acc[a][c][r];
+                for (int r = 0; r < 4; ++r) {
+                    float* o = &Xr[(r0 + a * 16 + kq * 4 + r) * CP + nb0 + c * 16 + li];
+                    *o = SC ? acc[a][c][r] : __fadd_rn(*o, acc[a][c][r]);   // identity shortcut: x + block(x), element owned by this lane
+                }
         __syncthreads();
         {
             const int b = tile / p.ntiles, t0 = (tile % p.ntiles) * BM;

@@ -20,11 +20,16 @@ struct RvqEncParams {
     const float* epk;    // packed codebooks: [K][C/16 code tiles][H/16 ksteps][64 lanes][4]
     const float* e;      // plain codebooks [K][C][H] (for the residual update)
     const float* ee;     // [K][C] squared norms of the code vectors
-    long long* toks;     // [F][K]
+    long long* toks;     // [F][tK]: stage k of this launch writes column tk0 + k
     int F, H, C, K;
+    int xs;              // row pitch of x (floats)
+    int tK, tk0;
 };
 
-template <int HV, int MS>  // HV = H/16: 16-byte vectors of a residual row per lane; MS: 16-frame sub-tiles per wave
+// CDIST = false: EnCodec's expanded form above.  CDIST = true: Mimi, [HF] mimi :985-990
+//     idx = argmin(cdist(x, E, p=2))  with cdist's matmul form  sqrt(clamp_min(|x|^2 - 2 x.E^T + |E|^2, 1e-30)):
+// the square root is kept because it merges near-equal squared distances into exact ties (first index wins).
+template <int HV, int MS, bool CDIST>  // HV = H/16: 16-byte vectors of a residual row per lane; MS: 16-frame sub-tiles per wave
 __global__ __launch_bounds__(64) void rvq_encode_kernel(const RvqEncParams p) {
     const int lane = threadIdx.x & 63;
     const int li = lane & 15, kq = lane >> 4;
@@ -39,7 +44,7 @@ __global__ __launch_bounds__(64) void rvq_encode_kernel(const RvqEncParams p) {
         const int frow = f0 + m * 16 + li;                 // the frame whose A-fragment this lane holds
 #pragma unroll
         for (int v = 0; v < HV; ++v)
-            res[m][v] = frow < p.F ? *reinterpret_cast<const f32x4*>(p.x + (long long)frow * H + v * 16 + 4 * kq)
+            res[m][v] = frow < p.F ? *reinterpret_cast<const f32x4*>(p.x + (long long)frow * p.xs + v * 16 + 4 * kq)
                                    : f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
@@ -93,7 +98,8 @@ __global__ __launch_bounds__(64) void rvq_encode_kernel(const RvqEncParams p) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     // dist = -((xx - 2*dot) + ee), evaluated in the reference's order
-                    const float d = -((xxr[m][r] - 2.0f * acc[m][r]) + eev);
+                    float d = (xxr[m][r] - 2.0f * acc[m][r]) + eev;
+                    d = CDIST ? -sqrtf(fmaxf(d, 1e-30f)) : -d;
                     if (d > best[m][r]) { best[m][r] = d; bidx[m][r] = code; }
                 }
         };
@@ -123,7 +129,7 @@ __global__ __launch_bounds__(64) void rvq_encode_kernel(const RvqEncParams p) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int f = f0 + m * 16 + kq * 4 + r;
-                    if (f < p.F) p.toks[(long long)f * p.K + k] = (long long)bidx[m][r];
+                    if (f < p.F) p.toks[(long long)f * p.tK + p.tk0 + k] = (long long)bidx[m][r];
                 }
             }
             // residual update: this lane needs the index of frame li = row (li>>2)*4 + (li&3)
@@ -146,10 +152,12 @@ __global__ __launch_bounds__(64) void rvq_encode_kernel(const RvqEncParams p) {
 }
 
 struct RvqDecParams {
-    const long long* toks;  // [F][K]
-    const float* e;         // [Kall][C][H]
+    const long long* toks;  // [F][tK]: stage k reads column tk0 + k
+    const float* e;         // [K][C][H] codebooks of the stages summed here
     float* out;             // [F][H]
     int F, H, C, K;
+    int tK, tk0;
+    int os;                 // row pitch of out (floats)
 };
 
 __global__ __launch_bounds__(256) void rvq_decode_kernel(const RvqDecParams p) {
@@ -160,12 +168,12 @@ __global__ __launch_bounds__(256) void rvq_decode_kernel(const RvqDecParams p) {
     const int q = (int)(gid % hv);
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int k = 0; k < p.K; ++k) {
-        long long idx = p.toks[f * p.K + k];
+        long long idx = p.toks[f * p.tK + p.tk0 + k];
         idx = idx < 0 ? 0 : (idx >= p.C ? p.C - 1 : idx);   // F.embedding would raise; stay in bounds
         const f32x4 v = *reinterpret_cast<const f32x4*>(p.e + ((long long)k * p.C + idx) * p.H + 4 * q);
         acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
     }
-    *reinterpret_cast<f32x4*>(p.out + f * p.H + 4 * q) = acc;
+    *reinterpret_cast<f32x4*>(p.out + f * p.os + 4 * q) = acc;
 }
 
 }  // namespace ac

@@ -43,7 +43,7 @@ struct TapSeg {
     int J;              // taps = reshaped rows per output row
     int Lp;             // reflect period base: L if L > max_pad else max_pad+1 ([HF]:148-155)
     int lim;            // valid padded range is [-(J-1)*s, lim): lim = L + extra_padding
-    int reflect;        // 1 reflect, 0 zero
+    int reflect;        // padding rule for indices outside [0, L): 0 zero, 1 reflect, 2 replicate (PAD_*)
     int elu;            // 1: ELU(alpha=1) on load
     int kofs;           // offset of this segment inside a packed weight row
 };
@@ -60,7 +60,26 @@ struct TapGemmParams {
     long long y_bs, y_rs;
     int B, M, N, Ktot;
     int mtiles, ntiles;
+    // optional epilogue terms (Mimi): v = acc + bias; gelu -> v = GELU(v) (exact erf form); scale -> v *= scale[n]
+    // (LayerScale); res -> v = res[b][m][n] + v (identity shortcut / residual stream; may alias y)
+    const float* scale;
+    const float* res;
+    long long res_bs, res_rs;
+    int gelu;
 };
+
+enum { PAD_ZERO = 0, PAD_REFLECT = 1, PAD_REPLICATE = 2 };
+
+// GELU as torch.nn.functional.gelu(approximate="none") evaluates it: 0.5 * x * (1 + erf(x / sqrt(2))).
+__device__ __forceinline__ float gelu1(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
+
+// bias-added accumulator -> layer output, in the reference's operation order: scale * x, then residual + (.)
+__device__ __forceinline__ float epilogue1(const TapGemmParams& p, float v, int n, long long res_off) {
+    if (p.gelu) v = gelu1(v);
+    if (p.scale) v = __fmul_rn(p.scale[n], v);
+    if (p.res) v = __fadd_rn(p.res[res_off], v);
+    return v;
+}
 
 // ELU(alpha=1) as torch evaluates it on CPU: x > 0 ? x : exp(x) - 1 (not expm1).  exp goes through the
 // hardware v_exp_f32 (2^x, ~1 ulp) after one multiply by log2(e): absolute error of the result
@@ -80,13 +99,13 @@ constexpr int KCP = KC + 4;   // LDS pitch (floats): keeps 16-B alignment, sprea
 __device__ __forceinline__ long long src_index(const TapSeg& sg, int i) {
     if (i >= sg.lim) return -1;
     int j = i;
-    if (j < 0) {
-        if (!sg.reflect) return -1;
-        j = -j;
-    } else if (j >= sg.Lp) {
-        j = 2 * (sg.Lp - 1) - j;
+    if (sg.reflect == PAD_REFLECT) {
+        if (j < 0) j = -j;
+        else if (j >= sg.Lp) j = 2 * (sg.Lp - 1) - j;
+    } else if (sg.reflect == PAD_REPLICATE) {     // [HF] mimi :1199-1208 down-sampler: F.pad(mode="replicate")
+        j = j < 0 ? 0 : (j >= sg.L ? sg.L - 1 : j);
     }
-    if (j < 0 || j >= sg.L) return -1;   // zero-extension of the small-input rule / guard
+    if (j < 0 || j >= sg.L) return -1;   // zero padding / zero-extension of the small-input rule / guard
     return j;
 }
 
@@ -213,7 +232,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void tap_gemm_kernel(const TapGemmPa
                 for (int r = 0; r < 4; ++r) {
                     const int m = m0 + (wm * WM + a) * 16 + kq * 4 + r;
                     if (m < p.M) {
-                        const float v = acc[a][c][r] + bv;
+                        const float v = epilogue1(p, acc[a][c][r] + bv, n, (long long)b * p.res_bs + (long long)m * p.res_rs + n);
                         if (p.y) p.y[yoff + (long long)m * p.y_rs + n] = v;
                         if (p.y_elu) p.y_elu[yoff + (long long)m * p.y_rs + n] = elu1(v);
                     }

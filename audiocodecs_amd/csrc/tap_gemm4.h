@@ -267,11 +267,23 @@ __global__ __launch_bounds__(WGM* WGN * 64) void tap_gemm4_kernel(const TapGemmP
         }
     __syncthreads();
     const long long yoff = (long long)b * p.y_bs;
+    const bool post = p.gelu || p.scale || p.res;
     for (int e = tid; e < BM * (BN / 4); e += NT) {
         const int row = e / (BN / 4), q = e % (BN / 4);
         const int m = m0 + row, n = n0 + 4 * q;
         if (m < p.M && n < p.N) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(&Cs[row * CP + 4 * q]);
+            f32x4 v = *reinterpret_cast<const f32x4*>(&Cs[row * CP + 4 * q]);
+            if (post) {
+                if (p.gelu) { v.x = gelu1(v.x); v.y = gelu1(v.y); v.z = gelu1(v.z); v.w = gelu1(v.w); }
+                if (p.scale) {
+                    const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + n);
+                    v.x = __fmul_rn(sc.x, v.x); v.y = __fmul_rn(sc.y, v.y); v.z = __fmul_rn(sc.z, v.z); v.w = __fmul_rn(sc.w, v.w);
+                }
+                if (p.res) {
+                    const f32x4 rv = *reinterpret_cast<const f32x4*>(p.res + (long long)b * p.res_bs + (long long)m * p.res_rs + n);
+                    v.x = __fadd_rn(rv.x, v.x); v.y = __fadd_rn(rv.y, v.y); v.z = __fadd_rn(rv.z, v.z); v.w = __fadd_rn(rv.w, v.w);
+                }
+            }
             const long long o = yoff + (long long)m * p.y_rs + n;
             if (p.y) *reinterpret_cast<f32x4*>(p.y + o) = v;
             if (p.y_elu) *reinterpret_cast<f32x4*>(p.y_elu + o) = elu4(v);

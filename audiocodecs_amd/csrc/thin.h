@@ -2,8 +2,8 @@
 // be almost empty:
 //   stem_kernel : [HF] EncodecEncoder.layers[0]  Conv1d(1, F, k)  sig[B][T] -> x[B][T][F] (raw and ELU'd)
 //   head_kernel : [HF] EncodecDecoder.layers[-1] Conv1d(F, 1, k)  ELU'd y[B][T][F] -> sig[B][T]
-// Both are causal with reflect padding ([HF] modeling_encodec.py:157-176, small-input rule :148-155),
-// the stem also applies the length mask (audiocodecs/encodec.py:84-92, [HF]:589-590).
+// Both are causal with reflect padding ([HF] modeling_encodec.py:157-176, small-input rule :148-155) or, for
+// Mimi's SEANet, zero padding; the stem also applies the length mask (audiocodecs/encodec.py:84-92, [HF]:589-590).
 // Algorithmic bytes: stem 4*T*(1 + F*flavours), head 4*T*(F + 1) per clip; plain fp32 FMAs (the
 // arithmetic is ~1 flop/B).  Accumulation order: bias first, then taps (and channels) ascending.
 #pragma once
@@ -21,10 +21,12 @@ struct ThinParams {
     float* y_elu;          // stem: ELU'd [B][T][F] (may be null)
     int B, T, F, k;
     int Lp;                // reflect base length: T if T > k-1 else k ([HF]:148-155)
+    int pad;               // PAD_REFLECT (EnCodec) or PAD_ZERO (Mimi: pad_mode "constant", [HF] mimi :336-338)
 };
 
-__device__ __forceinline__ int reflect_src(int i, int T, int Lp) {
-    int j = i < 0 ? -i : (i >= Lp ? 2 * (Lp - 1) - i : i);
+__device__ __forceinline__ int reflect_src(int i, int T, int Lp, int pad) {
+    int j = i;
+    if (pad == PAD_REFLECT) j = i < 0 ? -i : (i >= Lp ? 2 * (Lp - 1) - i : i);
     return (j >= 0 && j < T) ? j : -1;
 }
 
@@ -40,7 +42,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const ThinParams p) {
     if (p.rel_len) alen = (float)p.T * p.rel_len[b];
     const int pad = p.k - 1;
     for (int e = tid; e < STEM_TT + pad; e += 256) {
-        const int j = reflect_src(t0 - pad + e, p.T, p.Lp);
+        const int j = reflect_src(t0 - pad + e, p.T, p.Lp, p.pad);
         xs[e] = (j >= 0 && (float)j < alen) ? xb[j] : 0.f;
     }
     const int cq = p.F / 4;                 // float4 groups per time step
@@ -86,7 +88,7 @@ __global__ __launch_bounds__(256) void head_kernel(const ThinParams p) {
     const float* xb = p.x + (long long)b * p.T * F;
     for (int e = tid; e < (HEAD_TT + pad) * fq; e += 256) {
         const int row = e / fq, q = e % fq;
-        const int j = reflect_src(t0 - pad + row, p.T, p.Lp);
+        const int j = reflect_src(t0 - pad + row, p.T, p.Lp, p.pad);
         f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
         if (j >= 0) v = *reinterpret_cast<const f32x4*>(xb + (long long)j * F + 4 * q);
         *reinterpret_cast<f32x4*>(&xs[row * FP + 4 * q]) = v;

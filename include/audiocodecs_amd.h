@@ -64,11 +64,49 @@ typedef struct ac_config {
     int32_t device;                    /* HIP device ordinal                                   */
 } ac_config;
 
+/* Mimi: the fields of transformers.MimiConfig the path depends on; defaults = kyutai/mimi,
+ * what audiocodecs/mimi.py:45 loads.  Replaces, behind Mimi._sig_to_toks/_toks_to_sig/_sig_to_feats/
+ * _toks_to_qfeats/embs (mimi.py:52-156):
+ *     mimi.py:105-108  self.model.encode(sig[:, None], padding_mask[:, None], num_quantizers=K)
+ *     mimi.py:146-147  self.model.decode(toks.movedim(-1, -2))
+ *     mimi.py:115-119  encoder -> encoder_transformer -> downsample
+ *     mimi.py:139,153  self.model.quantizer.decode(...)
+ * Causal convs with zero ("constant") padding, identity ResBlock shortcuts, no weight-norm, multi-head
+ * attention with num_key_value_heads == num_attention_heads, "default" RoPE, exact-erf GELU, LayerScale. */
+typedef struct ac_mimi_config {
+    int32_t struct_size;               /* = sizeof(ac_mimi_config)                              */
+    int32_t sampling_rate;             /* 24000                                                 */
+    int32_t num_filters;               /* 64                                                    */
+    int32_t hidden_size;               /* 512 (transformer / latent width)                      */
+    int32_t num_ratios;                /* 4                                                     */
+    int32_t upsampling_ratios[AC_MAX_RATIOS]; /* 8,6,5,4 (decoder order)                        */
+    int32_t kernel_size;               /* 7                                                     */
+    int32_t last_kernel_size;          /* 3                                                     */
+    int32_t residual_kernel_size;      /* 3                                                     */
+    int32_t compress;                  /* 2                                                     */
+    int32_t codebook_size;             /* 2048                                                  */
+    int32_t codebook_dim;              /* 256 (== vector_quantization_hidden_dimension)         */
+    int32_t num_quantizers;            /* 32                                                    */
+    int32_t num_semantic_quantizers;   /* 1                                                     */
+    int32_t num_hidden_layers;         /* 8 (per transformer)                                   */
+    int32_t num_attention_heads;       /* 8                                                     */
+    int32_t head_dim;                  /* 64                                                    */
+    int32_t intermediate_size;         /* 2048                                                  */
+    int32_t sliding_window;            /* 250                                                   */
+    int32_t resample_stride;           /* 2 (encodec_frame_rate / frame_rate)                   */
+    int32_t device;                    /* HIP device ordinal                                    */
+    float rope_theta;                  /* 10000                                                 */
+    float norm_eps;                    /* 1e-5                                                  */
+} ac_mimi_config;
+
 /* Library/ABI version: major*10000 + minor*100 + patch. */
 int ac_version(void);
 
 /* Create a handle for `cfg` on device cfg->device.  No device memory is allocated yet. */
 int ac_create(const ac_config* cfg, ac_handle** out);
+
+/* Same, for a Mimi handle.  Every other entry point below works on either kind of handle. */
+int ac_mimi_create(const ac_mimi_config* cfg, ac_handle** out);
 
 /* Hand one fp32 tensor to the handle (copied).  `name` uses the HF state-dict keys of
  * EncodecModel with weight-norm either
@@ -78,7 +116,15 @@ int ac_create(const ac_config* cfg, ac_handle** out);
  *                        folded inside ac_finalize as  w = v * (g / ||v||_2), norm over dims (1,2).
  * plus "<prefix>.bias", "<lstm>.weight_{ih,hh}_l{n}", "<lstm>.bias_{ih,hh}_l{n}",
  * "quantizer.layers.{k}.codebook.embed".  Other keys (embed_avg, cluster_size, inited) are
- * accepted and ignored.  `bytes` must equal 4 * number of elements expected for that key. */
+ * accepted and ignored.  `bytes` must equal 4 * number of elements expected for that key.
+ * Mimi handles take the keys of MimiModel.state_dict(): "<conv>.weight"/".bias" (no weight-norm),
+ * "{encoder,decoder}_transformer.layers.{l}.{self_attn.{q,k,v,o}_proj,mlp.fc{1,2}}.weight",
+ * ".{input,post_attention}_layernorm.{weight,bias}", ".{self_attn,mlp}_layer_scale.scale",
+ * "downsample.conv.weight", "upsample.conv.weight",
+ * "quantizer.{semantic,acoustic}_residual_vector_quantizer.{input,output}_proj.weight" and
+ * "...layers.{q}.codebook.{embed_sum,cluster_usage}" (embed = embed_sum / max(cluster_usage, 1e-5),
+ * [HF] mimi :980-983); optionally "encoder_transformer.rotary_emb.inv_freq" (the model's non-persistent
+ * buffer; computed as 1/theta^(2i/d) in fp32 when absent). */
 int ac_load_weights(ac_handle* h, const char* name, const void* host_ptr, size_t bytes);
 
 /* Check that every tensor of the configuration arrived, fold/pack them into the kernels' layouts
@@ -87,9 +133,11 @@ int ac_finalize(ac_handle* h);
 
 /* Frames produced for T samples: ceil at every strided conv (T=1..320 -> 1, 321 -> 2, ...). */
 int ac_num_frames(const ac_handle* h, int T);
-/* Hop length (product of ratios, 320) and latent width (128). */
+/* Hop length (product of ratios, 320; Mimi: x resample_stride = 1920), latent width of feats/qfeats
+ * (128; Mimi 512) and codebook vector width (EnCodec: == hidden; Mimi 256). */
 int ac_hop_length(const ac_handle* h);
 int ac_hidden_size(const ac_handle* h);
+int ac_codebook_dim(const ac_handle* h);
 
 /* Scratch the caller must provide (device memory, 256-byte aligned) for one call. */
 size_t ac_encode_workspace_bytes(const ac_handle* h, int B, int T);
@@ -118,9 +166,21 @@ int ac_decode(ac_handle* h, const int64_t* toks_dev, int B, int N, int K, float*
  * ac_dequantize: toks_dev [B,N,K] -> qfeats_dev [B,N,H] = sum_k E_k[tok]  ([HF]:440-447). */
 int ac_quantize(ac_handle* h, const float* feats_dev, int B, int N, int K, int64_t* toks_dev, void* stream);
 int ac_dequantize(ac_handle* h, const int64_t* toks_dev, int B, int N, int K, float* qfeats_dev, void* stream);
+/* Mimi's split quantiser projects in and out of the codebook space (mimi.py:139,153 ->
+ * [HF] mimi :1129-1138), which needs scratch: same calls with a workspace of
+ * ac_quantizer_workspace_bytes(h, B, N) bytes (0 for EnCodec handles, which may pass NULL). */
+size_t ac_quantizer_workspace_bytes(const ac_handle* h, int B, int N);
+int ac_quantize_ws(ac_handle* h, const float* feats_dev, int B, int N, int K, int64_t* toks_dev,
+                   void* workspace_dev, size_t workspace_bytes, void* stream);
+int ac_dequantize_ws(ac_handle* h, const int64_t* toks_dev, int B, int N, int K, float* qfeats_dev,
+                     void* workspace_dev, size_t workspace_bytes, void* stream);
 
-/* Copy the first K codebooks to embs_dev [K, codebook_size, H] fp32 (encodec.py:74-79). */
+/* Copy the first K codebooks to embs_dev [K, codebook_size, ac_codebook_dim] fp32 (encodec.py:74-79;
+ * mimi.py:52-62 `latent=True`). */
 int ac_embs(ac_handle* h, int K, float* embs_dev, void* stream);
+/* Mimi `latent=False` (mimi.py:63-90): every code vector through its quantiser's output projection
+ * -> embs_dev [K, codebook_size, hidden].  AC_EINVAL on EnCodec handles. */
+int ac_embs_projected(ac_handle* h, int K, float* embs_dev, void* stream);
 
 /* Sample-rate conversion at the Codec boundary (audiocodecs/codec.py:59-63,95-99 call
  * torchaudio.functional.resample): polyphase windowed-sinc FIR.  kern_dev [n][taps] is the filter
