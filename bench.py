@@ -33,6 +33,32 @@ FLOP_PER_AUDIO_S = 6.12e9
 LAYER_BYTES_PER_AUDIO_S = 117.6e6
 
 
+def cpu_baseline_mimi(cfg, sd, sig_cpu, clips=8):
+    """Same protocol with the Mimi oracle (oracle/mimi_oracle.py)."""
+    from oracle import mimi_oracle as O  # checker/baseline only -- never on the product path
+
+    W = O.cast_weights(sd)
+    x = sig_cpu[:clips]
+    ncpu = os.cpu_count() or 2
+    cands = sorted({t for t in (16, 32, 64, ncpu // 2) if 1 <= t <= ncpu}) or [ncpu]
+    best, best_t = None, None
+    with torch.inference_mode():
+        for t in cands:
+            torch.set_num_threads(t)
+            O.toks_to_sig(cfg, W, O.sig_to_toks(cfg, W, x[:1, :48000]))
+            t0 = time.perf_counter()
+            O.toks_to_sig(cfg, W, O.sig_to_toks(cfg, W, x))
+            dt = time.perf_counter() - t0
+            if best is None or dt < best:
+                best, best_t = dt, t
+    audio_s = x.shape[0] * x.shape[1] / cfg.sampling_rate
+    return {
+        "value": round(audio_s / best, 2), "unit": "audio-s/s", "cores": best_t, "kind": "port",
+        "sample": f"{clips} clips x {x.shape[1] / cfg.sampling_rate:.0f} s of the same batch, fp32 torch-CPU Mimi oracle; "
+                  f"best of thread counts {cands} (one timed run each after a warm-up)",
+    }
+
+
 def cpu_baseline(cfg, sd, sig_cpu, clips=8):
     """Oracle (kind 'port': torch-CPU restatement of the reference, oracle/encodec_oracle.py) on the
     host cores.  torch's CPU convs do not scale to every core of a 2-socket host on 8 clips, so a
@@ -65,13 +91,13 @@ def cpu_baseline(cfg, sd, sig_cpu, clips=8):
     }
 
 
-def measured_traffic(kernel_name, unit):
+def measured_traffic(kernel_name, unit, codec="encodec"):
     """HBM bytes per launch of `kernel_name` from the committed PMC summary (rocprofv3 --pmc FETCH_SIZE /
     WRITE_SIZE in separate passes, gfx950 FETCH x2 correction: tools/collect_traffic.py).  bench.py cannot
     run the profiler on itself, so the newest profiles/r*_traffic.json is quoted; null if absent."""
     import glob
 
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")) if ("mimi" in os.path.basename(f)) == (codec == "mimi"))
     if not files:
         return None
     try:
@@ -87,6 +113,8 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="clips per GPU")
+    ap.add_argument("--codec", choices=["encodec", "mimi"], default="encodec",
+                    help="encodec = BASELINE.json configs[1] (the contract's default); mimi = configs[3] shape (SURVEY.md §8 f3)")
     ap.add_argument("--seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -105,13 +133,20 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    from audiocodecs_amd import Encodec, checkpoint, prng
-    from audiocodecs_amd.config import ENCODEC_24KHZ as cfg
+    from audiocodecs_amd import Encodec, Mimi, checkpoint, prng
+    from audiocodecs_amd.config import ENCODEC_24KHZ, MIMI_24KHZ
     from audiocodecs_amd.sharding import gather_tokens
 
+    mimi = args.codec == "mimi"
+    cfg = MIMI_24KHZ if mimi else ENCODEC_24KHZ
+    label = "Mimi-24k" if mimi else "EnCodec-24k"
     B, T = args.batch, int(round(args.seconds * cfg.sampling_rate))
-    sd = checkpoint.synthetic_state_dict(cfg, seed=0)
-    codec = Encodec(cfg.sampling_rate, num_codebooks=8, state_dict=sd).eval()
+    if mimi:
+        sd = checkpoint.synthetic_mimi_state_dict(cfg, seed=0)
+        codec = Mimi(cfg.sampling_rate, num_codebooks=8, state_dict=sd).eval()
+    else:
+        sd = checkpoint.synthetic_state_dict(cfg, seed=0)
+        codec = Encodec(cfg.sampling_rate, num_codebooks=8, state_dict=sd).eval()
     # sig = 0.1*N(0,1), repo PRNG seed 123; each rank draws its own shard
     sig_cpu = torch.from_numpy((prng.normal(123, f"bench.sig.rank{rank}", (B, T)) * 0.1).astype(np.float32))
     sig = sig_cpu.cuda()
@@ -161,13 +196,13 @@ def main():
         else:
             roof = {"bound": "hbm", "achieved": round(nbytes / (tot_ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s"}
         roof["frac"] = round(roof["achieved"] / roof["peak"], 4)
-        roof["traffic"] = measured_traffic(name, roof["unit"])
+        roof["traffic"] = measured_traffic(name, roof["unit"], args.codec)
         roof["kernel"] = name
         roof["launches_per_step"] = launches / args.steps
         roof["avg_launch_us"] = round(avg_us, 2)
         roof["share_of_step"] = round(tot_ms / (dt * 1e3), 4)
         out = {
-            "metric": "encode+decode audio-sec/s, EnCodec-24k 8cb",
+            "metric": f"encode+decode audio-sec/s, {label} 8cb",
             "value": round(audio_s / dt, 1),
             "unit": "audio-s/s",
             "n_gpus": world,
@@ -178,14 +213,15 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic (0.1*N(0,1) clips, seeded synthetic weights of the EnCodec-24k architecture)",
-            "config": {"workload": f"EnCodec-24k 8 codebooks, encode+decode, {B} clips x {args.seconds:g} s per GPU, resident in HBM",
+            "data": f"synthetic (0.1*N(0,1) clips, seeded synthetic weights of the {label} architecture)",
+            "config": {"workload": f"{label} 8 codebooks, encode+decode, {B} clips x {args.seconds:g} s per GPU, resident in HBM",
                        "clips_per_gpu": B, "seconds_per_clip": args.seconds, "parallelism": f"clip-sharded x{world}"},
             "rtf": round(dt / audio_s, 7),
             "x_realtime_per_gpu": round(audio_s / dt / world, 1),
             "whole_path": {
-                "mfma_fp32_frac": round(FLOP_PER_AUDIO_S * audio_s / world / dt / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4),
-                "hbm_layer_boundary_frac": round(LAYER_BYTES_PER_AUDIO_S * audio_s / world / dt / (PEAK_HBM_GBS * 1e9), 4),
+                # EnCodec: SURVEY.md §8(d) per-audio-second figures; Mimi: the kernels' own algorithmic counts
+                "mfma_fp32_frac": round((sum(s[3] for s in stats) if mimi else FLOP_PER_AUDIO_S * audio_s / world) / dt / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4),
+                "hbm_layer_boundary_frac": round((sum(s[4] for s in stats) if mimi else LAYER_BYTES_PER_AUDIO_S * audio_s / world) / dt / (PEAK_HBM_GBS * 1e9), 4),
                 "ms_per_step_without_kernel_events": round(dt_plain / args.steps * 1e3, 3),
             },
             "roofline": roof,
@@ -196,7 +232,7 @@ def main():
             ],
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg, sd, sig_cpu)
+            out["cpu_baseline"] = (cpu_baseline_mimi if mimi else cpu_baseline)(cfg, sd, sig_cpu)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -19,11 +19,11 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, num_clips, q):
+def _worker(rank, world, port, num_clips, q, vocab=1024):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    full = (torch.arange(num_clips * 5 * 8).reshape(num_clips, 5, 8) * 7) % 1024
+    full = (torch.arange(num_clips * 5 * 8).reshape(num_clips, 5, 8) * 7) % vocab
     lo, hi = shard_bounds(num_clips, rank, world)
     got = gather_tokens(full[lo:hi].clone(), num_clips)
     q.put((rank, bool(torch.equal(got, full)), got.dtype == torch.int64))
@@ -37,6 +37,21 @@ def test_gather_tokens_two_ranks(num_clips):
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, 2, port, num_clips, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok and dt for _, ok, dt in res), res
+
+
+def test_gather_tokens_mimi_vocabulary():
+    """Mimi ids reach 2047: still exact through the int16 wire format."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, 5, q, 2048)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in procs]
