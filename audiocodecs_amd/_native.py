@@ -71,7 +71,7 @@ class AcMimiConfig(C.Structure):
 
 class AcKernelStat(C.Structure):
     _fields_ = [
-        ("name", C.c_char * 48),
+        ("name", C.c_char * 96),
         ("launches", C.c_int32),
         ("total_ms", C.c_float),
         ("flops", C.c_double),

@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -107,6 +108,7 @@ struct ac_handle {
     std::vector<const void*> lds_opted;
     // profiling
     bool prof = false;
+    bool prof_detail = false;   // AC_PROF_DETAIL=1: one record per tap-GEMM shape
     std::vector<ProfRec> recs;
     std::vector<std::string> prof_names;
     std::vector<hipEvent_t> ev_pool;
@@ -472,10 +474,13 @@ int run_tap(ac_handle* h, hipStream_t st, TapGemmParams& p) {
     const double flops = 2.0 * p.B * (double)p.M * p.N * kk;
     const double bytes = inb + (double)p.B * p.M * p.N * 4.0 * ((p.y ? 1 : 0) + (p.y_elu ? 1 : 0)) + (double)p.N * p.Ktot * 4.0;
     int rc = AC_OK;
+    char shape[64] = "";
+    if (h->prof && h->prof_detail)
+        std::snprintf(shape, sizeof shape, " B%d M%d N%d K%d J%d s%d", p.B, p.M, p.N, (int)kk, p.seg[0].J, p.seg[0].s);
 #define TAP_CASE(WGM, WGN, WM, WN)                                                                          \
     do {                                                                                                    \
         if (fast) {                                                                                         \
-            ProfScope ps(h, st, "tap_gemm4_kernel<" #WGM ", " #WGN ", " #WM ", " #WN ">", flops, bytes);    \
+            ProfScope ps(h, st, (std::string("tap_gemm4_kernel<" #WGM ", " #WGN ", " #WM ", " #WN ">") + shape).c_str(), flops, bytes); \
             rc = launch_tap4<WGM, WGN, WM, WN>(h, p, st);                                                   \
         } else if (vec) {                                                                                   \
             ProfScope ps(h, st, "tap_gemm_kernel<" #WGM ", " #WGN ", " #WM ", " #WN ", true>", flops, bytes); \
@@ -1306,6 +1311,8 @@ size_t ac_debug_captured(const ac_handle* h) { return h ? h->dbg_used : 0; }
 int ac_profile_begin(ac_handle* h) {
     if (!h) return AC_EINVAL;
     h->prof = true;
+    const char* det = std::getenv("AC_PROF_DETAIL");
+    h->prof_detail = det && det[0] == '1';
     h->recs.clear();
     h->ev_used = 0;
     return AC_OK;

@@ -244,7 +244,7 @@ class Encodec(Codec):
         try:
             fn()
         finally:
-            buf = (_native.AcKernelStat * 64)()
-            n = nat.lib.ac_profile_end(nat.h, buf, 64)
+            buf = (_native.AcKernelStat * 256)()
+            n = nat.lib.ac_profile_end(nat.h, buf, 256)
         _native.check(n, nat.h, "ac_profile_end")
         return [(buf[i].name.decode(), buf[i].launches, buf[i].total_ms, buf[i].flops, buf[i].bytes) for i in range(n)]

@@ -193,7 +193,8 @@ int ac_resample(const float* x_dev, int B, int L, const float* kern_dev, int n, 
  * ac_profile_begin arms it; every launch made by subsequent calls is bracketed by events.
  * ac_profile_end synchronises those events and writes up to `cap` records; returns the count. */
 typedef struct ac_kernel_stat {
-    char name[48];       /* kernel (family) name as it appears in rocprofv3 --kernel-trace */
+    char name[96];       /* kernel (family) name as it appears in rocprofv3 --kernel-trace; with the
+                          * environment variable AC_PROF_DETAIL=1 the tap-GEMM records also carry their shape */
     int32_t launches;
     float total_ms;
     double flops;        /* algorithmic flops of those launches (2*M*N*K, ...)             */
