@@ -27,7 +27,7 @@ import torch
 from . import prng
 from .config import EncodecConfig
 
-__all__ = ["conv_specs", "synthetic_state_dict", "fold_weight_norm", "mimi_conv_specs", "synthetic_mimi_state_dict", "mimi_codebook"]
+__all__ = ["conv_specs", "synthetic_state_dict", "fold_weight_norm", "mimi_conv_specs", "synthetic_mimi_state_dict", "mimi_codebook", "dac_conv_specs", "dac_snake_specs", "synthetic_dac_state_dict"]
 
 CODEBOOK_S0 = 0.10
 CODEBOOK_RHO = 0.94
@@ -238,3 +238,90 @@ def mimi_codebook(sd: Dict[str, torch.Tensor], part: str, q: int) -> torch.Tenso
     """embed = embed_sum / clamp(cluster_usage, 1e-5)[:, None]  ([HF] mimi :980-983), fp32."""
     cb = f"quantizer.{part}_residual_vector_quantizer.layers.{q}.codebook"
     return sd[f"{cb}.embed_sum"].float() / sd[f"{cb}.cluster_usage"].float().clamp(min=1e-5)[:, None]
+
+
+# ---------------------------------------------------------------------------------------------
+# DAC (SURVEY.md §8 f4).  The reference's backend (descript-audio-codec 1.0.0) is not on disk; the key
+# layout below is that of the same-architecture third-party HF ``DacModel.state_dict()`` (plain weights).
+# ---------------------------------------------------------------------------------------------
+def dac_conv_specs(cfg) -> List[Tuple[str, str, int, int, int, int, int]]:
+    """(key prefix, kind, Cin, Cout, kernel, stride, dilation) for every conv ([HF] dac :175-264, :407-474)."""
+    specs: List[Tuple[str, str, int, int, int, int, int]] = []
+
+    def res_units(prefix: str, dim: int):
+        for u, d in enumerate(cfg.dilations, start=1):
+            specs.append((f"{prefix}.res_unit{u}.conv1", "conv", dim, dim, 7, 1, d))
+            specs.append((f"{prefix}.res_unit{u}.conv2", "conv", dim, dim, 1, 1, 1))
+
+    c = cfg.encoder_hidden_size
+    specs.append(("encoder.conv1", "conv", 1, c, 7, 1, 1))
+    for i, s in enumerate(cfg.downsampling_ratios):
+        res_units(f"encoder.block.{i}", c)
+        specs.append((f"encoder.block.{i}.conv1", "conv", c, 2 * c, 2 * s, s, 1))
+        c *= 2
+    specs.append(("encoder.conv2", "conv", c, cfg.hidden_size, 3, 1, 1))
+    c = cfg.decoder_hidden_size
+    specs.append(("decoder.conv1", "conv", cfg.hidden_size, c, 7, 1, 1))
+    for i, s in enumerate(cfg.upsampling_ratios):
+        specs.append((f"decoder.block.{i}.conv_t1", "convtr", c, c // 2, 2 * s, s, 1))
+        res_units(f"decoder.block.{i}", c // 2)
+        c //= 2
+    specs.append(("decoder.conv2", "conv", c, 1, 7, 1, 1))
+    return specs
+
+
+def dac_snake_specs(cfg) -> List[Tuple[str, int]]:
+    """(key prefix, channels) of every Snake1d ([HF] dac :86-100): alpha has shape [1, C, 1]."""
+    out: List[Tuple[str, int]] = []
+
+    def res_units(prefix: str, dim: int):
+        for u in range(1, len(cfg.dilations) + 1):
+            out.append((f"{prefix}.res_unit{u}.snake1", dim))
+            out.append((f"{prefix}.res_unit{u}.snake2", dim))
+
+    c = cfg.encoder_hidden_size
+    for i in range(len(cfg.downsampling_ratios)):
+        res_units(f"encoder.block.{i}", c)
+        out.append((f"encoder.block.{i}.snake1", c))
+        c *= 2
+    out.append(("encoder.snake1", c))
+    c = cfg.decoder_hidden_size
+    for i in range(len(cfg.upsampling_ratios)):
+        out.append((f"decoder.block.{i}.snake1", c))
+        res_units(f"decoder.block.{i}", c // 2)
+        c //= 2
+    out.append(("decoder.snake1", c))
+    return out
+
+
+def synthetic_dac_state_dict(cfg, seed: int = 0) -> Dict[str, torch.Tensor]:
+    """Seeded checkpoint in HF DacModel layout: conv weights ~ N(0, 1/fan_in) * U(0.9, 1.1) (the k1 conv of a
+    residual unit at 0.5 gain so 3 units per block do not blow the scale up), biases ~ N(0, 0.02^2), Snake
+    alpha ~ U(0.5, 2), quantiser in_proj ~ N(0, 1/in), out_proj ~ in_proj^T + noise, codebook k ~ N(0, 0.85^2k)
+    (L2-normalised for the search; the un-normalised vectors feed the output projection)."""
+    sd: Dict[str, torch.Tensor] = {}
+    for prefix, kind, cin, cout, k, s, d in dac_conv_specs(cfg):
+        if kind == "conv":
+            shape, fan_in = (cout, cin, k), cin * k
+        else:
+            shape, fan_in = (cin, cout, k), cin * k / s
+        gain = 0.5 if prefix.endswith("conv2") and ".res_unit" in prefix else 1.0
+        w = prng.normal(seed, prefix + ".w", shape) * (gain / np.sqrt(fan_in))
+        w = w * prng.uniform(seed, prefix + ".g", (shape[0], 1, 1), 0.9, 1.1)
+        sd[f"{prefix}.weight"] = _f32(w)
+        sd[f"{prefix}.bias"] = _f32(prng.normal(seed, prefix + ".b", (cout,)) * 0.02)
+    for prefix, c in dac_snake_specs(cfg):
+        sd[f"{prefix}.alpha"] = _f32(prng.uniform(seed, prefix + ".alpha", (1, c, 1), 0.5, 2.0))
+    H, D = cfg.hidden_size, cfg.codebook_dim
+    for q in range(cfg.n_codebooks):
+        p = f"quantizer.quantizers.{q}"
+        sd[f"{p}.in_proj.weight"] = _f32(prng.normal(seed, p + ".in", (D, H, 1)) / np.sqrt(H))
+        sd[f"{p}.in_proj.bias"] = _f32(prng.normal(seed, p + ".inb", (D,)) * 0.02)
+        w_in = prng.normal(seed, p + ".in", (D, H, 1)) / np.sqrt(H)
+        # out_proj ~ in_proj^T (W W^T ~ I_D) + noise: subtracting out_proj(q) then really removes the quantised component
+        w_out = np.transpose(w_in, (1, 0, 2)) * prng.uniform(seed, p + ".outg", (1, D, 1), 0.9, 1.1)
+        w_out = w_out + prng.normal(seed, p + ".out", (H, D, 1)) * (0.1 / np.sqrt(H))
+        sd[f"{p}.out_proj.weight"] = _f32(w_out)
+        sd[f"{p}.out_proj.bias"] = _f32(prng.normal(seed, p + ".outb", (H,)) * 0.002)
+        sd[f"{p}.codebook.weight"] = _f32(prng.normal(seed, p + ".cb", (cfg.codebook_size, D)) * (1.0 * 0.85**q))
+    return sd

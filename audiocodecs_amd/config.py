@@ -12,7 +12,7 @@ import math
 from dataclasses import dataclass, field
 from typing import Tuple
 
-__all__ = ["EncodecConfig", "TINY", "ENCODEC_24KHZ", "MimiConfig", "MIMI_24KHZ", "MIMI_TINY"]
+__all__ = ["EncodecConfig", "TINY", "ENCODEC_24KHZ", "MimiConfig", "MIMI_24KHZ", "MIMI_TINY", "DacConfig", "DAC_44KHZ", "DAC_24KHZ", "DAC_16KHZ", "DAC_TINY"]
 
 
 @dataclass(frozen=True)
@@ -114,3 +114,52 @@ MIMI_TINY = MimiConfig(
     num_filters=8, hidden_size=64, codebook_dim=32, num_hidden_layers=2, num_attention_heads=4, head_dim=16,
     intermediate_size=128, sliding_window=6,
 )
+
+
+@dataclass(frozen=True)
+class DacConfig:
+    """Architecture of the Descript Audio Codec as the reference wrapper uses it
+    (/root/reference/audiocodecs/dac.py:28-60 loads `dac.DAC` of descript-audio-codec 1.0.0 -- NOT on
+    disk).  Field names follow the same-architecture third-party ``transformers.DacConfig``
+    (SURVEY.md Appendix D); defaults = the 44.1 kHz model of BASELINE.json configs[2]."""
+
+    sampling_rate: int = 44100
+    encoder_hidden_size: int = 64
+    downsampling_ratios: Tuple[int, ...] = (2, 4, 8, 8)
+    decoder_hidden_size: int = 1536
+    upsampling_ratios: Tuple[int, ...] = (8, 8, 4, 2)
+    n_codebooks: int = 9
+    codebook_size: int = 1024
+    codebook_dim: int = 8
+    dilations: Tuple[int, ...] = (1, 3, 9)  # residual units per block ([HF] dac :218-220)
+
+    @property
+    def hidden_size(self) -> int:  # latent width
+        return self.encoder_hidden_size * 2 ** len(self.downsampling_ratios)
+
+    @property
+    def hop_length(self) -> int:
+        return int(math.prod(self.downsampling_ratios))
+
+    def num_frames(self, num_samples: int) -> int:
+        """Encoder output length: symmetric padding, so each strided conv (k = 2s, pad = ceil(s/2)) gives
+        floor((L + 2*ceil(s/2) - 2s) / s) + 1; the stride-1 convs keep the length."""
+        n = num_samples
+        for s in self.downsampling_ratios:
+            n = (n + 2 * math.ceil(s / 2) - 2 * s) // s + 1
+        return n
+
+    def num_samples(self, num_frames: int) -> int:
+        """Decoder output length: each transposed conv (k = 2s, pad = ceil(s/2)) gives (L-1)*s - 2*pad + 2s."""
+        n = num_frames
+        for s in self.upsampling_ratios:
+            n = (n - 1) * s - 2 * math.ceil(s / 2) + 2 * s
+        return n
+
+
+DAC_44KHZ = DacConfig()
+DAC_24KHZ = DacConfig(sampling_rate=24000, downsampling_ratios=(2, 4, 5, 8), upsampling_ratios=(8, 5, 4, 2), n_codebooks=32)
+DAC_16KHZ = DacConfig(sampling_rate=16000, downsampling_ratios=(2, 4, 5, 8), upsampling_ratios=(8, 5, 4, 2), n_codebooks=12)
+# 1/8 width, odd stride included, every activation fits a fixture
+DAC_TINY = DacConfig(encoder_hidden_size=8, decoder_hidden_size=64, downsampling_ratios=(2, 4, 5, 8),
+                     upsampling_ratios=(8, 5, 4, 2), n_codebooks=4)

@@ -67,3 +67,29 @@ def mimi_checkpoints():
         return _MIMI_CKPT[key]
 
     return get
+
+
+@pytest.fixture(scope="session")
+def dac_golden():
+    z = np.load(os.path.join(GOLDEN_DIR, "dac_golden.npz"))
+    meta = json.loads(bytes(z["meta_json"]).decode())
+    return z, meta
+
+
+_DAC_CKPT = {}
+
+
+@pytest.fixture(scope="session")
+def dac_checkpoints():
+    """(cfg_name, seed) -> (DacConfig, HF-layout synthetic DAC state dict); cached for the session."""
+    from audiocodecs_amd import checkpoint
+    from audiocodecs_amd.config import DAC_44KHZ, DAC_TINY
+
+    def get(cfg_name, seed):
+        key = (cfg_name, seed)
+        if key not in _DAC_CKPT:
+            cfg = {"full": DAC_44KHZ, "tiny": DAC_TINY}[cfg_name]
+            _DAC_CKPT[key] = (cfg, checkpoint.synthetic_dac_state_dict(cfg, seed=seed))
+        return _DAC_CKPT[key]
+
+    return get
