@@ -12,7 +12,7 @@ import os
 
 import torch  # noqa: F401  (loads libamdhip64 first)
 
-__all__ = ["lib", "lib_path", "AcConfig", "AcMimiConfig", "AcKernelStat", "NativeError", "check", "EXPORTS"]
+__all__ = ["lib", "lib_path", "AcConfig", "AcMimiConfig", "AcDacConfig", "AcKernelStat", "NativeError", "check", "EXPORTS"]
 
 AC_MAX_RATIOS = 8
 lib_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libaudiocodecs_amd.so")
@@ -69,6 +69,27 @@ class AcMimiConfig(C.Structure):
     ]
 
 
+AC_MAX_DILATIONS = 4
+
+
+class AcDacConfig(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_int32),
+        ("sampling_rate", C.c_int32),
+        ("encoder_hidden_size", C.c_int32),
+        ("decoder_hidden_size", C.c_int32),
+        ("num_ratios", C.c_int32),
+        ("downsampling_ratios", C.c_int32 * AC_MAX_RATIOS),
+        ("upsampling_ratios", C.c_int32 * AC_MAX_RATIOS),
+        ("n_codebooks", C.c_int32),
+        ("codebook_size", C.c_int32),
+        ("codebook_dim", C.c_int32),
+        ("num_dilations", C.c_int32),
+        ("dilations", C.c_int32 * AC_MAX_DILATIONS),
+        ("device", C.c_int32),
+    ]
+
+
 class AcKernelStat(C.Structure):
     _fields_ = [
         ("name", C.c_char * 96),
@@ -85,9 +106,11 @@ EXPORTS = {
     "ac_version": (_i, []),
     "ac_create": (_i, [C.POINTER(AcConfig), C.POINTER(_vp)]),
     "ac_mimi_create": (_i, [C.POINTER(AcMimiConfig), C.POINTER(_vp)]),
+    "ac_dac_create": (_i, [C.POINTER(AcDacConfig), C.POINTER(_vp)]),
     "ac_load_weights": (_i, [_vp, C.c_char_p, _vp, _sz]),
     "ac_finalize": (_i, [_vp]),
     "ac_num_frames": (_i, [_vp, _i]),
+    "ac_num_samples": (C.c_longlong, [_vp, _i]),
     "ac_hop_length": (_i, [_vp]),
     "ac_hidden_size": (_i, [_vp]),
     "ac_codebook_dim": (_i, [_vp]),
@@ -98,6 +121,8 @@ EXPORTS = {
     "ac_decode": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "ac_quantize": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "ac_dequantize": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    "ac_encode_quantized": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "ac_encode_feats_latent": (_i, [_vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
     "ac_quantizer_workspace_bytes": (_sz, [_vp, _i, _i]),
     "ac_quantize_ws": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "ac_dequantize_ws": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _sz, _vp]),

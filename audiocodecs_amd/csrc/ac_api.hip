@@ -20,6 +20,7 @@
 #include "thin.h"
 #include "rb_fused.h"
 #include "mimi.h"
+#include "dac.h"
 
 using namespace ac;
 
@@ -68,6 +69,27 @@ struct MimiPlan {
     int D = 0;                                         // SEANet width at the bottleneck
 };
 
+struct DacResUnitPlan {
+    PackedGemm c7, c1;                                 // dilated k7 conv, k1 conv (both C -> C)
+    size_t a1 = 0, a1i = 0, a2 = 0, a2i = 0;           // Snake alpha / (alpha + 1e-9)^-1 of snake1, snake2
+    int dil = 1;
+};
+
+struct DacBlockPlan {
+    int C = 0, stride = 1;                             // residual-unit width; stride of the block's (transposed) conv
+    std::vector<DacResUnitPlan> ru;
+    size_t a = 0, ai = 0;                              // the block's own Snake (before the strided / transposed conv)
+    PackedGemm conv;
+};
+
+struct DacPlan {
+    PackedGemm enc_stem, enc_final, dec_first, dec_head, in_proj0;
+    std::vector<DacBlockPlan> enc, dec;
+    size_t enc_a = 0, enc_ai = 0, dec_a = 0, dec_ai = 0;
+    size_t win = 0, bin = 0, wout = 0, bout = 0, cb = 0, cbn = 0, c2 = 0, proj = 0;
+    int H = 0;                                         // latent width
+};
+
 struct ProfRec {
     int name_id;
     int count;
@@ -77,13 +99,15 @@ struct ProfRec {
 
 }  // namespace
 
-enum { ARCH_ENCODEC = 0, ARCH_MIMI = 1 };
+enum { ARCH_ENCODEC = 0, ARCH_MIMI = 1, ARCH_DAC = 2 };
 
 struct ac_handle {
     int arch = ARCH_ENCODEC;
     ac_config cfg{};
     ac_mimi_config mcfg{};
     MimiPlan mimi;
+    ac_dac_config dcfg{};
+    DacPlan dac;
     std::string err;
     std::map<std::string, std::vector<float>> host;
     bool finalized = false;
@@ -449,6 +473,8 @@ TapSeg make_seg(const Act& x, int s, int J, int pad /*PAD_**/, int extra, int ko
     g.reflect = pad;
     g.elu = 0;
     g.kofs = kofs;
+    g.pad = pad_left;     // causal: every tap to the left
+    g.dil = 1;
     return g;
 }
 
@@ -626,8 +652,11 @@ int resblock_fwd(ac_handle* h, hipStream_t st, const ResBlockPlan& rb, const Act
 bool thin_ok(const ac_config& c, int k) { return c.num_filters % 4 == 0 && c.num_filters <= 64 && k <= THIN_MAXK; }
 
 int thin_stem(ac_handle* h, hipStream_t st, const PackedGemm& g, int F, int k, int pad, const float* sig, const float* rel_len, int B, int T,
-              Out out, Act2* y) {
+              Out out, Act2* y, int padl = -1, const float* alpha = nullptr, const float* alpha_inv = nullptr) {
     ThinParams p{};
+    p.padl = padl < 0 ? k - 1 : padl;
+    p.alpha = alpha;
+    p.alpha_inv = alpha_inv;
     p.x = sig;
     p.w = h->blob + g.w_off;
     p.bias = h->blob + g.b_off;
@@ -655,8 +684,11 @@ int stem_fwd(ac_handle* h, hipStream_t st, const float* sig, const float* rel_le
     return thin_stem(h, st, h->enc_stem, h->cfg.num_filters, h->cfg.kernel_size, PAD_REFLECT, sig, rel_len, B, T, out, y);
 }
 
-int thin_head(ac_handle* h, hipStream_t st, const PackedGemm& g, int F, int k, int pad, const Act& x, int B, float* sig) {
+int thin_head(ac_handle* h, hipStream_t st, const PackedGemm& g, int F, int k, int pad, const Act& x, int B, float* sig, int padl = -1,
+              int tanh_out = 0) {
     ThinParams p{};
+    p.padl = padl < 0 ? k - 1 : padl;
+    p.tanh_out = tanh_out;
     p.x = x.p;
     p.w = h->blob + g.w_off;
     p.bias = h->blob + g.b_off;
@@ -1007,6 +1039,7 @@ int decoder_fwd(ac_handle* h, hipStream_t st, const long long* toks, int B, int 
 }
 
 #include "mimi_path.h"
+#include "dac_path.h"
 
 }  // namespace
 
@@ -1066,6 +1099,35 @@ int ac_mimi_create(const ac_mimi_config* cfg, ac_handle** out) {
     return AC_OK;
 }
 
+int ac_dac_create(const ac_dac_config* cfg, ac_handle** out) {
+    if (!cfg || !out) return AC_EINVAL;
+    *out = nullptr;
+    if (cfg->struct_size != (int32_t)sizeof(ac_dac_config)) return AC_EINVAL;
+    const ac_dac_config& c = *cfg;
+    if (c.num_ratios < 1 || c.num_ratios > AC_MAX_RATIOS || c.encoder_hidden_size < 1 || c.decoder_hidden_size < (1 << c.num_ratios) ||
+        c.decoder_hidden_size % (1 << c.num_ratios) || c.n_codebooks < 1 || c.codebook_size % 64 || c.codebook_size < 64 ||
+        c.codebook_dim != DAC_D || c.num_dilations < 1 || c.num_dilations > AC_MAX_DILATIONS)
+        return AC_EINVAL;
+    const int H = c.encoder_hidden_size << c.num_ratios;
+    if (H % 64 || H > 1024) return AC_EINVAL;
+    for (int i = 0; i < c.num_dilations; ++i)
+        if (c.dilations[i] < 1 || 6 * c.dilations[i] > GEN_EXTRA) return AC_EINVAL;
+    for (int i = 0; i < c.num_ratios; ++i)
+        if (c.downsampling_ratios[i] < 1 || c.upsampling_ratios[i] < 1) return AC_EINVAL;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= c.device || c.device < 0) return AC_ENODEV;
+    ac_handle* h = new (std::nothrow) ac_handle();
+    if (!h) return AC_ENOMEM;
+    h->arch = ARCH_DAC;
+    h->dcfg = c;
+    h->hop = 1;
+    for (int i = 0; i < c.num_ratios; ++i) h->hop *= c.downsampling_ratios[i];
+    h->D = H;
+    h->dac.H = H;
+    *out = h;
+    return AC_OK;
+}
+
 int ac_load_weights(ac_handle* h, const char* name, const void* host_ptr, size_t bytes) {
     if (!h || !name || !host_ptr) return h ? fail(h, AC_EINVAL, "null argument") : AC_EINVAL;
     if (h->finalized) return fail(h, AC_ESTATE, "handle already finalized");
@@ -1096,6 +1158,11 @@ int ac_finalize(ac_handle* h) {
         Packer pk{h};
         if (int rc = mimi_finalize(h, pk)) return rc;
         return upload_blob(h, pk, h->mcfg.device);
+    }
+    if (h->arch == ARCH_DAC) {
+        Packer pk{h};
+        if (int rc = dac_finalize(h, pk)) return rc;
+        return upload_blob(h, pk, h->dcfg.device);
     }
     const ac_config& c = h->cfg;
     Arch a = make_arch(c);
@@ -1147,18 +1214,60 @@ int ac_finalize(ac_handle* h) {
 int ac_num_frames(const ac_handle* h, int T) {
     if (!h || T < 1) return AC_EINVAL;
     if (h->arch == ARCH_MIMI) return cdiv(mimi_num_frames25(h->mcfg, T), h->mcfg.resample_stride);
+    if (h->arch == ARCH_DAC) return dac_num_frames(h->dcfg, T);   // 0: too short for the strided convs
     long long L = T;
     for (int r = h->cfg.num_ratios - 1; r >= 0; --r) L = (L + h->cfg.upsampling_ratios[r] - 1) / h->cfg.upsampling_ratios[r];
     return (int)L;
 }
+long long ac_num_samples(const ac_handle* h, int N) {
+    if (!h || N < 1) return AC_EINVAL;
+    return h->arch == ARCH_DAC ? dac_num_samples(h->dcfg, N) : (long long)N * h->hop;
+}
 int ac_hop_length(const ac_handle* h) { return h ? h->hop : AC_EINVAL; }
-int ac_hidden_size(const ac_handle* h) { return h ? (h->arch == ARCH_MIMI ? h->mcfg.hidden_size : h->cfg.hidden_size) : AC_EINVAL; }
-int ac_codebook_dim(const ac_handle* h) { return h ? (h->arch == ARCH_MIMI ? h->mcfg.codebook_dim : h->cfg.hidden_size) : AC_EINVAL; }
+int ac_hidden_size(const ac_handle* h) {
+    if (!h) return AC_EINVAL;
+    return h->arch == ARCH_MIMI ? h->mcfg.hidden_size : h->arch == ARCH_DAC ? h->dac.H : h->cfg.hidden_size;
+}
+int ac_codebook_dim(const ac_handle* h) {
+    if (!h) return AC_EINVAL;
+    return h->arch == ARCH_MIMI ? h->mcfg.codebook_dim : h->arch == ARCH_DAC ? DAC_D : h->cfg.hidden_size;
+}
 
-static int num_q(const ac_handle* h) { return h->arch == ARCH_MIMI ? h->mcfg.num_quantizers : h->cfg.num_quantizers; }
+static int num_q(const ac_handle* h) {
+    return h->arch == ARCH_MIMI ? h->mcfg.num_quantizers : h->arch == ARCH_DAC ? h->dcfg.n_codebooks : h->cfg.num_quantizers;
+}
 
 static Workspace any_plan_ws(const ac_handle* h, int B, int T, int N, bool enc) {
+    if (h->arch == ARCH_DAC) return dac_plan_ws(h, B, T, N, enc);
     return h->arch == ARCH_MIMI ? mimi_plan_ws(h, B, T, N, enc) : plan_ws(h, B, T, N, enc);
+}
+
+// DAC: clips go through the stack in chunks that keep the workspace bounded (dac_path.h)
+static int dac_encode_impl(ac_handle* h, const float* sig, int B, int T, int K, float* z_out, float* zlat_out, long long* toks, float* qfeats,
+                           void* ws, size_t ws_bytes, hipStream_t st) {
+    const int N = dac_num_frames(h->dcfg, T);
+    if (N < 1) return fail(h, AC_EINVAL, "input too short: %d samples give no frame (hop %d)", T, h->hop);
+    const int Bc = dac_chunk_clips(h, B, T, 0, true), H = h->dac.H;
+    for (int b0 = 0; b0 < B; b0 += Bc) {
+        const int nb = std::min(Bc, B - b0);
+        WsPtrs p;
+        int rc = carve(h, dac_plan_ws(h, B, T, 0, true), ws, ws_bytes, &p);
+        if (rc) return rc;
+        float* z = z_out ? z_out + (size_t)b0 * N * H : p.act[NACT - 1];
+        if (!z_out) p.used[NACT - 1] = true;
+        rc = dac_encoder_fwd(h, st, sig + (size_t)b0 * T, nb, T, z, p);
+        if (rc) return rc;
+        if (zlat_out) {
+            Act za{z, (long long)N * H, H, N, H};
+            rc = dac_conv(h, st, h->dac.in_proj0, za, 1, 1, 1, 0, Out{zlat_out + (size_t)b0 * N * DAC_D, nullptr}, SnakeP{}, nb, nullptr);
+            if (rc) return rc;
+        }
+        if (toks) {
+            rc = dac_vq_encode(h, st, z, nb * N, K, toks + (size_t)b0 * N * K, qfeats ? qfeats + (size_t)b0 * N * H : nullptr);
+            if (rc) return rc;
+        }
+    }
+    return AC_OK;
 }
 
 size_t ac_encode_workspace_bytes(const ac_handle* h, int B, int T) {
@@ -1178,6 +1287,7 @@ int ac_encode_feats(ac_handle* h, const float* sig, const float* rel_len, int B,
     int rc = check_ready(h);
     if (rc) return rc;
     if (!sig || !feats || B < 1 || T < 1) return fail(h, AC_EINVAL, "ac_encode_feats: bad argument (B=%d, T=%d)", B, T);
+    if (h->arch == ARCH_DAC) return dac_encode_impl(h, sig, B, T, 0, feats, nullptr, nullptr, nullptr, ws, ws_bytes, (hipStream_t)stream);
     WsPtrs p;
     rc = carve(h, any_plan_ws(h, B, T, 0, true), ws, ws_bytes, &p);
     if (rc) return rc;
@@ -1190,6 +1300,8 @@ int ac_encode(ac_handle* h, const float* sig, const float* rel_len, int B, int T
     if (rc) return rc;
     if (!sig || !toks || B < 1 || T < 1) return fail(h, AC_EINVAL, "ac_encode: bad argument (B=%d, T=%d)", B, T);
     if (K < 1 || K > num_q(h)) return fail(h, AC_EINVAL, "ac_encode: K=%d outside [1, %d]", K, num_q(h));
+    if (h->arch == ARCH_DAC)
+        return dac_encode_impl(h, sig, B, T, K, nullptr, nullptr, reinterpret_cast<long long*>(toks), nullptr, ws, ws_bytes, (hipStream_t)stream);
     WsPtrs p;
     rc = carve(h, any_plan_ws(h, B, T, 0, true), ws, ws_bytes, &p);
     if (rc) return rc;
@@ -1217,6 +1329,7 @@ int ac_quantize_ws(ac_handle* h, const float* feats, int B, int N, int K, int64_
     int rc = check_ready(h);
     if (rc) return rc;
     if (!feats || !toks || B < 1 || N < 1 || K < 1 || K > num_q(h)) return fail(h, AC_EINVAL, "ac_quantize: bad argument");
+    if (h->arch == ARCH_DAC) return dac_vq_encode(h, (hipStream_t)stream, feats, B * N, K, reinterpret_cast<long long*>(toks), nullptr);
     if (h->arch == ARCH_MIMI) {
         const ac_mimi_config& c = h->mcfg;
         if (!ws || ws_bytes < ac_quantizer_workspace_bytes(h, B, N)) return fail(h, AC_ENOMEM, "ac_quantize: workspace missing or too small");
@@ -1237,6 +1350,7 @@ int ac_dequantize_ws(ac_handle* h, const int64_t* toks, int B, int N, int K, flo
     int rc = check_ready(h);
     if (rc) return rc;
     if (!qfeats || !toks || B < 1 || N < 1 || K < 1 || K > num_q(h)) return fail(h, AC_EINVAL, "ac_dequantize: bad argument");
+    if (h->arch == ARCH_DAC) return dac_from_codes(h, (hipStream_t)stream, reinterpret_cast<const long long*>(toks), B * N, K, qfeats);
     if (h->arch == ARCH_MIMI) {
         if (!ws || ws_bytes < ac_quantizer_workspace_bytes(h, B, N)) return fail(h, AC_ENOMEM, "ac_dequantize: workspace missing or too small");
         float* qsum = reinterpret_cast<float*>(align_up(reinterpret_cast<uintptr_t>(ws), 256));
@@ -1255,6 +1369,25 @@ int ac_decode(ac_handle* h, const int64_t* toks, int B, int N, int K, float* sig
     if (rc) return rc;
     if (!sig || !toks || B < 1 || N < 1) return fail(h, AC_EINVAL, "ac_decode: bad argument (B=%d, N=%d)", B, N);
     if (K < 1 || K > num_q(h)) return fail(h, AC_EINVAL, "ac_decode: K=%d outside [1, %d]", K, num_q(h));
+    if (h->arch == ARCH_DAC) {
+        hipStream_t st = (hipStream_t)stream;
+        const int Bc = dac_chunk_clips(h, B, 0, N, false);
+        const long long Lout = dac_num_samples(h->dcfg, N);
+        if (Lout < 1) return fail(h, AC_EINVAL, "ac_decode: %d frames decode to no samples", N);
+        for (int b0 = 0; b0 < B; b0 += Bc) {
+            const int nb = std::min(Bc, B - b0);
+            WsPtrs p;
+            rc = carve(h, dac_plan_ws(h, B, 0, N, false), ws, ws_bytes, &p);
+            if (rc) return rc;
+            float* zq = p.take();
+            rc = dac_from_codes(h, st, reinterpret_cast<const long long*>(toks) + (size_t)b0 * N * K, nb * N, K, zq);
+            if (rc) return rc;
+            capture(h, st, Act{zq, (long long)N * h->dac.H, h->dac.H, N, h->dac.H}, nb);
+            rc = dac_decoder_fwd(h, st, zq, nb, N, sig + (size_t)b0 * Lout, p);
+            if (rc) return rc;
+        }
+        return AC_OK;
+    }
     WsPtrs p;
     rc = carve(h, any_plan_ws(h, B, 0, N, false), ws, ws_bytes, &p);
     if (rc) return rc;
@@ -1276,16 +1409,24 @@ int ac_embs(ac_handle* h, int K, float* embs, void* stream) {
     int rc = check_ready(h);
     if (rc) return rc;
     if (!embs || K < 1 || K > num_q(h)) return fail(h, AC_EINVAL, "ac_embs: bad argument");
-    const bool mimi = h->arch == ARCH_MIMI;
-    const size_t n = mimi ? (size_t)K * h->mcfg.codebook_size * h->mcfg.codebook_dim : (size_t)K * h->cfg.codebook_size * h->cfg.hidden_size;
-    HIPCHK(h, hipMemcpyAsync(embs, h->blob + (mimi ? h->mimi.cb_plain : h->cb_plain), n * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    size_t n, off;
+    if (h->arch == ARCH_MIMI) { n = (size_t)K * h->mcfg.codebook_size * h->mcfg.codebook_dim; off = h->mimi.cb_plain; }
+    else if (h->arch == ARCH_DAC) { n = (size_t)K * h->dcfg.codebook_size * DAC_D; off = h->dac.cb; }
+    else { n = (size_t)K * h->cfg.codebook_size * h->cfg.hidden_size; off = h->cb_plain; }
+    HIPCHK(h, hipMemcpyAsync(embs, h->blob + off, n * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return AC_OK;
 }
 
 int ac_embs_projected(ac_handle* h, int K, float* embs, void* stream) {
     int rc = check_ready(h);
     if (rc) return rc;
-    if (h->arch != ARCH_MIMI) return fail(h, AC_EINVAL, "ac_embs_projected: only Mimi has an output projection");
+    if (h->arch == ARCH_DAC) {   // out_proj_k(codebook_k) + bias, tabulated at ac_finalize (dac.py:68-90)
+        if (!embs || K < 1 || K > h->dcfg.n_codebooks) return fail(h, AC_EINVAL, "ac_embs_projected: bad argument");
+        const size_t n = (size_t)K * h->dcfg.codebook_size * h->dac.H;
+        HIPCHK(h, hipMemcpyAsync(embs, h->blob + h->dac.proj, n * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+        return AC_OK;
+    }
+    if (h->arch != ARCH_MIMI) return fail(h, AC_EINVAL, "ac_embs_projected: EnCodec has no output projection");
     const ac_mimi_config& c = h->mcfg;
     if (!embs || K < 1 || K > c.num_quantizers) return fail(h, AC_EINVAL, "ac_embs_projected: bad argument");
     for (int q = 0; q < K; ++q) {
@@ -1296,6 +1437,22 @@ int ac_embs_projected(ac_handle* h, int K, float* embs, void* stream) {
         if (rc) return rc;
     }
     return AC_OK;
+}
+
+int ac_encode_quantized(ac_handle* h, const float* sig, int B, int T, int K, int64_t* toks, float* qfeats, void* ws, size_t ws_bytes, void* stream) {
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (h->arch != ARCH_DAC) return fail(h, AC_EINVAL, "ac_encode_quantized: DAC handles only (others: ac_encode + ac_dequantize_ws)");
+    if (!sig || !toks || !qfeats || B < 1 || T < 1 || K < 1 || K > num_q(h)) return fail(h, AC_EINVAL, "ac_encode_quantized: bad argument");
+    return dac_encode_impl(h, sig, B, T, K, nullptr, nullptr, reinterpret_cast<long long*>(toks), qfeats, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int ac_encode_feats_latent(ac_handle* h, const float* sig, int B, int T, float* feats_latent, void* ws, size_t ws_bytes, void* stream) {
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (h->arch != ARCH_DAC) return fail(h, AC_EINVAL, "ac_encode_feats_latent: DAC handles only");
+    if (!sig || !feats_latent || B < 1 || T < 1) return fail(h, AC_EINVAL, "ac_encode_feats_latent: bad argument");
+    return dac_encode_impl(h, sig, B, T, 0, nullptr, feats_latent, nullptr, nullptr, ws, ws_bytes, (hipStream_t)stream);
 }
 
 int ac_debug_capture(ac_handle* h, float* buf_dev, size_t cap_floats) {

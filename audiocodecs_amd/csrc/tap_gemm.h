@@ -46,6 +46,9 @@ struct TapSeg {
     int reflect;        // padding rule for indices outside [0, L): 0 zero, 1 reflect, 2 replicate (PAD_*)
     int elu;            // 1: ELU(alpha=1) on load
     int kofs;           // offset of this segment inside a packed weight row
+    int pad;            // left padding in time steps: output row m, tap j, in-row step tp reads time
+    int dil;            //   t = (m + j*dil)*s + tp - pad      (causal k-tap conv: pad = (J-1)*s, dil = 1;
+                        //   DAC: symmetric pad 3*dil for the dilated k7 conv, ceil(s/2) for the strided ones)
 };
 
 struct TapGemmParams {
@@ -66,20 +69,21 @@ struct TapGemmParams {
     const float* res;
     long long res_bs, res_rs;
     int gelu;
+    // DAC: the activated flavour is Snake (x + sin^2(alpha x)/(alpha + 1e-9), per channel n % alpha_n) when
+    // `alpha` is set, ELU otherwise; `tanh_out` applies tanh to the raw output (decoder head).  A padded
+    // transposed conv writes rows that start p*cout floats before the item: y_off shifts the flat index and
+    // only indices in [0, y_len) are stored (y_len = 0: no check).
+    const float* alpha;
+    const float* alpha_inv;
+    int alpha_n;
+    int tanh_out;
+    long long y_off, y_len;
 };
 
 enum { PAD_ZERO = 0, PAD_REFLECT = 1, PAD_REPLICATE = 2 };
 
 // GELU as torch.nn.functional.gelu(approximate="none") evaluates it: 0.5 * x * (1 + erf(x / sqrt(2))).
 __device__ __forceinline__ float gelu1(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
-
-// bias-added accumulator -> layer output, in the reference's operation order: scale * x, then residual + (.)
-__device__ __forceinline__ float epilogue1(const TapGemmParams& p, float v, int n, long long res_off) {
-    if (p.gelu) v = gelu1(v);
-    if (p.scale) v = __fmul_rn(p.scale[n], v);
-    if (p.res) v = __fadd_rn(p.res[res_off], v);
-    return v;
-}
 
 // ELU(alpha=1) as torch evaluates it on CPU: x > 0 ? x : exp(x) - 1 (not expm1).  exp goes through the
 // hardware v_exp_f32 (2^x, ~1 ulp) after one multiply by log2(e): absolute error of the result
@@ -92,6 +96,31 @@ __device__ __forceinline__ f32x4 elu4(f32x4 v) {
     return v;
 }
 
+// Snake1d ([HF] dac :95-100): x + (alpha + 1e-9)^-1 * sin(alpha*x)^2; ainv is precomputed in fp32 on the host.
+__device__ __forceinline__ float snake1(float v, float a, float ainv) {
+    const float sn = sinf(__fmul_rn(a, v));
+    return __fadd_rn(v, __fmul_rn(ainv, __fmul_rn(sn, sn)));
+}
+
+// the activated flavour of an output element (what the consuming conv reads)
+__device__ __forceinline__ float act1(const TapGemmParams& p, float v, int n) {
+    if (p.alpha) {
+        const int c = n % p.alpha_n;
+        return snake1(v, p.alpha[c], p.alpha_inv[c]);
+    }
+    return elu1(v);
+}
+
+// bias-added accumulator -> layer output, in the reference's operation order: scale * x, then residual + (.)
+__device__ __forceinline__ float epilogue1(const TapGemmParams& p, float v, int n, long long res_off) {
+    if (p.gelu) v = gelu1(v);
+    if (p.scale) v = __fmul_rn(p.scale[n], v);
+    if (p.res) v = __fadd_rn(p.res[res_off], v);
+    if (p.tanh_out) v = tanhf(v);
+    return v;
+}
+
+constexpr int GEN_EXTRA = 56; // halo rows of the generic kernel's A slab: (J-1)*dil <= 6*9
 constexpr int KC = 32;        // K chunk staged per iteration
 constexpr int KCP = KC + 4;   // LDS pitch (floats): keeps 16-B alignment, spreads banks
 
@@ -112,10 +141,9 @@ __device__ __forceinline__ long long src_index(const TapSeg& sg, int i) {
 template <int WGM, int WGN, int WM, int WN, bool VEC>
 __global__ __launch_bounds__(WGM* WGN * 64) void tap_gemm_kernel(const TapGemmParams p) {
     constexpr int BM = WGM * WM * 16, BN = WGN * WN * 16, NT = WGM * WGN * 64;
-    constexpr int MAXJ = 8;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;                              // [(BM + MAXJ-1)][KCP]
-    float* Ws = smem + (BM + MAXJ - 1) * KCP;      // [BN][KCP]
+    float* As = smem;                              // [(BM + GEN_EXTRA)][KCP]
+    float* Ws = smem + (BM + GEN_EXTRA) * KCP;     // [BN][KCP]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
@@ -136,7 +164,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void tap_gemm_kernel(const TapGemmPa
     for (int si = 0; si < p.nseg; ++si) {
         const TapSeg& sg = p.seg[si];
         const int Cw = sg.s * sg.cin;
-        const int R = BM + sg.J - 1;
+        const int R = BM + (sg.J - 1) * sg.dil;
         const float* xb = sg.x + (long long)b * sg.bs;
         float alen = 3.0e38f;
         if (sg.rel_len) alen = (float)sg.L * sg.rel_len[b];
@@ -148,10 +176,10 @@ __global__ __launch_bounds__(WGM* WGN * 64) void tap_gemm_kernel(const TapGemmPa
                     const int c = c0 + 4 * q;
                     f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
                     if (c < Cw) {
-                        const int r = m0 - (sg.J - 1) + row;
+                        const int r = m0 + row;
                         const int tp = sg.cin_shift >= 0 ? (c >> sg.cin_shift) : (c / sg.cin);
                         const int ci = c - tp * sg.cin;
-                        const long long j = src_index(sg, r * sg.s + tp);
+                        const long long j = src_index(sg, r * sg.s + tp - sg.pad);
                         if (j >= 0 && (float)j < alen) {
                             v = *reinterpret_cast<const f32x4*>(xb + j * sg.ts + ci);
                             if (sg.elu) { v.x = elu1(v.x); v.y = elu1(v.y); v.z = elu1(v.z); v.w = elu1(v.w); }
@@ -165,10 +193,10 @@ __global__ __launch_bounds__(WGM* WGN * 64) void tap_gemm_kernel(const TapGemmPa
                     const int c = c0 + cc;
                     float v = 0.f;
                     if (c < Cw) {
-                        const int r = m0 - (sg.J - 1) + row;
+                        const int r = m0 + row;
                         const int tp = c / sg.cin;
                         const int ci = c - tp * sg.cin;
-                        const long long j = src_index(sg, r * sg.s + tp);
+                        const long long j = src_index(sg, r * sg.s + tp - sg.pad);
                         if (j >= 0 && (float)j < alen) {
                             v = xb[j * sg.ts + ci];
                             if (sg.elu) v = elu1(v);
@@ -203,7 +231,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void tap_gemm_kernel(const TapGemmPa
                     f32x4 af[WM], bf[WN];
 #pragma unroll
                     for (int a = 0; a < WM; ++a)
-                        af[a] = *reinterpret_cast<const f32x4*>(&As[((wm * WM + a) * 16 + li + j) * KCP + ks * 16 + 4 * kq]);
+                        af[a] = *reinterpret_cast<const f32x4*>(&As[((wm * WM + a) * 16 + li + j * sg.dil) * KCP + ks * 16 + 4 * kq]);
 #pragma unroll
                     for (int c = 0; c < WN; ++c)
                         bf[c] = *reinterpret_cast<const f32x4*>(&Ws[((wn * WN + c) * 16 + li) * KCP + ks * 16 + 4 * kq]);
@@ -231,10 +259,11 @@ __global__ __launch_bounds__(WGM* WGN * 64) void tap_gemm_kernel(const TapGemmPa
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int m = m0 + (wm * WM + a) * 16 + kq * 4 + r;
-                    if (m < p.M) {
+                    const long long fi = (long long)m * p.y_rs + n + p.y_off;     // flat index inside the item
+                    if (m < p.M && (p.y_len == 0 || (fi >= 0 && fi < p.y_len))) {
                         const float v = epilogue1(p, acc[a][c][r] + bv, n, (long long)b * p.res_bs + (long long)m * p.res_rs + n);
-                        if (p.y) p.y[yoff + (long long)m * p.y_rs + n] = v;
-                        if (p.y_elu) p.y_elu[yoff + (long long)m * p.y_rs + n] = elu1(v);
+                        if (p.y) p.y[yoff + fi] = v;
+                        if (p.y_elu) p.y_elu[yoff + fi] = act1(p, v, n);
                     }
                 }
             }
@@ -243,7 +272,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void tap_gemm_kernel(const TapGemmPa
 
 template <int WGM, int WGN, int WM, int WN>
 constexpr size_t tap_gemm_lds_bytes() {
-    return (size_t)((WGM * WM * 16 + 8 - 1) * KCP + WGN * WN * 16 * KCP) * sizeof(float);
+    return (size_t)((WGM * WM * 16 + GEN_EXTRA) * KCP + WGN * WN * 16 * KCP) * sizeof(float);
 }
 
 }  // namespace ac

@@ -105,6 +105,8 @@ __global__ __launch_bounds__(WGM* WGN * 64) void tap_gemm4_kernel(const TapGemmP
     // ---- segment state (wave-uniform)
     int si = 0, c0 = 0, j = 0;
     int seg_J, seg_Cw, seg_kofs;
+    int seg_tapoff = 0;     // dilated segments (DAC) reload the A slab per tap: byte offset of one tap step
+    bool seg_reload = false;
     bool seg_interior;      // fast loads: per-slot constant row offsets (+ a zero mask on clip-edge tiles)
     unsigned a_zero = 0;    // bit i: slot i is padding that reads as zero (edge tiles of stride-1 segments)
     __amdgpu_buffer_rsrc_t a_rs;
@@ -113,35 +115,43 @@ __global__ __launch_bounds__(WGM* WGN * 64) void tap_gemm4_kernel(const TapGemmP
         seg_J = sg.J;
         seg_Cw = sg.s * sg.cin;
         seg_kofs = sg.kofs;
-        const long long lo = (long long)(m0 - (sg.J - 1)) * sg.s;
-        const long long hi = (long long)(m0 + BM - 1) * sg.s + (sg.s - 1);
+        seg_reload = sg.dil != 1;
+        // time steps touched by the tile: t = (m + j*dil)*s + tp - pad  (tap_gemm.h TapSeg)
+        const long long lo = (long long)m0 * sg.s - sg.pad;
+        const long long hi = (long long)(m0 + BM - 1 + (sg.J - 1) * sg.dil) * sg.s + (sg.s - 1) - sg.pad;
         const bool inside = lo >= 0 && hi < sg.L;
-        // stride-1 segments: a slot's source row does not depend on the chunk, so even clip-edge tiles
-        // (reflect / zero rows, ragged tail; 2 of 6 tiles at 750 frames) keep the constant-offset loads
-        seg_interior = inside || sg.s == 1;
+        // stride-1 undilated segments: a slot's source row does not depend on the chunk, so even clip-edge
+        // tiles (reflect / zero rows, ragged tail; 2 of 6 tiles at 750 frames) keep the constant-offset loads
+        seg_interior = inside || (sg.s == 1 && !seg_reload);
         a_zero = 0;
-        const int pitch = sg.s == 1 ? (int)sg.ts : seg_Cw;   // floats between consecutive reshaped rows
+        const int tsf = sg.s == 1 ? (int)sg.ts : sg.cin;     // floats per time step
+        seg_tapoff = sg.dil * sg.s * tsf * 4;
         a_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(sg.x + (long long)b * sg.bs), 0,
                                                  (int)(((long long)(sg.L - 1) * sg.ts + sg.cin) * 4), 0x00020000);
-        const int R = BM + sg.J - 1;
+        const int R = seg_reload ? BM : BM + sg.J - 1;
 #pragma unroll
         for (int i = 0; i < A_SLOTS; ++i) {
             const int e = tid + i * NT;
             const int row = e / (KC / 4), q = e % (KC / 4);
-            int srow = m0 - (sg.J - 1) + (row < R ? row : sg.J - 1);                     // rows past R: any valid row
-            if (!inside && sg.s == 1) {
-                const long long jj = row < R ? src_index(sg, srow) : 0;                   // [HF]:139-162 reflect / zero rule
-                if (jj < 0) a_zero |= 1u << i;
-                srow = jj < 0 ? 0 : (int)jj;
+            long long t = (long long)(m0 + (row < R ? row : 0)) * sg.s - sg.pad;          // rows past R: any valid row
+            if (!inside) {
+                if (sg.s == 1 && !seg_reload) {
+                    const long long jj = row < R ? src_index(sg, (int)t) : 0;             // [HF]:139-162 reflect / zero rule
+                    if (jj < 0) a_zero |= 1u << i;
+                    t = jj < 0 ? 0 : jj;
+                } else {
+                    t = 0;                                                                // unused: slow path
+                }
             }
-            a_boff[i] = (srow * pitch + 4 * q) * 4;
+            a_boff[i] = (int)((t * tsf + 4 * q) * 4);
         }
     };
     f32x4 ra[A_SLOTS], rw[W_SLOTS];
-    auto load_a = [&](int s_, int c_) {
+    auto load_a = [&](int s_, int c_, int j_) {
         if (seg_interior) {
+            const int soff = c_ * 4 + (seg_reload ? j_ * seg_tapoff : 0);
 #pragma unroll
-            for (int i = 0; i < A_SLOTS; ++i) ra[i] = bufload16(a_rs, a_boff[i], c_ * 4);
+            for (int i = 0; i < A_SLOTS; ++i) ra[i] = bufload16(a_rs, a_boff[i], soff);
             if (a_zero) {
 #pragma unroll
                 for (int i = 0; i < A_SLOTS; ++i)
@@ -150,7 +160,8 @@ __global__ __launch_bounds__(WGM* WGN * 64) void tap_gemm4_kernel(const TapGemmP
         } else {
             // exact edge handling ([HF]:139-162 reflect rule, zero pad of the transposed conv, ragged tail)
             const TapSeg& sg = p.seg[s_];
-            const int R = BM + sg.J - 1;
+            const int R = seg_reload ? BM : BM + sg.J - 1;
+            const int jr = seg_reload ? j_ * sg.dil : 0;
             const float* xb = sg.x + (long long)b * sg.bs;
 #pragma unroll
             for (int i = 0; i < A_SLOTS; ++i) {
@@ -158,7 +169,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void tap_gemm4_kernel(const TapGemmP
                 const int row = e / (KC / 4), q = e % (KC / 4);
                 const int c = c_ + 4 * q;
                 const int tp = sg.cin_shift >= 0 ? (c >> sg.cin_shift) : (c / sg.cin);
-                const long long jj = row < R ? src_index(sg, (m0 - (sg.J - 1) + row) * sg.s + tp) : -1;
+                const long long jj = row < R ? src_index(sg, (m0 + row + jr) * sg.s + tp - sg.pad) : -1;
                 ra[i] = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (jj >= 0) ra[i] = *reinterpret_cast<const f32x4*>(xb + jj * sg.ts + (c - tp * sg.cin));
             }
@@ -182,7 +193,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void tap_gemm4_kernel(const TapGemmP
 
     // ---- prologue: stage 0 into buffers 0
     enter_segment(0);
-    load_a(0, 0);
+    load_a(0, 0, 0);
     load_w(0, 0);
     store_a(As0);
     store_w(Ws0);
@@ -202,11 +213,12 @@ __global__ __launch_bounds__(WGM* WGN * 64) void tap_gemm4_kernel(const TapGemmP
             if (nc0 >= seg_Cw) { nc0 = 0; nsi = si + 1; }
         }
         const bool has_next = nsi < p.nseg;
-        const int cur_j = j;
+        const int cur_j = seg_reload ? 0 : j;      // a reloaded slab already starts at the tap's first row
         TRC4(trc_stage, 0);
         if (has_next) {
             if (nsi != si) enter_segment(nsi);
-            if (new_chunk) load_a(nsi, nc0);
+            new_chunk = new_chunk || seg_reload;
+            if (new_chunk) load_a(nsi, nc0, nj);
             load_w(nc0, nj);
         }
         TRC4(trc_stage, 1);
@@ -267,11 +279,12 @@ __global__ __launch_bounds__(WGM* WGN * 64) void tap_gemm4_kernel(const TapGemmP
         }
     __syncthreads();
     const long long yoff = (long long)b * p.y_bs;
-    const bool post = p.gelu || p.scale || p.res;
+    const bool post = p.gelu || p.scale || p.res || p.tanh_out;
     for (int e = tid; e < BM * (BN / 4); e += NT) {
         const int row = e / (BN / 4), q = e % (BN / 4);
         const int m = m0 + row, n = n0 + 4 * q;
-        if (m < p.M && n < p.N) {
+        const long long fi = (long long)m * p.y_rs + n + p.y_off;      // flat index inside the item
+        if (m < p.M && n < p.N && (p.y_len == 0 || (fi >= 0 && fi < p.y_len))) {
             f32x4 v = *reinterpret_cast<const f32x4*>(&Cs[row * CP + 4 * q]);
             if (post) {
                 if (p.gelu) { v.x = gelu1(v.x); v.y = gelu1(v.y); v.z = gelu1(v.z); v.w = gelu1(v.w); }
@@ -283,10 +296,21 @@ __global__ __launch_bounds__(WGM* WGN * 64) void tap_gemm4_kernel(const TapGemmP
                     const f32x4 rv = *reinterpret_cast<const f32x4*>(p.res + (long long)b * p.res_bs + (long long)m * p.res_rs + n);
                     v.x = __fadd_rn(rv.x, v.x); v.y = __fadd_rn(rv.y, v.y); v.z = __fadd_rn(rv.z, v.z); v.w = __fadd_rn(rv.w, v.w);
                 }
+                if (p.tanh_out) { v.x = tanhf(v.x); v.y = tanhf(v.y); v.z = tanhf(v.z); v.w = tanhf(v.w); }
             }
-            const long long o = yoff + (long long)m * p.y_rs + n;
+            const long long o = yoff + fi;
             if (p.y) *reinterpret_cast<f32x4*>(p.y + o) = v;
-            if (p.y_elu) *reinterpret_cast<f32x4*>(p.y_elu + o) = elu4(v);
+            if (p.y_elu) {
+                f32x4 w;
+                if (p.alpha) {
+                    const int c = n % p.alpha_n;
+                    const f32x4 al = *reinterpret_cast<const f32x4*>(p.alpha + c), ai = *reinterpret_cast<const f32x4*>(p.alpha_inv + c);
+                    w.x = snake1(v.x, al.x, ai.x); w.y = snake1(v.y, al.y, ai.y); w.z = snake1(v.z, al.z, ai.z); w.w = snake1(v.w, al.w, ai.w);
+                } else {
+                    w = elu4(v);
+                }
+                *reinterpret_cast<f32x4*>(p.y_elu + o) = w;
+            }
         }
     }
 }

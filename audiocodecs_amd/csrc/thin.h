@@ -22,6 +22,10 @@ struct ThinParams {
     int B, T, F, k;
     int Lp;                // reflect base length: T if T > k-1 else k ([HF]:148-155)
     int pad;               // PAD_REFLECT (EnCodec) or PAD_ZERO (Mimi: pad_mode "constant", [HF] mimi :336-338)
+    int padl;              // left padding in samples: k-1 (causal) or (k-1)/2 (DAC, symmetric zero padding)
+    const float* alpha;    // stem: Snake parameters of the consumer -> y_elu = snake(y) instead of ELU(y) (DAC)
+    const float* alpha_inv;
+    int tanh_out;          // head: tanh on the output (DAC decoder, [HF] dac :439-440)
 };
 
 __device__ __forceinline__ int reflect_src(int i, int T, int Lp, int pad) {
@@ -33,7 +37,7 @@ __device__ __forceinline__ int reflect_src(int i, int T, int Lp, int pad) {
 constexpr int STEM_TT = 2048;   // time steps per workgroup
 constexpr int THIN_MAXK = 8;
 
-// F must be a multiple of 4 (<= 64): thread = (time step, 4 channels); k <= 8.
+// F must be a multiple of 4 (<= 128): thread = (time step, 4 channels); k <= 8.
 __global__ __launch_bounds__(256) void stem_kernel(const ThinParams p) {
     __shared__ float xs[STEM_TT + THIN_MAXK];
     const int b = blockIdx.y, t0 = blockIdx.x * STEM_TT, tid = threadIdx.x;
@@ -42,7 +46,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const ThinParams p) {
     if (p.rel_len) alen = (float)p.T * p.rel_len[b];
     const int pad = p.k - 1;
     for (int e = tid; e < STEM_TT + pad; e += 256) {
-        const int j = reflect_src(t0 - pad + e, p.T, p.Lp, p.pad);
+        const int j = reflect_src(t0 - p.padl + e, p.T, p.Lp, p.pad);
         xs[e] = (j >= 0 && (float)j < alen) ? xb[j] : 0.f;
     }
     const int cq = p.F / 4;                 // float4 groups per time step
@@ -71,13 +75,22 @@ __global__ __launch_bounds__(256) void stem_kernel(const ThinParams p) {
         }
         const long long o = ob + (long long)t * p.F + c4;
         if (p.y) *reinterpret_cast<f32x4*>(p.y + o) = acc;
-        if (p.y_elu) *reinterpret_cast<f32x4*>(p.y_elu + o) = elu4(acc);
+        if (p.y_elu) {
+            f32x4 w;
+            if (p.alpha) {
+                const f32x4 al = *reinterpret_cast<const f32x4*>(p.alpha + c4), ai = *reinterpret_cast<const f32x4*>(p.alpha_inv + c4);
+                w.x = snake1(acc.x, al.x, ai.x); w.y = snake1(acc.y, al.y, ai.y); w.z = snake1(acc.z, al.z, ai.z); w.w = snake1(acc.w, al.w, ai.w);
+            } else {
+                w = elu4(acc);
+            }
+            *reinterpret_cast<f32x4*>(p.y_elu + o) = w;
+        }
     }
 }
 
 constexpr int HEAD_TT = 256;    // outputs per workgroup (one per thread)
 
-// F multiple of 4, F <= 64, k <= 8.  LDS: (HEAD_TT + k - 1) rows of F (+4 pad) floats + the weights.
+// F multiple of 4, F <= 128, k <= 8.  LDS: (HEAD_TT + k - 1) rows of F (+4 pad) floats + the weights.
 __global__ __launch_bounds__(256) void head_kernel(const ThinParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int F = p.F, FP = F + 4;
@@ -88,7 +101,7 @@ __global__ __launch_bounds__(256) void head_kernel(const ThinParams p) {
     const float* xb = p.x + (long long)b * p.T * F;
     for (int e = tid; e < (HEAD_TT + pad) * fq; e += 256) {
         const int row = e / fq, q = e % fq;
-        const int j = reflect_src(t0 - pad + row, p.T, p.Lp, p.pad);
+        const int j = reflect_src(t0 - p.padl + row, p.T, p.Lp, p.pad);
         f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
         if (j >= 0) v = *reinterpret_cast<const f32x4*>(xb + (long long)j * F + 4 * q);
         *reinterpret_cast<f32x4*>(&xs[row * FP + 4 * q]) = v;
@@ -108,7 +121,7 @@ __global__ __launch_bounds__(256) void head_kernel(const ThinParams p) {
             acc = fmaf(wv.z, xv.z, acc); acc = fmaf(wv.w, xv.w, acc);
         }
     }
-    p.y[(long long)b * p.T + t] = acc;
+    p.y[(long long)b * p.T + t] = p.tanh_out ? tanhf(acc) : acc;
 }
 
 // Polyphase windowed-sinc sample-rate conversion: what torchaudio.functional.resample applies at the

@@ -99,6 +99,30 @@ typedef struct ac_mimi_config {
     float norm_eps;                    /* 1e-5                                                  */
 } ac_mimi_config;
 
+/* DAC (BASELINE.json configs[2]).  The reference wrapper (audiocodecs/dac.py:28-130) calls
+ * `dac.DAC` of descript-audio-codec 1.0.0, which is NOT on disk: parity with it is unpinned; this path is
+ * pinned to the same-architecture transformers.DacModel (field names below are DacConfig's).  Replaces
+ *     dac.py:96-99    self.model.encode(sig[:, None], n_quantizers=K)            -> ac_encode / ac_encode_quantized
+ *     dac.py:105-111  self.model.encoder(...), quantizers[0].in_proj(...)          -> ac_encode_feats / ac_encode_feats_latent
+ *     dac.py:126-129  self.model.quantizer.from_codes(...), self.model.decode(...) -> ac_decode (ac_dequantize_ws)
+ *     dac.py:63-90    codebooks / out_proj(codebooks)                              -> ac_embs / ac_embs_projected */
+#define AC_MAX_DILATIONS 4
+typedef struct ac_dac_config {
+    int32_t struct_size;               /* = sizeof(ac_dac_config)                               */
+    int32_t sampling_rate;             /* 44100                                                 */
+    int32_t encoder_hidden_size;       /* 64                                                    */
+    int32_t decoder_hidden_size;       /* 1536                                                  */
+    int32_t num_ratios;                /* 4                                                     */
+    int32_t downsampling_ratios[AC_MAX_RATIOS]; /* 2,4,8,8                                      */
+    int32_t upsampling_ratios[AC_MAX_RATIOS];   /* 8,8,4,2                                      */
+    int32_t n_codebooks;               /* 9                                                     */
+    int32_t codebook_size;             /* 1024                                                  */
+    int32_t codebook_dim;              /* 8 (the only supported value)                          */
+    int32_t num_dilations;             /* 3 residual units per block ...                        */
+    int32_t dilations[AC_MAX_DILATIONS]; /* ... with dilations 1,3,9                            */
+    int32_t device;
+} ac_dac_config;
+
 /* Library/ABI version: major*10000 + minor*100 + patch. */
 int ac_version(void);
 
@@ -107,6 +131,11 @@ int ac_create(const ac_config* cfg, ac_handle** out);
 
 /* Same, for a Mimi handle.  Every other entry point below works on either kind of handle. */
 int ac_mimi_create(const ac_mimi_config* cfg, ac_handle** out);
+
+/* Same, for a DAC handle (keys of DacModel.state_dict(): "encoder.conv1.weight", "encoder.block.{i}.
+ * res_unit{u}.{snake1.alpha,conv1.weight,...}", "decoder.block.{i}.conv_t1.weight", "quantizer.quantizers.{k}.
+ * {in_proj,out_proj}.{weight,bias}", "...codebook.weight"; weights plain, i.e. weight-norm already folded). */
+int ac_dac_create(const ac_dac_config* cfg, ac_handle** out);
 
 /* Hand one fp32 tensor to the handle (copied).  `name` uses the HF state-dict keys of
  * EncodecModel with weight-norm either
@@ -133,6 +162,10 @@ int ac_finalize(ac_handle* h);
 
 /* Frames produced for T samples: ceil at every strided conv (T=1..320 -> 1, 321 -> 2, ...). */
 int ac_num_frames(const ac_handle* h, int T);
+/* Samples ac_decode writes per clip for N frames: N*hop, except DAC (symmetric padding):
+ * each transposed conv gives (L-1)*s - 2*ceil(s/2) + 2s.  DAC's ac_num_frames follows the strided convs
+ * floor((L + 2*ceil(s/2) - 2s)/s) + 1 and is 0 when the input is too short (upstream's conv1d raises). */
+long long ac_num_samples(const ac_handle* h, int N);
 /* Hop length (product of ratios, 320; Mimi: x resample_stride = 1920), latent width of feats/qfeats
  * (128; Mimi 512) and codebook vector width (EnCodec: == hidden; Mimi 256). */
 int ac_hop_length(const ac_handle* h);
@@ -161,6 +194,15 @@ int ac_encode_feats(ac_handle* h, const float* sig_dev, const float* rel_len_dev
  * The output is not trimmed to the encoder's input length (encodec.py:139-140). */
 int ac_decode(ac_handle* h, const int64_t* toks_dev, int B, int N, int K, float* sig_dev,
               void* workspace_dev, size_t workspace_bytes, void* stream);
+
+/* DAC only.  ac_encode_quantized: ac_encode that also returns the quantised representation
+ * qfeats_dev [B,N,H] `model.encode` yields (dac.py:117-119; not bit-identical to from_codes: the
+ * straight-through form rounds).  ac_encode_feats_latent: quantizers[0].in_proj(encoder(sig)) -> [B,N,8]
+ * (dac.py:104-108, `latent=True`). */
+int ac_encode_quantized(ac_handle* h, const float* sig_dev, int B, int T, int K, int64_t* toks_dev, float* qfeats_dev,
+                        void* workspace_dev, size_t workspace_bytes, void* stream);
+int ac_encode_feats_latent(ac_handle* h, const float* sig_dev, int B, int T, float* feats_latent_dev,
+                           void* workspace_dev, size_t workspace_bytes, void* stream);
 
 /* RVQ only.  ac_quantize: feats_dev [B,N,H] -> toks_dev [B,N,K] ([HF]:424-438).
  * ac_dequantize: toks_dev [B,N,K] -> qfeats_dev [B,N,H] = sum_k E_k[tok]  ([HF]:440-447). */

@@ -34,7 +34,9 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layout_matches_header():
     native = _built()
     assert C.sizeof(native.AcConfig) == 4 * (5 + 8 + 8)
-    assert C.sizeof(native.AcKernelStat) == 48 + 4 + 4 + 8 + 8
+    assert C.sizeof(native.AcKernelStat) == 96 + 4 + 4 + 8 + 8
+    assert C.sizeof(native.AcMimiConfig) == 4 * (5 + 8 + 4 + 4 + 7 + 2)
+    assert C.sizeof(native.AcDacConfig) == 4 * (5 + 8 + 8 + 4 + 4 + 1)
 
 
 def test_create_rejects_bad_config_without_gpu():
@@ -44,4 +46,6 @@ def test_create_rejects_bad_config_without_gpu():
     h = C.c_void_p()
     assert L.ac_create(C.byref(cfg), C.byref(h)) == -1  # struct_size == 0 -> AC_EINVAL
     assert L.ac_create(None, C.byref(h)) == -1
+    assert L.ac_mimi_create(C.byref(native.AcMimiConfig()), C.byref(h)) == -1
+    assert L.ac_dac_create(C.byref(native.AcDacConfig()), C.byref(h)) == -1
     assert L.ac_last_error(None) == b"null handle"
