@@ -519,6 +519,7 @@ int run_tap(ac_handle* h, hipStream_t st, TapGemmParams& p) {
     if (p.N <= 16) TAP_CASE(4, 1, 2, 1);
     else if (p.N <= 32) TAP_CASE(4, 1, 2, 2);
     else if (p.N <= 64) TAP_CASE(2, 2, 2, 2);
+    else if (p.N % 96 == 0 && p.N % 128 != 0) TAP_CASE(2, 2, 4, 3);   // DAC widths 96 / 192: 128-column tiles would idle a quarter of the MFMAs
     else TAP_CASE(2, 2, 4, 4);
 #undef TAP_CASE
     if (rc) return rc;

@@ -59,6 +59,32 @@ def cpu_baseline_mimi(cfg, sd, sig_cpu, clips=8):
     }
 
 
+def cpu_baseline_dac(cfg, sd, sig_cpu, clips=2):
+    """Same protocol with the DAC oracle (oracle/dac_oracle.py); 2 clips: DAC is ~100 GMAC per audio-second."""
+    from oracle import dac_oracle as O  # checker/baseline only -- never on the product path
+
+    W = O.cast_weights(sd)
+    x = sig_cpu[:clips]
+    ncpu = os.cpu_count() or 2
+    cands = sorted({t for t in (32, 64, ncpu // 2) if 1 <= t <= ncpu}) or [ncpu]
+    best, best_t = None, None
+    with torch.inference_mode():
+        for t in cands:
+            torch.set_num_threads(t)
+            O.toks_to_sig(cfg, W, O.sig_to_toks(cfg, W, x[:1, :44100], None, 9))
+            t0 = time.perf_counter()
+            O.toks_to_sig(cfg, W, O.sig_to_toks(cfg, W, x, None, 9))
+            dt = time.perf_counter() - t0
+            if best is None or dt < best:
+                best, best_t = dt, t
+    audio_s = x.shape[0] * x.shape[1] / cfg.sampling_rate
+    return {
+        "value": round(audio_s / best, 2), "unit": "audio-s/s", "cores": best_t, "kind": "port",
+        "sample": f"{clips} clips x {x.shape[1] / cfg.sampling_rate:.0f} s of the same batch, fp32 torch-CPU DAC oracle; "
+                  f"best of thread counts {cands} (one timed run each after a warm-up)",
+    }
+
+
 def cpu_baseline(cfg, sd, sig_cpu, clips=8):
     """Oracle (kind 'port': torch-CPU restatement of the reference, oracle/encodec_oracle.py) on the
     host cores.  torch's CPU convs do not scale to every core of a 2-socket host on 8 clips, so a
@@ -97,7 +123,7 @@ def measured_traffic(kernel_name, unit, codec="encodec"):
     run the profiler on itself, so the newest profiles/r*_traffic.json is quoted; null if absent."""
     import glob
 
-    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")) if ("mimi" in os.path.basename(f)) == (codec == "mimi"))
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")) if (codec in os.path.basename(f)) or (codec == "encodec" and not any(c in os.path.basename(f) for c in ("mimi", "dac"))))
     if not files:
         return None
     try:
@@ -113,8 +139,9 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="clips per GPU")
-    ap.add_argument("--codec", choices=["encodec", "mimi"], default="encodec",
-                    help="encodec = BASELINE.json configs[1] (the contract's default); mimi = configs[3] shape (SURVEY.md §8 f3)")
+    ap.add_argument("--codec", choices=["encodec", "mimi", "dac"], default="encodec",
+                    help="encodec = BASELINE.json configs[1] (the contract's default); mimi = configs[3] shape (SURVEY.md §8 f3); "
+                         "dac = configs[2] (DAC 44.1 kHz, 9 codebooks; use --batch 256)")
     ap.add_argument("--seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -133,17 +160,21 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    from audiocodecs_amd import Encodec, Mimi, checkpoint, prng
-    from audiocodecs_amd.config import ENCODEC_24KHZ, MIMI_24KHZ
+    from audiocodecs_amd import DAC, Encodec, Mimi, checkpoint, prng
+    from audiocodecs_amd.config import DAC_44KHZ, ENCODEC_24KHZ, MIMI_24KHZ
     from audiocodecs_amd.sharding import gather_tokens
 
-    mimi = args.codec == "mimi"
-    cfg = MIMI_24KHZ if mimi else ENCODEC_24KHZ
-    label = "Mimi-24k" if mimi else "EnCodec-24k"
+    mimi = args.codec != "encodec"   # "not the headline codec": whole-path fractions from the kernels' own counts
+    cfg = {"mimi": MIMI_24KHZ, "dac": DAC_44KHZ, "encodec": ENCODEC_24KHZ}[args.codec]
+    label = {"mimi": "Mimi-24k", "dac": "DAC-44.1k", "encodec": "EnCodec-24k"}[args.codec]
+    ncb = 9 if args.codec == "dac" else 8
     B, T = args.batch, int(round(args.seconds * cfg.sampling_rate))
-    if mimi:
+    if args.codec == "mimi":
         sd = checkpoint.synthetic_mimi_state_dict(cfg, seed=0)
         codec = Mimi(cfg.sampling_rate, num_codebooks=8, state_dict=sd).eval()
+    elif args.codec == "dac":
+        sd = checkpoint.synthetic_dac_state_dict(cfg, seed=0)
+        codec = DAC(cfg.sampling_rate, cfg.sampling_rate, num_codebooks=9, state_dict=sd, config=cfg).eval()
     else:
         sd = checkpoint.synthetic_state_dict(cfg, seed=0)
         codec = Encodec(cfg.sampling_rate, num_codebooks=8, state_dict=sd).eval()
@@ -202,7 +233,7 @@ def main():
         roof["avg_launch_us"] = round(avg_us, 2)
         roof["share_of_step"] = round(tot_ms / (dt * 1e3), 4)
         out = {
-            "metric": f"encode+decode audio-sec/s, {label} 8cb",
+            "metric": f"encode+decode audio-sec/s, {label} {ncb}cb",
             "value": round(audio_s / dt, 1),
             "unit": "audio-s/s",
             "n_gpus": world,
@@ -214,7 +245,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": f"synthetic (0.1*N(0,1) clips, seeded synthetic weights of the {label} architecture)",
-            "config": {"workload": f"{label} 8 codebooks, encode+decode, {B} clips x {args.seconds:g} s per GPU, resident in HBM",
+            "config": {"workload": f"{label} {ncb} codebooks, encode+decode, {B} clips x {args.seconds:g} s per GPU, resident in HBM",
                        "clips_per_gpu": B, "seconds_per_clip": args.seconds, "parallelism": f"clip-sharded x{world}"},
             "rtf": round(dt / audio_s, 7),
             "x_realtime_per_gpu": round(audio_s / dt / world, 1),
@@ -232,7 +263,7 @@ def main():
             ],
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = (cpu_baseline_mimi if mimi else cpu_baseline)(cfg, sd, sig_cpu)
+            out["cpu_baseline"] = {"mimi": cpu_baseline_mimi, "dac": cpu_baseline_dac, "encodec": cpu_baseline}[args.codec](cfg, sd, sig_cpu)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
