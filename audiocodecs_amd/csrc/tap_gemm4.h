@@ -152,11 +152,8 @@ __global__ __launch_bounds__(WGM* WGN * 64) void tap_gemm4_kernel(const TapGemmP
             const int soff = c_ * 4 + (seg_reload ? j_ * seg_tapoff : 0);
 #pragma unroll
             for (int i = 0; i < A_SLOTS; ++i) ra[i] = bufload16(a_rs, a_boff[i], soff);
-            if (a_zero) {
-#pragma unroll
-                for (int i = 0; i < A_SLOTS; ++i)
-                    if (a_zero & (1u << i)) ra[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
+            // padding slots (a_zero) are cleared in store_a, after the MFMA phase: masking here would wait for
+            // the loads right after issuing them (every chunk of a clip-edge tile; 2 of 6 tiles at 750 frames)
         } else {
             // exact edge handling ([HF]:139-162 reflect rule, zero pad of the transposed conv, ragged tail)
             const TapSeg& sg = p.seg[s_];
@@ -183,7 +180,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void tap_gemm4_kernel(const TapGemmP
     auto store_a = [&](float* dst) {
 #pragma unroll
         for (int i = 0; i < A_SLOTS; ++i)
-            if (a_lds[i] >= 0) *reinterpret_cast<f32x4*>(&dst[a_lds[i]]) = ra[i];
+            if (a_lds[i] >= 0) *reinterpret_cast<f32x4*>(&dst[a_lds[i]]) = (a_zero & (1u << i)) ? f32x4{0.f, 0.f, 0.f, 0.f} : ra[i];
     };
     auto store_w = [&](float* dst) {
 #pragma unroll
