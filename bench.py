@@ -117,13 +117,20 @@ def cpu_baseline(cfg, sd, sig_cpu, clips=8):
     }
 
 
-def measured_traffic(kernel_name, unit, codec="encodec"):
+def measured_traffic(kernel_name, unit, codec="encodec", batch=64):
     """HBM bytes per launch of `kernel_name` from the committed PMC summary (rocprofv3 --pmc FETCH_SIZE /
     WRITE_SIZE in separate passes, gfx950 FETCH x2 correction: tools/collect_traffic.py).  bench.py cannot
     run the profiler on itself, so the newest profiles/r*_traffic.json is quoted; null if absent."""
     import glob
 
     files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")) if (codec in os.path.basename(f)) or (codec == "encodec" and not any(c in os.path.basename(f) for c in ("mimi", "dac"))))
+    import re
+
+    def batch_ok(f):   # r1_mimi_b32_traffic.json was collected at 32 clips per GPU; no tag = the default 64
+        m = re.search(r"_b(\d+)_", os.path.basename(f))
+        return (int(m.group(1)) if m else 64) == batch
+
+    files = [f for f in files if batch_ok(f)]
     if not files:
         return None
     try:
@@ -227,7 +234,7 @@ def main():
         else:
             roof = {"bound": "hbm", "achieved": round(nbytes / (tot_ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s"}
         roof["frac"] = round(roof["achieved"] / roof["peak"], 4)
-        roof["traffic"] = measured_traffic(name, roof["unit"], args.codec)
+        roof["traffic"] = measured_traffic(name, roof["unit"], args.codec, B)
         roof["kernel"] = name
         roof["launches_per_step"] = launches / args.steps
         roof["avg_launch_us"] = round(avg_us, 2)
