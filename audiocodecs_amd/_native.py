@@ -133,6 +133,7 @@ EXPORTS = {
     "ac_profile_end": (_i, [_vp, C.POINTER(AcKernelStat), _i]),
     "ac_debug_capture": (_i, [_vp, _vp, _sz]),
     "ac_debug_captured": (_sz, [_vp]),
+    "ac_lstm_status": (_i, [_vp]),
     "ac_last_error": (C.c_char_p, [_vp]),
     "ac_destroy": (None, [_vp]),
 }

@@ -14,6 +14,7 @@
 
 #include "../../include/audiocodecs_amd.h"
 #include "lstm.h"
+#include "lstm_persist.h"
 #include "rvq.h"
 #include "tap_gemm.h"
 #include "tap_gemm4.h"
@@ -48,6 +49,8 @@ struct LstmPlan {
     std::vector<PackedGemm> ih;     // [4D][D] + (b_ih + b_hh)
     std::vector<size_t> hh_off;     // W_hh per layer, MFMA B-fragment order
     std::vector<size_t> ihpk_off;   // W_ih per layer, same order (used by the in-step projection of layers >= 1)
+    size_t persist_off = 0;         // register images of W_hh0, W_ih1, W_hh1 for lstm_persist_kernel (D = 512, 2 layers)
+    bool has_persist = false;
 };
 
 struct MimiTfLayer {
@@ -130,6 +133,10 @@ struct ac_handle {
     size_t dbg_cap = 0, dbg_used = 0;
     // kernels that already got their > 64 KB dynamic-LDS opt-in on this handle's device
     std::vector<const void*> lds_opted;
+    // persistent LSTM (lstm_persist.h): control words, device shape, opt-out (AC_LSTM=step)
+    unsigned* lp_ctl = nullptr;
+    int num_cus = 0;
+    bool lstm_step_only = false;
     // profiling
     bool prof = false;
     bool prof_detail = false;   // AC_PROF_DETAIL=1: one record per tap-GEMM shape
@@ -374,6 +381,23 @@ struct Packer {
                             blob[off2 + (((size_t)ug * (D / 16) + ks) * 64 + lane) * 4 + u] = (*wih)[(size_t)row * D + k];
                         }
             lp.ihpk_off.push_back(off2);
+        }
+        if (D == LP_D && layers == 2) {
+            // lstm_persist_kernel: [hh0, ih1, hh1][32 unit slices][4 waves = K quarters][4 gates][8 k-steps][64 lanes][4]
+            const std::vector<float>* mats[3] = {get(prefix + ".weight_hh_l0", (size_t)4 * D * D), get(prefix + ".weight_ih_l1", (size_t)4 * D * D),
+                                                 get(prefix + ".weight_hh_l1", (size_t)4 * D * D)};
+            const size_t mat = (size_t)LP_SLICES * 4 * 4 * 8 * 256;
+            lp.persist_off = reserve(3 * mat);
+            for (int m = 0; m < 3; ++m)
+                for (int idx = 0; idx < LP_SLICES; ++idx)
+                    for (int w = 0; w < 4; ++w)
+                        for (int n = 0; n < 4; ++n)
+                            for (int ks = 0; ks < 8; ++ks)
+                                for (int lane = 0; lane < 64; ++lane)
+                                    for (int e = 0; e < 4; ++e)
+                                        blob[lp.persist_off + m * mat + ((((size_t)idx * 4 + w) * 4 + n) * 8 + ks) * 256 + lane * 4 + e] =
+                                            (*mats[m])[(size_t)(n * D + idx * 16 + (lane & 15)) * D + (w * 8 + ks) * 16 + 4 * (lane >> 4) + e];
+            lp.has_persist = true;
         }
         return true;
     }
@@ -750,6 +774,38 @@ int lstm_fwd(ac_handle* h, hipStream_t st, const LstmPlan& lp, const Act& x, con
     }
     const int nroles = 2 * L - 1, nlaunch = T + 2 * (L - 1);
     const long long BD = (long long)((B + 31) / 32 * 32) * D, B4D = (long long)B * 4 * D;   // h lives in A-fragment tiles of 16 clips
+    if (lp.has_persist && h->lp_ctl && h->num_cus == 256 && !h->lstm_step_only && x.ts == D) {
+        // one cooperative launch per 64 clips walks all T steps (lstm_persist.h)
+        const int chunks = cdiv(B, 64);
+        ProfScope ps(h, st, "lstm_persist_kernel", 2.0 * T * (double)B * 4 * D * D * nroles,
+                     (double)T * ((double)B * 4 * D * 4 + 3.0 * B * D * 4) + 12.0 * D * D * 4, chunks);
+        for (int c0 = 0; c0 < B; c0 += 64) {
+            LstmPersistParams q{};
+            q.gin0 = ws.gin;
+            q.w_pk = h->blob + lp.persist_off;
+            q.bias1 = h->blob + lp.ih[1].b_off;
+            q.hseq0 = ws.hseq0;
+            q.hseq1 = ws.hseq1;
+            q.skip = x.p;
+            q.yout = out.raw;
+            q.yout_elu = out.elu;
+            q.ctl = h->lp_ctl;
+            q.gin_ts = B4D;
+            q.h_ts = BD;
+            q.skip_bs = x.bs;
+            q.y_bs = (long long)T * D;
+            q.B = std::min(64, B - c0);
+            q.T = T;
+            q.group0 = c0 / 16;
+            q.clip0 = c0;
+            HIPCHK(h, hipMemsetAsync(h->lp_ctl, 0, LP_CTL_WORDS * sizeof(unsigned), st));
+            void* args[] = {&q};
+            HIPCHK(h, hipLaunchCooperativeKernel(reinterpret_cast<const void*>(lstm_persist_kernel), dim3(256), dim3(256), args, 0, st));
+        }
+        y->raw = Act{out.raw, (long long)T * D, D, T, D};
+        y->elu = Act{out.elu, (long long)T * D, D, T, D};
+        return AC_OK;
+    }
     {
         ProfScope ps(h, st, "lstm_step_kernel", 2.0 * T * (double)B * 4 * D * D * nroles,
                      (double)T * nroles * ((double)B * 4 * D * 4 + 4.0 * D * D * 4 + 2.0 * B * D * 4), nlaunch);
@@ -1144,6 +1200,11 @@ static int upload_blob(ac_handle* h, Packer& pk, int device) {
     HIPCHK(h, hipGetDeviceProperties(&prop, device));
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(h, AC_ENODEV, "device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
+    h->num_cus = prop.multiProcessorCount;
+    const char* lm = std::getenv("AC_LSTM");
+    h->lstm_step_only = lm && std::strcmp(lm, "step") == 0;
+    HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&h->lp_ctl), LP_CTL_WORDS * sizeof(unsigned)));
+    HIPCHK(h, hipMemset(h->lp_ctl, 0, LP_CTL_WORDS * sizeof(unsigned)));
     h->blob_floats = pk.blob.size();
     HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&h->blob), h->blob_floats * sizeof(float)));
     HIPCHK(h, hipMemcpy(h->blob, pk.blob.data(), h->blob_floats * sizeof(float), hipMemcpyHostToDevice));
@@ -1456,6 +1517,15 @@ int ac_encode_feats_latent(ac_handle* h, const float* sig, int B, int T, float* 
     return dac_encode_impl(h, sig, B, T, 0, nullptr, feats_latent, nullptr, nullptr, ws, ws_bytes, (hipStream_t)stream);
 }
 
+int ac_lstm_status(ac_handle* h) {
+    if (!h) return AC_EINVAL;
+    if (!h->lp_ctl) return 0;
+    unsigned tmo = 0;
+    if (hipMemcpy(&tmo, h->lp_ctl + LP_CTL_TIMEOUT, sizeof tmo, hipMemcpyDeviceToHost) != hipSuccess) return AC_EHIP;
+    const bool usable = (h->arch == ARCH_ENCODEC) && h->enc_lstm.has_persist && h->num_cus == 256 && !h->lstm_step_only;
+    return tmo ? AC_EHIP : (usable ? 1 : 0);
+}
+
 int ac_debug_capture(ac_handle* h, float* buf_dev, size_t cap_floats) {
     if (!h) return AC_EINVAL;
     h->dbg = buf_dev;
@@ -1513,6 +1583,7 @@ const char* ac_last_error(const ac_handle* h) { return h ? h->err.c_str() : "nul
 void ac_destroy(ac_handle* h) {
     if (!h) return;
     if (h->blob) (void)hipFree(h->blob);
+    if (h->lp_ctl) (void)hipFree(h->lp_ctl);
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
     delete h;
 }

@@ -252,6 +252,11 @@ int ac_profile_end(ac_handle* h, ac_kernel_stat* out, int cap);
 int ac_debug_capture(ac_handle* h, float* buf_dev, size_t cap_floats);
 size_t ac_debug_captured(const ac_handle* h);
 
+/* Which LSTM path the handle uses (synchronising; tests / diagnostics): 1 = the persistent single-launch kernel
+ * (D = 512, 2 layers, 256-CU device; opt out with the environment variable AC_LSTM=step), 0 = one launch per
+ * time step, AC_EHIP = the persistent kernel's bounded waits timed out in the last call (results invalid). */
+int ac_lstm_status(ac_handle* h);
+
 const char* ac_last_error(const ac_handle* h);
 void ac_destroy(ac_handle* h);
 
