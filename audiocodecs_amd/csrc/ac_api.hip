@@ -798,6 +798,8 @@ int lstm_fwd(ac_handle* h, hipStream_t st, const LstmPlan& lp, const Act& x, con
             q.T = T;
             q.group0 = c0 / 16;
             q.clip0 = c0;
+            const char* ld = std::getenv("AC_LSTM_DBG");
+            q.dbg = ld ? std::atoi(ld) : 0;
             HIPCHK(h, hipMemsetAsync(h->lp_ctl, 0, LP_CTL_WORDS * sizeof(unsigned), st));
             void* args[] = {&q};
             HIPCHK(h, hipLaunchCooperativeKernel(reinterpret_cast<const void*>(lstm_persist_kernel), dim3(256), dim3(256), args, 0, st));

@@ -17,8 +17,8 @@
 // where the other XCD sees them), `s_waitcnt vmcnt(0)` + workgroup barrier, then a relaxed agent-scope flag
 // store; consumers poll the 32 flags with one wave.  No wbl2 / inv fences (those cost the 5-12 us of a grid
 // barrier).  Every spin is bounded: on timeout a word is set and all workgroups leave.
-// Layer 1 first multiplies W_ih1 with h0[t] (available long before) while its peers finish step t-1, then
-// W_hh1 with h1[t-1]: the input projection is off the recurrent critical path and needs no gin buffer.
+// Layer 1 multiplies W_ih1 with h0[t+1] (layer 0 runs ahead) right after publishing h1[t], i.e. while its peers'
+// slices travel: the input projection hides behind the exchange latency and needs no gin buffer.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "lstm.h"
@@ -41,6 +41,8 @@ struct LstmPersistParams {
     int B, T;              // clips of this launch (<= 64), steps
     int group0;            // first 16-clip group of this launch inside hseq (clip0 / 16)
     int clip0;             // first clip (for gin / skip / y rows)
+    int dbg;               // developer timing modes (AC_LSTM_DBG; results invalid): 1 = layer 0 only, 2 = skip the MFMAs,
+                           // 4 = do not wait for flags
 };
 
 // control block layout (32-bit words)
@@ -56,7 +58,8 @@ constexpr int LP_SC1 = 16;   // buffer cache-policy bit: agent scope
 __device__ __forceinline__ unsigned lp_xcc_id() { return __builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xf; }   // hwreg(HW_REG_XCC_ID, 0, 4)
 
 // all 32 flags of (group, layer) >= want ?  polled by wave 0; returns false on timeout
-__device__ __forceinline__ bool lp_wait(unsigned* flags, unsigned want, unsigned* tmo, int lane) {
+__device__ __forceinline__ bool lp_wait(unsigned* flags, unsigned want, unsigned* tmo, int lane, int dbg = 0) {
+    if (dbg & 4) return true;
     for (unsigned spins = 0;; ++spins) {
         const unsigned f = lane < LP_SLICES ? __hip_atomic_load(&flags[lane * LP_FLAG_STRIDE], LP_RLX) : 0xffffffffu;
         if (__all(f >= want)) return true;
@@ -82,6 +85,7 @@ __global__ __launch_bounds__(256) void lstm_persist_kernel(const LstmPersistPara
     const int g = x >> 1;                                     // clip group of this launch
     const int G = (p.B + 15) >> 4;
     if (slot >= 32 || g >= G) return;
+    if ((p.dbg & 1) && (slot >> 4) == 1) return;
     const int layer = slot >> 4, idx = (x & 1) * 16 + (slot & 15), u0 = idx * 16;
 
     // ---- weights -> registers: wave w holds k-steps 8w..8w+7 of the 4 gate tiles
@@ -120,6 +124,35 @@ __global__ __launch_bounds__(256) void lstm_persist_kernel(const LstmPersistPara
     // where this thread's h lands inside the slice's 1 KB block (A-fragment order, see hfrag_index)
     const int hpos = (((ej >> 2) << 4) + ec) * 4 + (ej & 3);
 
+    // A operand: this wave's 8 k-step blocks of h[t] of `seq` (sc1: through L2 / memory, never the per-CU L1)
+    auto load_a = [&](const float* seq, int t, f32x4 (&a)[8]) {
+        const float* src = seq + (long long)t * p.h_ts + goff + (long long)(wave * 8) * 256;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, 8 * 1024, 0x00020000);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) a[ks] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (ks * 64 + lane) * 16, 0, LP_SC1));
+    };
+    // layer 1: accP = W_ih1 * h0[t]  (waits until layer 0 has published step t)
+    f32x4 accP[4];
+    auto project = [&](int t) -> bool {
+        if (wave == 0) { const bool ok = lp_wait(flags0, (unsigned)(t + 1), tmo, lane, p.dbg); if (lane == 0) s_okp = ok; }
+        __syncthreads();
+        if (!s_okp) return false;
+        f32x4 a[8];
+        load_a(p.hseq0, t, a);
+#pragma unroll
+        for (int n = 0; n < 4; ++n) accP[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) accP[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks][u], wa[n][ks][u], accP[n], 0, 0, 0);
+        return true;
+    };
+#pragma unroll
+    for (int n = 0; n < 4; ++n) accP[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (layer == 1 && !project(0)) return;
+
     for (int t = 0; t < p.T; ++t) {
         // epilogue operands early
         float gpre[4] = {bq[0], bq[1], bq[2], bq[3]};
@@ -135,36 +168,17 @@ __global__ __launch_bounds__(256) void lstm_persist_kernel(const LstmPersistPara
         }
         f32x4 acc[4];
 #pragma unroll
-        for (int n = 0; n < 4; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-        // ---- layer 1: input projection W_ih1 * h0[t]
-        if (layer == 1) {
-            if (wave == 0) { const bool ok = lp_wait(flags0, (unsigned)(t + 1), tmo, lane); if (lane == 0) s_okp = ok; }
-            __syncthreads();
-            if (!s_okp) return;
-            const float* src = p.hseq0 + (long long)t * p.h_ts + goff + (long long)(wave * 8) * 256;
-            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, 8 * 1024, 0x00020000);
-            f32x4 a[8];
-#pragma unroll
-            for (int ks = 0; ks < 8; ++ks) a[ks] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (ks * 64 + lane) * 16, 0, LP_SC1));
-#pragma unroll
-            for (int ks = 0; ks < 8; ++ks)
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-#pragma unroll
-                    for (int n = 0; n < 4; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks][u], wa[n][ks][u], acc[n], 0, 0, 0);
-        }
-        // ---- recurrent term W_hh * h[t-1]
+        for (int n = 0; n < 4; ++n) acc[n] = accP[n];           // layer 1: W_ih1 * h0[t], computed during the previous exchange
+        // ---- recurrent term W_hh * h[t-1]: the critical path
         if (t > 0) {
-            if (wave == 0) { const bool ok = lp_wait(layer ? flags1 : flags0, (unsigned)t, tmo, lane); if (lane == 0) s_okr = ok; }
+            if (wave == 0) { const bool ok = lp_wait(layer ? flags1 : flags0, (unsigned)t, tmo, lane, p.dbg); if (lane == 0) s_okr = ok; }
             __syncthreads();
             if (!s_okr) return;
-            const float* src = hmine + (long long)(t - 1) * p.h_ts + goff + (long long)(wave * 8) * 256;
-            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, 8 * 1024, 0x00020000);
             f32x4 a[8];
-#pragma unroll
-            for (int ks = 0; ks < 8; ++ks) a[ks] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (ks * 64 + lane) * 16, 0, LP_SC1));
-            if (layer == 0) {
+            load_a(hmine, t - 1, a);
+            if (p.dbg & 2) {
+                acc[0] += a[0] + a[7];
+            } else if (layer == 0) {
 #pragma unroll
                 for (int ks = 0; ks < 8; ++ks)
 #pragma unroll
@@ -198,15 +212,19 @@ __global__ __launch_bounds__(256) void lstm_persist_kernel(const LstmPersistPara
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)dst, 0, 1024, 0x00020000);
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, hn), rs, hpos * 4, 0, LP_SC1);
         }
-        if (layer == 1 && live) {
-            const float yv = hn + skipv;
-            const long long o = erow * p.y_bs + (long long)t * D + eu;
-            if (p.yout) p.yout[o] = yv;
-            if (p.yout_elu) p.yout_elu[o] = elu1(yv);
-        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the slice is at L2 / memory before the flag moves
         __syncthreads();                                       // also: `part` may be overwritten by the next step
         if (tid == 0) __hip_atomic_store(myflag, (unsigned)(t + 1), LP_RLX);
+        if (layer == 1) {
+            if (live) {                                        // module output, off the recurrent path
+                const float yv = hn + skipv;
+                const long long o = erow * p.y_bs + (long long)t * D + eu;
+                if (p.yout) p.yout[o] = yv;
+                if (p.yout_elu) p.yout_elu[o] = elu1(yv);
+            }
+            // next step's input projection while the peers' h1[t] slices travel
+            if (t + 1 < p.T && !project(t + 1)) return;
+        }
     }
 }
 
