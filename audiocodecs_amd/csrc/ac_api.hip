@@ -1207,6 +1207,18 @@ static int upload_blob(ac_handle* h, Packer& pk, int device) {
     h->lstm_step_only = lm && std::strcmp(lm, "step") == 0;
     HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&h->lp_ctl), LP_CTL_WORDS * sizeof(unsigned)));
     HIPCHK(h, hipMemset(h->lp_ctl, 0, LP_CTL_WORDS * sizeof(unsigned)));
+    if (h->num_cus == 256 && !h->lstm_step_only) {
+        // the persistent LSTM assigns roles from XCC_ID: use it only where a 256-workgroup cooperative launch really
+        // lands 32 workgroups on each of 8 XCDs (otherwise: the per-step kernel)
+        unsigned* hist = h->lp_ctl;
+        void* args[] = {&hist};
+        unsigned got[16] = {0};
+        bool ok = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(lstm_persist_probe_kernel), dim3(256), dim3(256), args, 0, nullptr) == hipSuccess &&
+                  hipDeviceSynchronize() == hipSuccess && hipMemcpy(got, hist, sizeof got, hipMemcpyDeviceToHost) == hipSuccess;
+        for (int i = 0; ok && i < 16; ++i) ok = got[i] == (i < 8 ? 32u : 0u);
+        if (!ok) { (void)hipGetLastError(); h->lstm_step_only = true; }
+        HIPCHK(h, hipMemset(h->lp_ctl, 0, LP_CTL_WORDS * sizeof(unsigned)));
+    }
     h->blob_floats = pk.blob.size();
     HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&h->blob), h->blob_floats * sizeof(float)));
     HIPCHK(h, hipMemcpy(h->blob, pk.blob.data(), h->blob_floats * sizeof(float), hipMemcpyHostToDevice));

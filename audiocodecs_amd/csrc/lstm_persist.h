@@ -57,6 +57,12 @@ constexpr int LP_SC1 = 16;   // buffer cache-policy bit: agent scope
 
 __device__ __forceinline__ unsigned lp_xcc_id() { return __builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xf; }   // hwreg(HW_REG_XCC_ID, 0, 4)
 
+// Placement probe (run once at ac_finalize): does a 256-workgroup cooperative launch of this shape put exactly 32
+// workgroups on each of 8 XCDs?  hist[x] counts the workgroups that read XCC_ID == x.
+__global__ __launch_bounds__(256) void lstm_persist_probe_kernel(unsigned* hist) {
+    if (threadIdx.x == 0) atomicAdd(&hist[lp_xcc_id() & 15], 1u);
+}
+
 // all 32 flags of (group, layer) >= want ?  polled by wave 0; returns false on timeout
 __device__ __forceinline__ bool lp_wait(unsigned* flags, unsigned want, unsigned* tmo, int lane, int dbg = 0) {
     if (dbg & 4) return true;
