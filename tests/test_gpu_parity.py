@@ -209,3 +209,26 @@ def test_error_behaviour(codecs, checkpoints):
         c8.sig_to_toks(torch.zeros(1, 100))  # CPU tensor: no fallback
     with pytest.raises(NativeError):
         c8.toks_to_sig(torch.zeros(1, 3, 33, dtype=torch.long, device="cuda"))  # K > num_quantizers
+
+
+def test_persistent_and_per_step_lstm_agree(checkpoints, monkeypatch):
+    """The single-launch LSTM (lstm_persist.h; full-width model on a 256-CU device) and the per-step fallback
+    (AC_LSTM=step, also what narrower models use) are the same function up to fp32 summation order."""
+    from audiocodecs_amd import Encodec
+
+    cfg, sd = checkpoints("full", 0)
+    sig = noise(4242, 5, 16000).cuda()          # 5 clips: a partial 16-clip group
+    fast = Encodec(24000, num_codebooks=8, state_dict=sd, config=cfg).eval()
+    a = fast.sig_to_feats(sig)
+    nat = next(iter(fast._natives.values()))
+    assert nat.lib.ac_lstm_status(nat.h) == 1   # persistent path in use, no timeout
+    monkeypatch.setenv("AC_LSTM", "step")
+    slow = Encodec(24000, num_codebooks=8, state_dict=sd, config=cfg).eval()
+    b = slow.sig_to_feats(sig)
+    nat2 = next(iter(slow._natives.values()))
+    assert nat2.lib.ac_lstm_status(nat2.h) == 0
+    assert rms((a - b).cpu().numpy()) < 2e-6
+    ra, rb = fast.toks_to_sig(fast.sig_to_toks(sig)), slow.toks_to_sig(fast.sig_to_toks(sig))
+    assert rms((ra - rb).cpu().numpy()) < 2e-6
+    big = noise(4243, 70, 3200).cuda()          # 70 clips: two cooperative launches (64 + 6)
+    assert rms((fast.sig_to_feats(big) - slow.sig_to_feats(big)).cpu().numpy()) < 2e-6
