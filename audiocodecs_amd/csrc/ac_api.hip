@@ -18,6 +18,7 @@
 #include "rvq.h"
 #include "tap_gemm.h"
 #include "tap_gemm4.h"
+#include "tap_gemm6.h"
 #include "thin.h"
 #include "rb_fused.h"
 #include "mimi.h"
@@ -133,6 +134,9 @@ struct ac_handle {
     size_t dbg_cap = 0, dbg_used = 0;
     // kernels that already got their > 64 KB dynamic-LDS opt-in on this handle's device
     std::vector<const void*> lds_opted;
+    // split-operand weights (tap_gemm6.h): float offset of a packed fp32 matrix -> float offset of its bf16 planes
+    std::map<size_t, size_t> w6_of;
+    bool gemm_fp32 = false;         // AC_GEMM=fp32: exact-product kernels only
     // persistent LSTM (lstm_persist.h): control words, device shape, opt-out (AC_LSTM=step)
     unsigned* lp_ctl = nullptr;
     int num_cus = 0;
@@ -279,6 +283,41 @@ struct Packer {
         blob.resize(off + n, 0.f);
         return off;
     }
+    // tap_gemm6.h weight operand: exact truncation split of every weight into three bf16 terms, packed in MFMA
+    // B-fragment order  [n-tile of 32][k-step of 16][plane][lane 64][8]
+    void pack6(const PackedGemm& g) {
+        if (g.N % 64 || g.Ktot % 32 || h->w6_of.count(g.w_off)) return;
+        const size_t n_el = (size_t)g.N * g.Ktot;
+        const size_t off = reserve((3 * n_el + 1) / 2);
+        std::vector<uint16_t> planes(3 * n_el);
+        const int ksteps = g.Ktot / 16;
+        for (int nt = 0; nt < g.N / 32; ++nt)
+            for (int s = 0; s < ksteps; ++s)
+                for (int l = 0; l < 64; ++l)
+                    for (int e = 0; e < 8; ++e) {
+                        const float v = blob[g.w_off + (size_t)(nt * 32 + (l & 31)) * g.Ktot + s * 16 + 8 * (l >> 5) + e];
+                        uint32_t b;
+                        std::memcpy(&b, &v, 4);
+                        const uint32_t bh = b & 0xffff0000u;
+                        float fh;
+                        std::memcpy(&fh, &bh, 4);
+                        const float r1 = v - fh;
+                        uint32_t b1;
+                        std::memcpy(&b1, &r1, 4);
+                        const uint32_t bm = b1 & 0xffff0000u;
+                        float fm;
+                        std::memcpy(&fm, &bm, 4);
+                        const float r2 = r1 - fm;
+                        uint32_t b2;
+                        std::memcpy(&b2, &r2, 4);
+                        const size_t base = (((size_t)nt * ksteps + s) * 3) * 512 + (size_t)l * 8 + e;
+                        planes[base] = (uint16_t)(bh >> 16);
+                        planes[base + 512] = (uint16_t)(bm >> 16);
+                        planes[base + 1024] = (uint16_t)(b2 >> 16);
+                    }
+        std::memcpy(&blob[off], planes.data(), planes.size() * 2);
+        h->w6_of[g.w_off] = off;
+    }
     // plain conv (stride 1 or k = 2*stride): packed[n][tap*cin + ci] = w[n][ci][tap]
     bool conv(const ConvSpec& s, PackedGemm& g, bool bias = true) {
         std::vector<float> w;
@@ -297,6 +336,7 @@ struct Packer {
             g.b_off = reserve(g.N);
             std::copy(b->begin(), b->end(), blob.begin() + g.b_off);
         }
+        pack6(g);
         return true;
     }
     // transposed conv, k = 2*s: out row m = [x[m-1] | x[m]] * Wp,  n = p*cout + co,
@@ -318,6 +358,7 @@ struct Packer {
         g.b_off = reserve(g.N);
         for (int p = 0; p < s.s; ++p)
             for (int co = 0; co < s.cout; ++co) blob[g.b_off + (size_t)p * s.cout + co] = (*b)[co];
+        pack6(g);
         return true;
     }
     bool resblock(const ConvSpec& c3, const ConvSpec& c1, const ConvSpec& sc, ResBlockPlan& rb) {
@@ -338,6 +379,7 @@ struct Packer {
         }
         rb.fused.b_off = reserve(C);
         for (int n = 0; n < C; ++n) blob[rb.fused.b_off + n] = (*b1)[n] + (*bs)[n];
+        pack6(rb.fused);
         return true;
     }
     bool lstm(const std::string& prefix, int D, int layers, LstmPlan& lp) {
@@ -357,6 +399,7 @@ struct Packer {
             std::copy(wih->begin(), wih->end(), blob.begin() + g.w_off);
             g.b_off = reserve((size_t)4 * D);
             for (int n = 0; n < 4 * D; ++n) blob[g.b_off + n] = (*bih)[n] + (*bhh)[n];
+            if (l == 0) pack6(g);
             lp.ih.push_back(g);
             // W_hh in MFMA B-fragment order: [ug][kstep][lane][u] = Whh[(lane&15 >> 2)*D + ug*4 + (lane&3)][kstep*16 + 4*(lane>>4) + u]
             const size_t off = reserve((size_t)4 * D * D);
@@ -523,6 +566,14 @@ int run_tap(ac_handle* h, hipStream_t st, TapGemmParams& p) {
     }
     const double flops = 2.0 * p.B * (double)p.M * p.N * kk;
     const double bytes = inb + (double)p.B * p.M * p.N * 4.0 * ((p.y ? 1 : 0) + (p.y_elu ? 1 : 0)) + (double)p.N * p.Ktot * 4.0;
+    // split-operand kernel on the bf16 pipe (tap_gemm6.h) where the shape allows and the weights were packed for it
+    const __bf16* w6 = nullptr;
+    if (fast && !h->gemm_fp32 && p.N % 64 == 0) {
+        auto it = h->w6_of.find((size_t)(p.w - h->blob));
+        bool ok6 = it != h->w6_of.end();
+        for (int i = 0; ok6 && i < p.nseg; ++i) ok6 = p.seg[i].kofs % 32 == 0;
+        if (ok6) w6 = reinterpret_cast<const __bf16*>(h->blob + it->second);
+    }
     int rc = AC_OK;
     char shape[64] = "";
     if (h->prof && h->prof_detail)
@@ -540,6 +591,23 @@ int run_tap(ac_handle* h, hipStream_t st, TapGemmParams& p) {
             launch_tap<WGM, WGN, WM, WN, false>(p, st);                                                     \
         }                                                                                                   \
     } while (0)
+    if (w6) {
+        const bool wide = p.N % 128 == 0;
+        p.mtiles = cdiv(p.M, 128);
+        p.ntiles = p.N / (wide ? 128 : 64);
+        const long long blocks = (long long)p.B * p.mtiles * p.ntiles;
+        if (wide) {
+            if ((rc = ensure_lds(h, reinterpret_cast<const void*>(tap_gemm6_kernel<2>), Tap6Cfg<2>::lds_bytes))) return rc;
+            ProfScope ps(h, st, (std::string("tap_gemm6_kernel<2>") + shape).c_str(), flops, bytes);
+            hipLaunchKernelGGL(tap_gemm6_kernel<2>, dim3((unsigned)blocks), dim3(256), Tap6Cfg<2>::lds_bytes, st, p, w6);
+        } else {
+            if ((rc = ensure_lds(h, reinterpret_cast<const void*>(tap_gemm6_kernel<1>), Tap6Cfg<1>::lds_bytes))) return rc;
+            ProfScope ps(h, st, (std::string("tap_gemm6_kernel<1>") + shape).c_str(), flops, bytes);
+            hipLaunchKernelGGL(tap_gemm6_kernel<1>, dim3((unsigned)blocks), dim3(256), Tap6Cfg<1>::lds_bytes, st, p, w6);
+        }
+        HIPCHK(h, hipGetLastError());
+        return AC_OK;
+    }
     if (p.N <= 16) TAP_CASE(4, 1, 2, 1);
     else if (p.N <= 32) TAP_CASE(4, 1, 2, 2);
     else if (p.N <= 64) TAP_CASE(2, 2, 2, 2);
@@ -1203,6 +1271,8 @@ static int upload_blob(ac_handle* h, Packer& pk, int device) {
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(h, AC_ENODEV, "device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
     h->num_cus = prop.multiProcessorCount;
+    const char* gm = std::getenv("AC_GEMM");
+    h->gemm_fp32 = gm && std::strcmp(gm, "fp32") == 0;
     const char* lm = std::getenv("AC_LSTM");
     h->lstm_step_only = lm && std::strcmp(lm, "step") == 0;
     HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&h->lp_ctl), LP_CTL_WORDS * sizeof(unsigned)));

@@ -471,6 +471,7 @@ int mimi_finalize(ac_handle* h, Packer& pk) {
             if (!w) return false;
             std::copy(w->begin(), w->end(), pk.blob.begin() + g.w_off + j * (size_t)out_each * in);
         }
+        pk.pack6(g);
         return true;
     };
     for (int part = 0; part < 2; ++part) {

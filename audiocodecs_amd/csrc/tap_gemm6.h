@@ -1,0 +1,290 @@
+// tap_gemm6: the tap-GEMM (tap_gemm.h: conv -> GEMM mapping, padding rules, epilogue terms) on the bf16 matrix
+// pipe with fp32 fidelity -- "split-operand" arithmetic:
+//     every fp32 operand is written EXACTLY as hi + mid + lo, three bf16 terms of 8 significand bits (truncation
+//     split), and a product a*b is accumulated in fp32 from 6 of its 9 partial products a_i*b_j (each exact):
+//     hh, hm, mh, mm, hl, lh; the dropped ml, lm, ll are below 2^-23 of the product -- the size of ONE fp32 rounding.
+//     Measured (tools/ubench/bf16x_gemm.hip, K = 1024): rms error 5.08e-7 of the rms value, an fp32 fma chain has
+//     5.56e-7 on the same data.  v_mfma_f32_32x32x16_bf16 runs 16x the fp32 MFMA rate, so 6 terms cost 0.375x of
+//     the fp32-MFMA time: the kernel's roofline moves from 157 to 417 fp32-equivalent TFLOP/s.
+// The probe also showed what binds such a kernel: LDS bandwidth (three planes of fragments).  Hence
+//   * the weight operand never touches LDS: it is split and packed OFFLINE in MFMA B-fragment order
+//       wp[n-tile of 32][k-step of 16][plane 3][lane 64][8 bf16]        (a wave-load = 1 KB contiguous per plane)
+//     and loaded from L2 straight into registers one k-step ahead;
+//   * the activation operand is loaded exactly like in tap_gemm4 (buffer loads with per-slot constant offsets,
+//     clip-edge rules) and split ONCE, while it is staged into a double-buffered LDS slab of three bf16 planes.
+// Workgroup = 4 waves (2 x 2), wave tile 64 x 32*WN, BM = 128, BN = 64*WN, KC = 32 (two k-steps) per stage.
+// Requirements beyond tap_gemm4's: N % 32 == 0 and every segment's kofs % 32 == 0 (k-steps align with stages).
+// The exact-product kernel tap_gemm4 stays selectable (environment AC_GEMM=fp32) and serves every other shape.
+#pragma once
+#include "tap_gemm4.h"
+
+namespace ac {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int T6_PITCH = 40;        // bf16 per LDS row (32 + 8): 80-byte rows keep 16-byte alignment, spread banks
+
+template <int WN>
+struct Tap6Cfg {
+    static constexpr int BM = 128, BN = 64 * WN, NT = 256;
+    static constexpr int MAXJ = 8;
+    static constexpr int A_ROWS = BM + MAXJ - 1;
+    static constexpr int A_SLOTS = (A_ROWS * (KC / 4) + NT - 1) / NT;
+    static constexpr int PLANE = A_ROWS * T6_PITCH;                 // bf16 elements per plane
+    static constexpr int CP = BN + 4;
+    static constexpr size_t main_bytes = (size_t)2 * 3 * PLANE * 2;
+    static constexpr size_t epi_bytes = (size_t)BM * CP * 4;
+    static constexpr size_t lds_bytes = main_bytes > epi_bytes ? main_bytes : epi_bytes;
+};
+
+template <int WN>
+__global__ __launch_bounds__(256) void tap_gemm6_kernel(const TapGemmParams p, const __bf16* __restrict__ wp) {
+    using Cfg = Tap6Cfg<WN>;
+    constexpr int BM = Cfg::BM, BN = Cfg::BN, NT = Cfg::NT, A_SLOTS = Cfg::A_SLOTS, PLANE = Cfg::PLANE;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __bf16* As0 = reinterpret_cast<__bf16*>(smem);            // [2 buffers][3 planes][A_ROWS][T6_PITCH]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int i32 = lane & 31, kh = lane >> 5;                // MFMA operand: row / column i32, k = 8*kh .. 8*kh + 7
+
+    int id;
+    {   // XCD-aware tile order (tap_gemm4.h)
+        const int total = gridDim.x, q = total >> 3, r = total & 7, xcd = blockIdx.x & 7, pos = blockIdx.x >> 3;
+        id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;
+    }
+    const int nt = id % p.ntiles; id /= p.ntiles;
+    const int mt = id % p.mtiles;
+    const int b = id / p.mtiles;
+    const int m0 = mt * BM, n0 = nt * BN;
+
+    f32x16 acc[2][WN];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < WN; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
+
+    int a_lds[A_SLOTS], a_boff[A_SLOTS];
+#pragma unroll
+    for (int i = 0; i < A_SLOTS; ++i) {
+        const int e = tid + i * NT;
+        a_lds[i] = (e / (KC / 4)) < Cfg::A_ROWS ? (e / (KC / 4)) * T6_PITCH + 4 * (e % (KC / 4)) : -1;
+    }
+
+    // ---- segment state (wave-uniform); identical to tap_gemm4
+    int si = 0, c0 = 0, j = 0;
+    int seg_J, seg_Cw, seg_kofs;
+    int seg_tapoff = 0;
+    bool seg_reload = false;
+    bool seg_interior;
+    unsigned a_zero = 0;
+    __amdgpu_buffer_rsrc_t a_rs;
+    auto enter_segment = [&](int s_) {
+        const TapSeg& sg = p.seg[s_];
+        seg_J = sg.J;
+        seg_Cw = sg.s * sg.cin;
+        seg_kofs = sg.kofs;
+        seg_reload = sg.dil != 1;
+        const long long lo = (long long)m0 * sg.s - sg.pad;
+        const long long hi = (long long)(m0 + BM - 1 + (sg.J - 1) * sg.dil) * sg.s + (sg.s - 1) - sg.pad;
+        const bool inside = lo >= 0 && hi < sg.L;
+        seg_interior = inside || (sg.s == 1 && !seg_reload);
+        a_zero = 0;
+        const int tsf = sg.s == 1 ? (int)sg.ts : sg.cin;
+        seg_tapoff = sg.dil * sg.s * tsf * 4;
+        a_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(sg.x + (long long)b * sg.bs), 0,
+                                                 (int)(((long long)(sg.L - 1) * sg.ts + sg.cin) * 4), 0x00020000);
+        const int R = seg_reload ? BM : BM + sg.J - 1;
+#pragma unroll
+        for (int i = 0; i < A_SLOTS; ++i) {
+            const int e = tid + i * NT;
+            const int row = e / (KC / 4), q = e % (KC / 4);
+            long long t = (long long)(m0 + (row < R ? row : 0)) * sg.s - sg.pad;
+            if (!inside) {
+                if (sg.s == 1 && !seg_reload) {
+                    const long long jj = row < R ? src_index(sg, (int)t) : 0;
+                    if (jj < 0) a_zero |= 1u << i;
+                    t = jj < 0 ? 0 : jj;
+                } else {
+                    t = 0;
+                }
+            }
+            a_boff[i] = (int)((t * tsf + 4 * q) * 4);
+        }
+    };
+    f32x4 ra[A_SLOTS];
+    auto load_a = [&](int s_, int c_, int j_) {
+        if (seg_interior) {
+            const int soff = c_ * 4 + (seg_reload ? j_ * seg_tapoff : 0);
+#pragma unroll
+            for (int i = 0; i < A_SLOTS; ++i) ra[i] = bufload16(a_rs, a_boff[i], soff);
+        } else {
+            const TapSeg& sg = p.seg[s_];
+            const int R = seg_reload ? BM : BM + sg.J - 1;
+            const int jr = seg_reload ? j_ * sg.dil : 0;
+            const float* xb = sg.x + (long long)b * sg.bs;
+#pragma unroll
+            for (int i = 0; i < A_SLOTS; ++i) {
+                const int e = tid + i * NT;
+                const int row = e / (KC / 4), q = e % (KC / 4);
+                const int c = c_ + 4 * q;
+                const int tp = sg.cin_shift >= 0 ? (c >> sg.cin_shift) : (c / sg.cin);
+                const long long jj = row < R ? src_index(sg, (m0 + row + jr) * sg.s + tp - sg.pad) : -1;
+                ra[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (jj >= 0) ra[i] = *reinterpret_cast<const f32x4*>(xb + jj * sg.ts + (c - tp * sg.cin));
+            }
+        }
+    };
+    // split 4 fp32 into the three bf16 planes (exact: v = hi + mid + lo) and store them
+    auto store_a = [&](__bf16* dst) {
+#pragma unroll
+        for (int i = 0; i < A_SLOTS; ++i)
+            if (a_lds[i] >= 0) {
+                const f32x4 v = (a_zero & (1u << i)) ? f32x4{0.f, 0.f, 0.f, 0.f} : ra[i];
+                unsigned h[4], m[4], l[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const unsigned bh = __float_as_uint(v[e]) & 0xffff0000u;
+                    const float r1 = v[e] - __uint_as_float(bh);
+                    const unsigned bm = __float_as_uint(r1) & 0xffff0000u;
+                    h[e] = bh; m[e] = bm; l[e] = __float_as_uint(r1 - __uint_as_float(bm));
+                }
+                unsigned* dh = reinterpret_cast<unsigned*>(dst + a_lds[i]);
+                unsigned* dm = reinterpret_cast<unsigned*>(dst + PLANE + a_lds[i]);
+                unsigned* dl = reinterpret_cast<unsigned*>(dst + 2 * PLANE + a_lds[i]);
+                dh[0] = (h[0] >> 16) | h[1]; dh[1] = (h[2] >> 16) | h[3];
+                dm[0] = (m[0] >> 16) | m[1]; dm[1] = (m[2] >> 16) | m[3];
+                dl[0] = (l[0] >> 16) | (l[1] & 0xffff0000u); dl[1] = (l[2] >> 16) | (l[3] & 0xffff0000u);
+            }
+    };
+    // B fragments of this wave's WN column tiles for ONE k-step: [plane][c]; k-step index inside the packed rows
+    const int ksteps = p.Ktot >> 4;
+    const __bf16* wbase = wp + ((long long)((n0 + wn * 32 * WN) >> 5) * ksteps) * (3 * 64 * 8) + lane * 8;
+    auto load_b = [&](int s_, bf16x8 (&bf)[3][WN]) {
+#pragma unroll
+        for (int c = 0; c < WN; ++c)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                bf[pl][c] = *reinterpret_cast<const bf16x8*>(wbase + (((long long)c * ksteps + s_) * 3 + pl) * (64 * 8));
+    };
+
+    // ---- prologue
+    enter_segment(0);
+    load_a(0, 0, 0);
+    bf16x8 b0[3][WN], b1[3][WN];                               // k-step 0 / 1 of the current stage
+    load_b(seg_kofs >> 4, b0);
+    store_a(As0);
+    __syncthreads();
+    int abuf = 0;
+    const int a_frag = (wm * 64 + i32) * T6_PITCH + 8 * kh;    // + (a*32 + j)*T6_PITCH + ks*16, + plane*PLANE
+    auto mfma_step = [&](const __bf16* Ac, int ks, const bf16x8 (&bf)[3][WN]) {
+        bf16x8 af[3][2];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int a = 0; a < 2; ++a) af[pl][a] = *reinterpret_cast<const bf16x8*>(Ac + pl * PLANE + a * 32 * T6_PITCH + ks * 16);
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int c = 0; c < WN; ++c) {
+                f32x16 v = acc[a][c];
+                // smallest partial products first: hl, lh, mm, hm, mh, hh
+                v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][a], bf[2][c], v, 0, 0, 0);
+                v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][a], bf[0][c], v, 0, 0, 0);
+                v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][a], bf[1][c], v, 0, 0, 0);
+                v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][a], bf[1][c], v, 0, 0, 0);
+                v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][a], bf[0][c], v, 0, 0, 0);
+                v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][a], bf[0][c], v, 0, 0, 0);
+                acc[a][c] = v;
+            }
+    };
+
+    for (;;) {
+        int nsi = si, nc0 = c0, nj = j + 1;
+        bool new_chunk = false;
+        if (nj == seg_J) {
+            nj = 0;
+            nc0 = c0 + KC;
+            new_chunk = true;
+            if (nc0 >= seg_Cw) { nc0 = 0; nsi = si + 1; }
+        }
+        const bool has_next = nsi < p.nseg;
+        const int cur_j = seg_reload ? 0 : j;
+        const int s_cur = (seg_kofs + j * seg_Cw + c0) >> 4;  // first k-step of this stage in the packed weight rows
+        load_b(s_cur + 1, b1);                                 // in flight during k-step 0
+        if (has_next) {
+            if (nsi != si) enter_segment(nsi);
+            new_chunk = new_chunk || seg_reload;
+            if (new_chunk) load_a(nsi, nc0, nj);
+        }
+        const __bf16* Ac = As0 + abuf * 3 * PLANE + a_frag + cur_j * T6_PITCH;
+        mfma_step(Ac, 0, b0);
+        if (has_next) {
+            load_b((seg_kofs + nj * seg_Cw + nc0) >> 4, b0);   // next stage's k-step 0, in flight during k-step 1
+            if (new_chunk) {
+                abuf ^= 1;
+                store_a(As0 + abuf * 3 * PLANE);
+            }
+        }
+        mfma_step(Ac, 1, b1);
+        if (!has_next) break;
+        __syncthreads();
+        si = nsi; c0 = nc0; j = nj;
+    }
+
+    // ---- epilogue through LDS (as tap_gemm4).  C layout of 32x32: column = lane & 31, row = 8*(r/4) + 4*kh + r%4
+    __syncthreads();
+    float* Cs = smem;
+    constexpr int CP = Cfg::CP;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < WN; ++c) {
+            const int n = (wn * WN + c) * 32 + i32;
+            const float bv = (p.bias && n0 + n < p.N) ? p.bias[n0 + n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Cs[(wm * 64 + a * 32 + 8 * (r / 4) + 4 * kh + (r % 4)) * CP + n] = acc[a][c][r] + bv;
+        }
+    __syncthreads();
+    const long long yoff = (long long)b * p.y_bs;
+    const bool post = p.gelu || p.scale || p.res || p.tanh_out;
+    for (int e = tid; e < BM * (BN / 4); e += NT) {
+        const int row = e / (BN / 4), q = e % (BN / 4);
+        const int m = m0 + row, n = n0 + 4 * q;
+        const long long fi = (long long)m * p.y_rs + n + p.y_off;
+        if (m < p.M && n < p.N && (p.y_len == 0 || (fi >= 0 && fi < p.y_len))) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(&Cs[row * CP + 4 * q]);
+            if (post) {
+                if (p.gelu) { v.x = gelu1(v.x); v.y = gelu1(v.y); v.z = gelu1(v.z); v.w = gelu1(v.w); }
+                if (p.scale) {
+                    const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + n);
+                    v.x = __fmul_rn(sc.x, v.x); v.y = __fmul_rn(sc.y, v.y); v.z = __fmul_rn(sc.z, v.z); v.w = __fmul_rn(sc.w, v.w);
+                }
+                if (p.res) {
+                    const f32x4 rv = *reinterpret_cast<const f32x4*>(p.res + (long long)b * p.res_bs + (long long)m * p.res_rs + n);
+                    v.x = __fadd_rn(rv.x, v.x); v.y = __fadd_rn(rv.y, v.y); v.z = __fadd_rn(rv.z, v.z); v.w = __fadd_rn(rv.w, v.w);
+                }
+                if (p.tanh_out) { v.x = tanhf(v.x); v.y = tanhf(v.y); v.z = tanhf(v.z); v.w = tanhf(v.w); }
+            }
+            const long long o = yoff + fi;
+            if (p.y) *reinterpret_cast<f32x4*>(p.y + o) = v;
+            if (p.y_elu) {
+                f32x4 w;
+                if (p.alpha) {
+                    const int c = n % p.alpha_n;
+                    const f32x4 al = *reinterpret_cast<const f32x4*>(p.alpha + c), ai = *reinterpret_cast<const f32x4*>(p.alpha_inv + c);
+                    w.x = snake1(v.x, al.x, ai.x); w.y = snake1(v.y, al.y, ai.y); w.z = snake1(v.z, al.z, ai.z); w.w = snake1(v.w, al.w, ai.w);
+                } else {
+                    w = elu4(v);
+                }
+                *reinterpret_cast<f32x4*>(p.y_elu + o) = w;
+            }
+        }
+    }
+}
+
+}  // namespace ac

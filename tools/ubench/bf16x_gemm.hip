@@ -231,6 +231,121 @@ __global__ __launch_bounds__(256) void gemm2(const float* A, const __bf16* Bp, f
             }
 }
 
+// v3: the weight operand never touches LDS: B is pre-split AND pre-packed in MFMA B-fragment order
+//   Bf[n-tile of 32][k-step of 16][plane 3][lane 64][8 bf16]   (a wave-load = 1 KB contiguous per plane)
+// and loaded straight from L2 into registers one k-step ahead; A is split while staged into a double-buffered LDS
+// slab (3 planes).  LDS now serves only the A fragments (the probe v2 was LDS-bandwidth-bound: 3 planes of A and B
+// fragments + staging ~ 96 of the 128 B/clk).
+template <int TERMS>
+__global__ __launch_bounds__(256) void gemm3(const float* A, const __bf16* Bf, float* C, int M, int N, int K) {
+    __shared__ __attribute__((aligned(16))) __bf16 As[2][3][BM * P2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int i32 = lane & 31, kh = lane >> 5;
+    const int ksteps = K / 16;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    f32x4 ra[4];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = tid + 256 * i, row = e >> 3, q = e & 7;
+            ra[i] = *reinterpret_cast<const f32x4*>(A + (long long)(m0 + row) * K + k0 + 4 * q);
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = tid + 256 * i, row = e >> 3, q = e & 7;
+            unsigned h[4], m[4], l[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float v = ra[i][j];
+                const unsigned bh = __float_as_uint(v) & 0xffff0000u;
+                const float r1 = v - __uint_as_float(bh);
+                const unsigned bm = __float_as_uint(r1) & 0xffff0000u;
+                h[j] = bh; m[j] = bm; l[j] = __float_as_uint(r1 - __uint_as_float(bm));
+            }
+            unsigned* dh = reinterpret_cast<unsigned*>(&As[buf][0][row * P2 + 4 * q]);
+            unsigned* dm = reinterpret_cast<unsigned*>(&As[buf][1][row * P2 + 4 * q]);
+            unsigned* dl = reinterpret_cast<unsigned*>(&As[buf][2][row * P2 + 4 * q]);
+            dh[0] = (h[0] >> 16) | h[1]; dh[1] = (h[2] >> 16) | h[3];
+            dm[0] = (m[0] >> 16) | m[1]; dm[1] = (m[2] >> 16) | m[3];
+            dl[0] = (l[0] >> 16) | (l[1] & 0xffff0000u); dl[1] = (l[2] >> 16) | (l[3] & 0xffff0000u);
+        }
+    };
+    // B fragments of this wave's two n-tiles for k-step s: [b][plane]
+    const __bf16* bbase = Bf + ((long long)((n0 + wn * 64) / 32) * ksteps) * (3 * 64 * 8) + lane * 8;
+    auto bload = [&](int s_, bf16x8 (&bf)[3][2]) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                bf[pl][b] = *reinterpret_cast<const bf16x8*>(bbase + (((long long)b * ksteps + s_) * 3 + pl) * (64 * 8));
+    };
+    gload(0);
+    lstore(0);
+    bf16x8 bcur[3][2], bnxt[3][2];
+    bload(0, bcur);
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = 0; k0 < K; k0 += KC) {
+        const bool more = k0 + KC < K;
+        if (more) gload(k0 + KC);
+#pragma unroll
+        for (int ks = 0; ks < KC / 16; ++ks) {
+            const int s_ = k0 / 16 + ks;
+            if (s_ + 1 < ksteps) bload(s_ + 1, bnxt);
+            bf16x8 af[3][2];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                for (int a = 0; a < 2; ++a) af[pl][a] = *reinterpret_cast<const bf16x8*>(&As[buf][pl][(wm * 64 + a * 32 + i32) * P2 + ks * 16 + 8 * kh]);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    f32x16 c = acc[a][b];
+                    if (TERMS == 9) {
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][a], bcur[2][b], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][a], bcur[2][b], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][a], bcur[1][b], c, 0, 0, 0);
+                    }
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][a], bcur[2][b], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][a], bcur[0][b], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][a], bcur[1][b], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][a], bcur[1][b], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][a], bcur[0][b], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][a], bcur[0][b], c, 0, 0, 0);
+                    acc[a][b] = c;
+                }
+            if (ks == 0 && more) lstore(buf ^ 1);
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) bcur[pl][b] = bnxt[pl][b];
+        }
+        __syncthreads();
+        buf ^= 1;
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + a * 32 + 8 * (r / 4) + kh * 4 + (r % 4);
+                const int col = n0 + wn * 64 + b * 32 + i32;
+                C[(long long)row * N + col] = acc[a][b][r];
+            }
+}
+
 int main() {
     const int M = 8192, N = 4096, K = 1024;
     std::vector<float> hA((size_t)M * K), hB((size_t)N * K), hC((size_t)M * N);
@@ -252,8 +367,18 @@ int main() {
         hBp[i] = bh >> 16; hBp[hB.size() + i] = bm >> 16; hBp[2 * hB.size() + i] = b2 >> 16;
     }
     __bf16* Bp; CK(hipMalloc(&Bp, hBp.size() * 2)); CK(hipMemcpy(Bp, hBp.data(), hBp.size() * 2, hipMemcpyHostToDevice));
+    // fragment-order packing of the planes for v3
+    std::vector<unsigned short> hBf((size_t)3 * N * K);
+    for (int nt = 0; nt < N / 32; ++nt)
+        for (int s_ = 0; s_ < K / 16; ++s_)
+            for (int pl = 0; pl < 3; ++pl)
+                for (int l = 0; l < 64; ++l)
+                    for (int e = 0; e < 8; ++e)
+                        hBf[((((size_t)nt * (K / 16) + s_) * 3 + pl) * 64 + l) * 8 + e] =
+                            hBp[(size_t)pl * N * K + (size_t)(nt * 32 + (l & 31)) * K + s_ * 16 + 8 * (l >> 5) + e];
+    __bf16* Bf; CK(hipMalloc(&Bf, hBf.size() * 2)); CK(hipMemcpy(Bf, hBf.data(), hBf.size() * 2, hipMemcpyHostToDevice));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int ver = 1; ver <= 2; ++ver)
+    for (int ver = 1; ver <= 3; ++ver)
     for (int terms : {6, 9}) {
         const dim3 grid(N / BN, M / BM);
         for (int rep = 0; rep < 3; ++rep) {
@@ -262,9 +387,12 @@ int main() {
                 if (ver == 1) {
                     if (terms == 6) hipLaunchKernelGGL(gemm<6>, grid, dim3(256), 0, 0, A, B, C, M, N, K);
                     else hipLaunchKernelGGL(gemm<9>, grid, dim3(256), 0, 0, A, B, C, M, N, K);
-                } else {
+                } else if (ver == 2) {
                     if (terms == 6) hipLaunchKernelGGL(gemm2<6>, grid, dim3(256), 0, 0, A, Bp, C, M, N, K);
                     else hipLaunchKernelGGL(gemm2<9>, grid, dim3(256), 0, 0, A, Bp, C, M, N, K);
+                } else {
+                    if (terms == 6) hipLaunchKernelGGL(gemm3<6>, grid, dim3(256), 0, 0, A, Bf, C, M, N, K);
+                    else hipLaunchKernelGGL(gemm3<9>, grid, dim3(256), 0, 0, A, Bf, C, M, N, K);
                 }
             }
             CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
