@@ -15,7 +15,8 @@ import torch  # noqa: F401  (loads libamdhip64 first)
 __all__ = ["lib", "lib_path", "AcConfig", "AcMimiConfig", "AcDacConfig", "AcKernelStat", "NativeError", "check", "EXPORTS"]
 
 AC_MAX_RATIOS = 8
-lib_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libaudiocodecs_amd.so")
+# AUDIOCODECS_AMD_LIB: developer override (timing variants built by hand); the product is the in-tree library
+lib_path = os.environ.get("AUDIOCODECS_AMD_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libaudiocodecs_amd.so")
 
 
 class NativeError(RuntimeError):

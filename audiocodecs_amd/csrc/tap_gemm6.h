@@ -39,7 +39,7 @@ struct Tap6Cfg {
 };
 
 template <int WN>
-__global__ __launch_bounds__(256) void tap_gemm6_kernel(const TapGemmParams p, const __bf16* __restrict__ wp) {
+__global__ __launch_bounds__(256, 2) void tap_gemm6_kernel(const TapGemmParams p, const __bf16* __restrict__ wp) {
     using Cfg = Tap6Cfg<WN>;
     constexpr int BM = Cfg::BM, BN = Cfg::BN, NT = Cfg::NT, A_SLOTS = Cfg::A_SLOTS, PLANE = Cfg::PLANE;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -148,10 +148,14 @@ __global__ __launch_bounds__(256) void tap_gemm6_kernel(const TapGemmParams p, c
                 unsigned h[4], m[4], l[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
+#ifdef T6_NOSPLIT   // developer timing variant (wrong results): what would the kernel do if the split were free?
+                    h[e] = m[e] = l[e] = __float_as_uint(v[e]);
+#else
                     const unsigned bh = __float_as_uint(v[e]) & 0xffff0000u;
                     const float r1 = v[e] - __uint_as_float(bh);
                     const unsigned bm = __float_as_uint(r1) & 0xffff0000u;
                     h[e] = bh; m[e] = bm; l[e] = __float_as_uint(r1 - __uint_as_float(bm));
+#endif
                 }
                 unsigned* dh = reinterpret_cast<unsigned*>(dst + a_lds[i]);
                 unsigned* dm = reinterpret_cast<unsigned*>(dst + PLANE + a_lds[i]);
@@ -175,8 +179,11 @@ __global__ __launch_bounds__(256) void tap_gemm6_kernel(const TapGemmParams p, c
     // ---- prologue
     enter_segment(0);
     load_a(0, 0, 0);
-    bf16x8 b0[3][WN], b1[3][WN];                               // k-step 0 / 1 of the current stage
-    load_b(seg_kofs >> 4, b0);
+    // three rotating B register sets: a stage uses (U0, U1) for its two k-steps and loads the NEXT stage's k-steps
+    // into (S, U0) -- each load is issued two k-steps before its use (one k-step is shorter than an L2 round trip)
+    bf16x8 bx[3][WN], by[3][WN], bz[3][WN];
+    load_b(seg_kofs >> 4, bx);
+    load_b((seg_kofs >> 4) + 1, by);
     store_a(As0);
     __syncthreads();
     int abuf = 0;
@@ -202,8 +209,8 @@ __global__ __launch_bounds__(256) void tap_gemm6_kernel(const TapGemmParams p, c
                 acc[a][c] = v;
             }
     };
-
-    for (;;) {
+    // one stage; returns true when it was the last one
+    auto stage = [&](bf16x8 (&u0)[3][WN], bf16x8 (&u1)[3][WN], bf16x8 (&sp)[3][WN]) -> bool {
         int nsi = si, nc0 = c0, nj = j + 1;
         bool new_chunk = false;
         if (nj == seg_J) {
@@ -214,26 +221,31 @@ __global__ __launch_bounds__(256) void tap_gemm6_kernel(const TapGemmParams p, c
         }
         const bool has_next = nsi < p.nseg;
         const int cur_j = seg_reload ? 0 : j;
-        const int s_cur = (seg_kofs + j * seg_Cw + c0) >> 4;  // first k-step of this stage in the packed weight rows
-        load_b(s_cur + 1, b1);                                 // in flight during k-step 0
+        int s_next = 0;
         if (has_next) {
             if (nsi != si) enter_segment(nsi);
             new_chunk = new_chunk || seg_reload;
+            s_next = (seg_kofs + nj * seg_Cw + nc0) >> 4;      // first k-step of the next stage in the packed weight rows
+            load_b(s_next, sp);
             if (new_chunk) load_a(nsi, nc0, nj);
         }
         const __bf16* Ac = As0 + abuf * 3 * PLANE + a_frag + cur_j * T6_PITCH;
-        mfma_step(Ac, 0, b0);
-        if (has_next) {
-            load_b((seg_kofs + nj * seg_Cw + nc0) >> 4, b0);   // next stage's k-step 0, in flight during k-step 1
-            if (new_chunk) {
-                abuf ^= 1;
-                store_a(As0 + abuf * 3 * PLANE);
-            }
+        mfma_step(Ac, 0, u0);
+        if (has_next) load_b(s_next + 1, u0);
+        mfma_step(Ac, 1, u1);
+        if (!has_next) return true;
+        if (new_chunk) {                                       // the A loads had the whole stage to arrive
+            abuf ^= 1;
+            store_a(As0 + abuf * 3 * PLANE);
         }
-        mfma_step(Ac, 1, b1);
-        if (!has_next) break;
         __syncthreads();
         si = nsi; c0 = nc0; j = nj;
+        return false;
+    };
+    for (;;) {
+        if (stage(bx, by, bz)) break;
+        if (stage(bz, bx, by)) break;
+        if (stage(by, bz, bx)) break;
     }
 
     // ---- epilogue through LDS (as tap_gemm4).  C layout of 32x32: column = lane & 31, row = 8*(r/4) + 4*kh + r%4

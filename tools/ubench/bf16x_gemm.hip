@@ -236,6 +236,8 @@ __global__ __launch_bounds__(256) void gemm2(const float* A, const __bf16* Bp, f
 // and loaded straight from L2 into registers one k-step ahead; A is split while staged into a double-buffered LDS
 // slab (3 planes).  LDS now serves only the A fragments (the probe v2 was LDS-bandwidth-bound: 3 planes of A and B
 // fragments + staging ~ 96 of the 128 B/clk).
+__device__ unsigned long long* g_trace;   // [wave 4][kstep 64][4 stamps]
+#define TRC(s_, k_) do { if (trace_on && lane == 0 && (s_) < 64) g_trace[((wave * 64) + (s_)) * 4 + (k_)] = __builtin_amdgcn_s_memtime(); } while (0)
 template <int TERMS>
 __global__ __launch_bounds__(256) void gemm3(const float* A, const __bf16* Bf, float* C, int M, int N, int K) {
     __shared__ __attribute__((aligned(16))) __bf16 As[2][3][BM * P2];
@@ -289,6 +291,7 @@ __global__ __launch_bounds__(256) void gemm3(const float* A, const __bf16* Bf, f
             for (int pl = 0; pl < 3; ++pl)
                 bf[pl][b] = *reinterpret_cast<const bf16x8*>(bbase + (((long long)b * ksteps + s_) * 3 + pl) * (64 * 8));
     };
+    const bool trace_on = g_trace && blockIdx.x == 3 && blockIdx.y == 17;
     gload(0);
     lstore(0);
     bf16x8 bcur[3][2], bnxt[3][2];
@@ -301,12 +304,15 @@ __global__ __launch_bounds__(256) void gemm3(const float* A, const __bf16* Bf, f
 #pragma unroll
         for (int ks = 0; ks < KC / 16; ++ks) {
             const int s_ = k0 / 16 + ks;
+            TRC(s_, 0);
             if (s_ + 1 < ksteps) bload(s_ + 1, bnxt);
             bf16x8 af[3][2];
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
                 for (int a = 0; a < 2; ++a) af[pl][a] = *reinterpret_cast<const bf16x8*>(&As[buf][pl][(wm * 64 + a * 32 + i32) * P2 + ks * 16 + 8 * kh]);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            TRC(s_, 1);
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -325,7 +331,110 @@ __global__ __launch_bounds__(256) void gemm3(const float* A, const __bf16* Bf, f
                     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][a], bcur[0][b], c, 0, 0, 0);
                     acc[a][b] = c;
                 }
+            TRC(s_, 2);
             if (ks == 0 && more) lstore(buf ^ 1);
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) bcur[pl][b] = bnxt[pl][b];
+            TRC(s_, 3);
+        }
+        __syncthreads();
+        buf ^= 1;
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + a * 32 + 8 * (r / 4) + kh * 4 + (r % 4);
+                const int col = n0 + wn * 64 + b * 32 + i32;
+                C[(long long)row * N + col] = acc[a][b][r];
+            }
+}
+
+// v4: like v3 (weights pre-split, fragment order, straight from L2) but the A slab stays fp32 in LDS (4 B/element
+// instead of 6: KC = 64 fits double-buffered, one barrier per 96 MFMAs) and is split after the fragment read --
+// the split VALU work then sits between the MFMAs of the same basic block instead of in front of a barrier.
+constexpr int KC4 = 64, KCP4 = KC4 + 4;
+template <int TERMS>
+__global__ __launch_bounds__(256, 2) void gemm4(const float* A, const __bf16* Bf, float* C, int M, int N, int K) {
+    extern __shared__ __attribute__((aligned(16))) float sm4[];
+    float* As = sm4;                                          // [2][BM][KCP4]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int i32 = lane & 31, kh = lane >> 5;
+    const int ksteps = K / 16;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    f32x4 ra[8];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int e = tid + 256 * i, row = e >> 4, q = e & 15;
+            ra[i] = *reinterpret_cast<const f32x4*>(A + (long long)(m0 + row) * K + k0 + 4 * q);
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int e = tid + 256 * i, row = e >> 4, q = e & 15;
+            *reinterpret_cast<f32x4*>(&As[(buf * BM + row) * KCP4 + 4 * q]) = ra[i];
+        }
+    };
+    const __bf16* bbase = Bf + ((long long)((n0 + wn * 64) / 32) * ksteps) * (3 * 64 * 8) + lane * 8;
+    auto bload = [&](int s_, bf16x8 (&bf)[3][2]) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                bf[pl][b] = *reinterpret_cast<const bf16x8*>(bbase + (((long long)b * ksteps + s_) * 3 + pl) * (64 * 8));
+    };
+    gload(0);
+    lstore(0);
+    bf16x8 bcur[3][2], bnxt[3][2];
+    bload(0, bcur);
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = 0; k0 < K; k0 += KC4) {
+        const bool more = k0 + KC4 < K;
+        if (more) gload(k0 + KC4);
+#pragma unroll
+        for (int ks = 0; ks < KC4 / 16; ++ks) {
+            const int s_ = k0 / 16 + ks;
+            if (s_ + 1 < ksteps) bload(s_ + 1, bnxt);
+            bf16x8 ah[2], am[2], al[2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const float* p = &As[(buf * BM + wm * 64 + a * 32 + i32) * KCP4 + ks * 16 + 8 * kh];
+                split8(*reinterpret_cast<const f32x4*>(p), *reinterpret_cast<const f32x4*>(p + 4), ah[a], am[a], al[a]);
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    f32x16 c = acc[a][b];
+                    if (TERMS == 9) {
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bcur[2][b], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[a], bcur[2][b], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bcur[1][b], c, 0, 0, 0);
+                    }
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bcur[2][b], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bcur[0][b], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[a], bcur[1][b], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bcur[1][b], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[a], bcur[0][b], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bcur[0][b], c, 0, 0, 0);
+                    acc[a][b] = c;
+                }
+            if (ks == 1 && more) lstore(buf ^ 1);
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
@@ -378,7 +487,11 @@ int main() {
                             hBp[(size_t)pl * N * K + (size_t)(nt * 32 + (l & 31)) * K + s_ * 16 + 8 * (l >> 5) + e];
     __bf16* Bf; CK(hipMalloc(&Bf, hBf.size() * 2)); CK(hipMemcpy(Bf, hBf.data(), hBf.size() * 2, hipMemcpyHostToDevice));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int ver = 1; ver <= 3; ++ver)
+    unsigned long long* dtr; CK(hipMalloc(&dtr, 4 * 64 * 4 * 8)); CK(hipMemset(dtr, 0, 4 * 64 * 4 * 8));
+    if (getenv("TRACE")) CK(hipMemcpyToSymbol(HIP_SYMBOL(g_trace), &dtr, sizeof dtr));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm4<6>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BM * KCP4 * 4));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm4<9>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BM * KCP4 * 4));
+    for (int ver = 1; ver <= 4; ++ver)
     for (int terms : {6, 9}) {
         const dim3 grid(N / BN, M / BM);
         for (int rep = 0; rep < 3; ++rep) {
@@ -390,9 +503,12 @@ int main() {
                 } else if (ver == 2) {
                     if (terms == 6) hipLaunchKernelGGL(gemm2<6>, grid, dim3(256), 0, 0, A, Bp, C, M, N, K);
                     else hipLaunchKernelGGL(gemm2<9>, grid, dim3(256), 0, 0, A, Bp, C, M, N, K);
-                } else {
+                } else if (ver == 3) {
                     if (terms == 6) hipLaunchKernelGGL(gemm3<6>, grid, dim3(256), 0, 0, A, Bf, C, M, N, K);
                     else hipLaunchKernelGGL(gemm3<9>, grid, dim3(256), 0, 0, A, Bf, C, M, N, K);
+                } else {
+                    if (terms == 6) hipLaunchKernelGGL(gemm4<6>, grid, dim3(256), 2 * BM * KCP4 * 4, 0, A, Bf, C, M, N, K);
+                    else hipLaunchKernelGGL(gemm4<9>, grid, dim3(256), 2 * BM * KCP4 * 4, 0, A, Bf, C, M, N, K);
                 }
             }
             CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
@@ -412,6 +528,18 @@ int main() {
             maxrel = fmax(maxrel, fabs(d) / (fabs(ref) + 1e-3));
         }
         printf(";  rms error / rms value %.3e (sequential fp32 fma chain: %.3e), max rel %.2e\n", sqrt(sumsq / refsq), sqrt(fp32err / refsq), maxrel);
+    }
+    if (getenv("TRACE")) {
+        std::vector<unsigned long long> tr(4 * 64 * 4);
+        CK(hipMemcpy(tr.data(), dtr, tr.size() * 8, hipMemcpyDeviceToHost));
+        for (int w = 0; w < 4; w += 3) {
+            printf("wave %d: k-step: [reads+wait] [mfma issue] [store/copy] [to next k-step incl. barrier]\n", w);
+            for (int s_ = 8; s_ < 20; ++s_) {
+                const unsigned long long* t = &tr[(w * 64 + s_) * 4];
+                const unsigned long long* n = &tr[(w * 64 + s_ + 1) * 4];
+                printf("  %2d: %5llu %5llu %5llu %5llu\n", s_, t[1] - t[0], t[2] - t[1], t[3] - t[2], n[0] - t[3]);
+            }
+        }
     }
     return 0;
 }
