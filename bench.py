@@ -137,11 +137,14 @@ def measured_traffic(kernel_name, unit, codec="encodec", batch=64):
     files = [f for f in files if batch_ok(f)]
     if not files:
         return None
-    try:
-        k = json.load(open(files[-1]))["kernels"].get(kernel_name)
-        return None if not k or k["hbm_bytes_per_launch"] is None else round(k["hbm_bytes_per_launch"])
-    except Exception:
-        return None
+    for f in reversed(files):   # newest summary that knows this kernel
+        try:
+            k = json.load(open(f))["kernels"].get(kernel_name)
+        except Exception:
+            continue
+        if k and k["hbm_bytes_per_launch"] is not None:
+            return round(k["hbm_bytes_per_launch"])
+    return None
 
 
 def main():
