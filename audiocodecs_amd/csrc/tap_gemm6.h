@@ -188,12 +188,13 @@ __global__ __launch_bounds__(256, 2) void tap_gemm6_kernel(const TapGemmParams p
     __syncthreads();
     int abuf = 0;
     const int a_frag = (wm * 64 + i32) * T6_PITCH + 8 * kh;    // + (a*32 + j)*T6_PITCH + ks*16, + plane*PLANE
-    auto mfma_step = [&](const __bf16* Ac, int ks, const bf16x8 (&bf)[3][WN]) {
-        bf16x8 af[3][2];
+    auto read_a = [&](const __bf16* Ac, int ks, bf16x8 (&af)[3][2]) {
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
             for (int a = 0; a < 2; ++a) af[pl][a] = *reinterpret_cast<const bf16x8*>(Ac + pl * PLANE + a * 32 * T6_PITCH + ks * 16);
+    };
+    auto mfma_step = [&](const bf16x8 (&af)[3][2], const bf16x8 (&bf)[3][WN]) {
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -230,9 +231,12 @@ __global__ __launch_bounds__(256, 2) void tap_gemm6_kernel(const TapGemmParams p
             if (new_chunk) load_a(nsi, nc0, nj);
         }
         const __bf16* Ac = As0 + abuf * 3 * PLANE + a_frag + cur_j * T6_PITCH;
-        mfma_step(Ac, 0, u0);
+        bf16x8 af0[3][2], af1[3][2];
+        read_a(Ac, 0, af0);
+        read_a(Ac, 1, af1);                                    // the second k-step's fragments travel under the first one's MFMAs
+        mfma_step(af0, u0);
         if (has_next) load_b(s_next + 1, u0);
-        mfma_step(Ac, 1, u1);
+        mfma_step(af1, u1);
         if (!has_next) return true;
         if (new_chunk) {                                       // the A loads had the whole stage to arrive
             abuf ^= 1;
