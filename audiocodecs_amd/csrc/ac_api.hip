@@ -15,6 +15,7 @@
 #include "../../include/audiocodecs_amd.h"
 #include "lstm.h"
 #include "lstm_persist.h"
+#include "lstm_persist6.h"
 #include "rvq.h"
 #include "tap_gemm.h"
 #include "tap_gemm4.h"
@@ -51,6 +52,7 @@ struct LstmPlan {
     std::vector<size_t> hh_off;     // W_hh per layer, MFMA B-fragment order
     std::vector<size_t> ihpk_off;   // W_ih per layer, same order (used by the in-step projection of layers >= 1)
     size_t persist_off = 0;         // register images of W_hh0, W_ih1, W_hh1 for lstm_persist_kernel (D = 512, 2 layers)
+    size_t persist6_off = 0;        // the same as three bf16 planes for lstm_persist6_kernel (float offset into the blob)
     bool has_persist = false;
 };
 
@@ -440,6 +442,38 @@ struct Packer {
                                     for (int e = 0; e < 4; ++e)
                                         blob[lp.persist_off + m * mat + ((((size_t)idx * 4 + w) * 4 + n) * 8 + ks) * 256 + lane * 4 + e] =
                                             (*mats[m])[(size_t)(n * D + idx * 16 + (lane & 15)) * D + (w * 8 + ks) * 16 + 4 * (lane >> 4) + e];
+            // lstm_persist6_kernel: [hh0, ih1, hh1][32 slices][4 waves][4 gates][4 k-steps of 32][3 planes][64 lanes][8 bf16]
+            const size_t mat6 = (size_t)LP_SLICES * 4 * 4 * 4 * 3 * 512;
+            lp.persist6_off = reserve((3 * mat6 + 1) / 2);
+            std::vector<uint16_t> pl6(3 * mat6);
+            for (int m = 0; m < 3; ++m)
+                for (int idx = 0; idx < LP_SLICES; ++idx)
+                    for (int w = 0; w < 4; ++w)
+                        for (int n = 0; n < 4; ++n)
+                            for (int ks = 0; ks < 4; ++ks)
+                                for (int lane = 0; lane < 64; ++lane)
+                                    for (int e = 0; e < 8; ++e) {
+                                        const float v = (*mats[m])[(size_t)(n * D + idx * 16 + (lane & 15)) * D + w * 128 + ks * 32 + 8 * (lane >> 4) + e];
+                                        uint32_t b;
+                                        std::memcpy(&b, &v, 4);
+                                        const uint32_t bh = b & 0xffff0000u;
+                                        float fh;
+                                        std::memcpy(&fh, &bh, 4);
+                                        const float r1 = v - fh;
+                                        uint32_t b1;
+                                        std::memcpy(&b1, &r1, 4);
+                                        const uint32_t bm = b1 & 0xffff0000u;
+                                        float fm;
+                                        std::memcpy(&fm, &bm, 4);
+                                        const float r2 = r1 - fm;
+                                        uint32_t b2;
+                                        std::memcpy(&b2, &r2, 4);
+                                        const size_t base = m * mat6 + (((((size_t)idx * 4 + w) * 4 + n) * 4 + ks) * 3) * 512 + (size_t)lane * 8 + e;
+                                        pl6[base] = (uint16_t)(bh >> 16);
+                                        pl6[base + 512] = (uint16_t)(bm >> 16);
+                                        pl6[base + 1024] = (uint16_t)(b2 >> 16);
+                                    }
+            std::memcpy(&blob[lp.persist6_off], pl6.data(), pl6.size() * 2);
             lp.has_persist = true;
         }
         return true;
@@ -868,6 +902,16 @@ int lstm_fwd(ac_handle* h, hipStream_t st, const LstmPlan& lp, const Act& x, con
             q.clip0 = c0;
             const char* ld = std::getenv("AC_LSTM_DBG");
             q.dbg = ld ? std::atoi(ld) : 0;
+            if (!h->gemm_fp32) {   // split-operand products on the bf16 pipe (lstm_persist6.h): h travels as bf16 plane blocks
+                LstmPersist6Params q6{};
+                q6.base = q;
+                q6.base.h_ts = (long long)((B + 31) / 32 * 2) * LP6_GROUP_BYTES;
+                q6.w_pk6 = reinterpret_cast<const __bf16*>(h->blob + lp.persist6_off);
+                HIPCHK(h, hipMemsetAsync(h->lp_ctl, 0, LP_CTL_WORDS * sizeof(unsigned), st));
+                void* args6[] = {&q6};
+                HIPCHK(h, hipLaunchCooperativeKernel(reinterpret_cast<const void*>(lstm_persist6_kernel), dim3(256), dim3(256), args6, 0, st));
+                continue;
+            }
             HIPCHK(h, hipMemsetAsync(h->lp_ctl, 0, LP_CTL_WORDS * sizeof(unsigned), st));
             void* args[] = {&q};
             HIPCHK(h, hipLaunchCooperativeKernel(reinterpret_cast<const void*>(lstm_persist_kernel), dim3(256), dim3(256), args, 0, st));
@@ -1034,7 +1078,7 @@ Workspace plan_ws(const ac_handle* h, int B, int T_in /*samples, encoder*/, int 
     mx = std::max(mx, (size_t)N * std::max(h->D, c.hidden_size));
     w.act_floats = align_up(mx * B, 64);
     w.gin = align_up((size_t)N * B * 4 * h->D, 64);
-    w.hseq = align_up((size_t)N * ((B + 31) / 32 * 32) * h->D, 64);   // clips padded to the 32-clip workgroup tile
+    w.hseq = align_up((size_t)N * ((B + 31) / 32 * 32) * h->D * 3 / 2, 64);   // clips padded to the 32-clip workgroup tile; x1.5: bf16 plane blocks (lstm_persist6.h)
     w.c = align_up((size_t)2 * B * h->D, 64);
     w.total_bytes = (NACT * w.act_floats + 2 * w.gin + 2 * w.hseq + w.c) * sizeof(float) + 256;
     return w;

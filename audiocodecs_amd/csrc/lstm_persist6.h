@@ -1,0 +1,189 @@
+// lstm_persist6: the persistent LSTM of lstm_persist.h (placement, flags, exchange protocol, cell update: see there)
+// with its two K = 512 products per step in split-operand arithmetic on the bf16 matrix pipe (tap_gemm6.h: every
+// fp32 value = hi + mid + lo, three exact bf16 terms; 6 of the 9 exact partial products, fp32 accumulate).
+//   * weights: split offline, register-resident for the whole sequence as B fragments of v_mfma_f32_16x16x32_bf16
+//       w_pk6[3 matrices][32 slices][4 waves][4 gates][4 k-steps of 32][3 planes][64 lanes][8 bf16]
+//     (192 VGPRs per matrix and wave; layer 1 holds W_ih1 and W_hh1);
+//   * h_t: the thread that owns (clip, unit) splits ITS value once and publishes three bf16 instead of one fp32;
+//     a slice's block is [3 planes][16 clips][16 units] bf16 (1536 B), so a consumer lane (clip i, kq) fetches the
+//     8 units 32 ks + 8 kq .. of a k-step with one 16-byte load per plane from slice 2 ks + kq/2.
+// Per step and wave: 4 gates x 4 k-steps x 6 = 96 MFMAs of 16 cycles per matrix instead of 128 of 32.
+#pragma once
+#include "lstm_persist.h"
+#include "tap_gemm6.h"
+
+namespace ac {
+
+constexpr int LP6_SLICE_BYTES = 3 * 16 * 16 * 2;     // 1536
+constexpr long long LP6_GROUP_BYTES = (long long)LP_SLICES * LP6_SLICE_BYTES;   // 48 KB per 16-clip group and time step
+
+struct LstmPersist6Params {
+    LstmPersistParams base;     // hseq0 / hseq1 are byte buffers of bf16 plane blocks here; h_ts = bytes per time step
+    const __bf16* w_pk6;
+};
+
+__global__ __launch_bounds__(256) void lstm_persist6_kernel(const LstmPersist6Params pp) {
+    const LstmPersistParams& p = pp.base;
+    constexpr int D = LP_D;
+    __shared__ float part[4][4][16][17];
+    __shared__ unsigned s_x, s_slot;
+    __shared__ int s_okp, s_okr;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, kq = lane >> 4;
+    unsigned* tmo = p.ctl + LP_CTL_TIMEOUT;
+    if (tid == 0) {
+        s_x = lp_xcc_id();
+        s_slot = __hip_atomic_fetch_add(&p.ctl[LP_CTL_SLOTS + (s_x & 7) * 16], 1u, LP_RLX);
+    }
+    __syncthreads();
+    const int x = s_x & 7, slot = s_slot;
+    const int g = x >> 1;
+    const int G = (p.B + 15) >> 4;
+    if (slot >= 32 || g >= G) return;
+    if ((p.dbg & 1) && (slot >> 4) == 1) return;
+    const int layer = slot >> 4, idx = (x & 1) * 16 + (slot & 15), u0 = idx * 16;
+
+    // ---- weights -> registers: [gate][k-step of 32][plane]
+    bf16x8 wa[4][4][3], wb[4][4][3];                          // layer 0: wa = W_hh0;  layer 1: wa = W_ih1, wb = W_hh1
+    {
+        const long long mat = (long long)LP_SLICES * 4 * 4 * 4 * 3 * 512;      // bf16 elements per matrix
+        const __bf16* base = pp.w_pk6 + ((long long)idx * 4 + wave) * (4 * 4 * 3 * 512) + lane * 8;
+        const __bf16* pa = base + (layer == 0 ? 0 : mat);
+        const __bf16* pb = base + 2 * mat;
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    wa[n][ks][pl] = *reinterpret_cast<const bf16x8*>(pa + ((n * 4 + ks) * 3 + pl) * 512);
+                    if (layer) wb[n][ks][pl] = *reinterpret_cast<const bf16x8*>(pb + ((n * 4 + ks) * 3 + pl) * 512);
+                    else wb[n][ks][pl] = wa[n][ks][pl];
+                }
+    }
+    unsigned* flags0 = p.ctl + LP_CTL_FLAGS + ((g * 2 + 0) * LP_SLICES) * LP_FLAG_STRIDE;
+    unsigned* flags1 = p.ctl + LP_CTL_FLAGS + ((g * 2 + 1) * LP_SLICES) * LP_FLAG_STRIDE;
+    unsigned* myflag = (layer ? flags1 : flags0) + idx * LP_FLAG_STRIDE;
+    char* h0b = reinterpret_cast<char*>(p.hseq0);
+    char* h1b = reinterpret_cast<char*>(p.hseq1);
+    char* hmine = layer ? h1b : h0b;
+    const long long goff = (long long)(p.group0 + g) * LP6_GROUP_BYTES;
+
+    const int ec = tid >> 4, ej = tid & 15;
+    const int eb = g * 16 + ec;
+    const bool live = eb < p.B;
+    const long long erow = (long long)(p.clip0 + eb);
+    const int eu = u0 + ej;
+    float cstate = 0.f;
+    float bq[4] = {0.f, 0.f, 0.f, 0.f};
+    if (layer == 1) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bq[q] = p.bias1[q * D + eu];
+    }
+    const int hpos = ec * 32 + ej * 2;                         // byte offset of (clip, unit) inside a plane of the slice block
+
+    // A operand: for k-step ks of this wave's K quarter, lane (clip li, kq) reads units 8 kq .. 8 kq + 7 of the 32
+    auto load_a = [&](const char* seq, int t, bf16x8 (&a)[4][3]) {
+        const char* src = seq + (long long)t * p.h_ts + goff + (long long)(wave * 8) * LP6_SLICE_BYTES;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, 8 * LP6_SLICE_BYTES, 0x00020000);
+        const int lo = (kq >> 1) * LP6_SLICE_BYTES + li * 32 + (kq & 1) * 16;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                a[ks][pl] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, ks * 2 * LP6_SLICE_BYTES + pl * 512 + lo, 0, LP_SC1));
+    };
+    auto mac = [&](const bf16x8 (&a)[4][3], const bf16x8 (&w)[4][4][3], f32x4 (&acc)[4]) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                f32x4 v = acc[n];
+                v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks][0], w[n][ks][2], v, 0, 0, 0);   // hl
+                v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks][2], w[n][ks][0], v, 0, 0, 0);   // lh
+                v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks][1], w[n][ks][1], v, 0, 0, 0);   // mm
+                v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks][0], w[n][ks][1], v, 0, 0, 0);   // hm
+                v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks][1], w[n][ks][0], v, 0, 0, 0);   // mh
+                v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks][0], w[n][ks][0], v, 0, 0, 0);   // hh
+                acc[n] = v;
+            }
+    };
+    f32x4 accP[4];
+    auto project = [&](int t) -> bool {
+        if (wave == 0) { const bool ok = lp_wait(flags0, (unsigned)(t + 1), tmo, lane, p.dbg); if (lane == 0) s_okp = ok; }
+        __syncthreads();
+        if (!s_okp) return false;
+        bf16x8 a[4][3];
+        load_a(h0b, t, a);
+#pragma unroll
+        for (int n = 0; n < 4; ++n) accP[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        mac(a, wa, accP);
+        return true;
+    };
+#pragma unroll
+    for (int n = 0; n < 4; ++n) accP[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (layer == 1 && !project(0)) return;
+
+    for (int t = 0; t < p.T; ++t) {
+        float gpre[4] = {bq[0], bq[1], bq[2], bq[3]};
+        float skipv = 0.f;
+        if (live) {
+            if (layer == 0) {
+                const float* gp = p.gin0 + (long long)t * p.gin_ts + erow * (4 * D);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) gpre[q] = gp[q * D + eu];
+            } else if (p.skip) {
+                skipv = p.skip[erow * p.skip_bs + (long long)t * D + eu];
+            }
+        }
+        f32x4 acc[4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[n] = accP[n];
+        if (t > 0) {
+            if (wave == 0) { const bool ok = lp_wait(layer ? flags1 : flags0, (unsigned)t, tmo, lane, p.dbg); if (lane == 0) s_okr = ok; }
+            __syncthreads();
+            if (!s_okr) return;
+            bf16x8 a[4][3];
+            load_a(hmine, t - 1, a);
+            if (layer == 0) mac(a, wa, acc);
+            else mac(a, wb, acc);
+        }
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) part[wave][n][kq * 4 + r][li] = acc[n][r];
+        __syncthreads();
+        float pre[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) pre[q] = gpre[q] + ((part[0][q][ec][ej] + part[1][q][ec][ej]) + (part[2][q][ec][ej] + part[3][q][ec][ej]));
+        const float ig = sigmoidf_(pre[0]), fg = sigmoidf_(pre[1]), gg = tanhf_(pre[2]), og = sigmoidf_(pre[3]);
+        cstate = fg * cstate + ig * gg;
+        const float hn = og * tanhf_(cstate);
+        // ---- publish h[t]: this thread's value as three exact bf16 terms, then the flag
+        {
+            const unsigned bh = __float_as_uint(hn) & 0xffff0000u;
+            const float r1 = hn - __uint_as_float(bh);
+            const unsigned bm = __float_as_uint(r1) & 0xffff0000u;
+            const unsigned bl = __float_as_uint(r1 - __uint_as_float(bm));
+            char* dst = hmine + (long long)t * p.h_ts + goff + (long long)idx * LP6_SLICE_BYTES;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)dst, 0, LP6_SLICE_BYTES, 0x00020000);
+            __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(bh >> 16), rs, hpos, 0, LP_SC1);
+            __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(bm >> 16), rs, 512 + hpos, 0, LP_SC1);
+            __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(bl >> 16), rs, 1024 + hpos, 0, LP_SC1);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(myflag, (unsigned)(t + 1), LP_RLX);
+        if (layer == 1) {
+            if (live) {
+                const float yv = hn + skipv;
+                const long long o = erow * p.y_bs + (long long)t * D + eu;
+                if (p.yout) p.yout[o] = yv;
+                if (p.yout_elu) p.yout_elu[o] = elu1(yv);
+            }
+            if (t + 1 < p.T && !project(t + 1)) return;
+        }
+    }
+}
+
+}  // namespace ac
