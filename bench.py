@@ -263,7 +263,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32" if os.environ.get("AC_GEMM") == "fp32" else "f32 (GEMMs: operands split exactly into 3 bf16 terms, 6 partial products, fp32 accumulate)",
+            "dtype": "f32" if os.environ.get("AC_GEMM") == "fp32" else "f32 (GEMMs and LSTM products: operands split exactly into 3 bf16 terms, 6 partial products, fp32 accumulate)",
             "data": f"synthetic (0.1*N(0,1) clips, seeded synthetic weights of the {label} architecture)",
             "config": {"workload": f"{label} {ncb} codebooks, encode+decode, {B} clips x {args.seconds:g} s per GPU, resident in HBM",
                        "clips_per_gpu": B, "seconds_per_clip": args.seconds, "parallelism": f"clip-sharded x{world}"},
