@@ -455,6 +455,127 @@ __global__ __launch_bounds__(256, 2) void gemm4(const float* A, const __bf16* Bf
             }
 }
 
+// v5: one workgroup per CU with a 256 x 128 tile: 2 x 2 waves of 128 x 64 (4 x 2 MFMA tiles, 128 accumulator
+// registers); A split while staged into a double-buffered slab of 3 planes (123 KB of LDS), B straight from L2 two
+// k-steps ahead; per k-step and wave 48 MFMAs for 12 fragment reads and 6 B loads, one barrier per 96 MFMAs.
+constexpr int BM5 = 256;
+template <int TERMS>
+__global__ __launch_bounds__(256) void gemm5(const float* A, const __bf16* Bf, float* C, int M, int N, int K) {
+    extern __shared__ __attribute__((aligned(16))) float sm5[];
+    __bf16* As = reinterpret_cast<__bf16*>(sm5);             // [2][3][BM5 * P2]
+    constexpr int PL = BM5 * P2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * BM5, n0 = blockIdx.x * BN;
+    const int i32 = lane & 31, kh = lane >> 5;
+    const int ksteps = K / 16;
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    f32x4 ra[8];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int e = tid + 256 * i, row = e >> 3, q = e & 7;
+            ra[i] = *reinterpret_cast<const f32x4*>(A + (long long)(m0 + row) * K + k0 + 4 * q);
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int e = tid + 256 * i, row = e >> 3, q = e & 7;
+            unsigned h[4], m[4], l[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float v = ra[i][j];
+                const unsigned bh = __float_as_uint(v) & 0xffff0000u;
+                const float r1 = v - __uint_as_float(bh);
+                const unsigned bm = __float_as_uint(r1) & 0xffff0000u;
+                h[j] = bh; m[j] = bm; l[j] = __float_as_uint(r1 - __uint_as_float(bm));
+            }
+            __bf16* base = As + buf * 3 * PL + row * P2 + 4 * q;
+            unsigned* dh = reinterpret_cast<unsigned*>(base);
+            unsigned* dm = reinterpret_cast<unsigned*>(base + PL);
+            unsigned* dl = reinterpret_cast<unsigned*>(base + 2 * PL);
+            dh[0] = (h[0] >> 16) | h[1]; dh[1] = (h[2] >> 16) | h[3];
+            dm[0] = (m[0] >> 16) | m[1]; dm[1] = (m[2] >> 16) | m[3];
+            dl[0] = (l[0] >> 16) | (l[1] & 0xffff0000u); dl[1] = (l[2] >> 16) | (l[3] & 0xffff0000u);
+        }
+    };
+    const __bf16* bbase = Bf + ((long long)((n0 + wn * 64) / 32) * ksteps) * (3 * 64 * 8) + lane * 8;
+    auto bload = [&](int s_, bf16x8 (&bf)[3][2]) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                bf[pl][b] = *reinterpret_cast<const bf16x8*>(bbase + (((long long)b * ksteps + (s_ < ksteps ? s_ : 0)) * 3 + pl) * (64 * 8));
+    };
+    auto kstep = [&](int buf, int ks, const bf16x8 (&bf)[3][2]) {
+        bf16x8 af[3][4];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int a = 0; a < 4; ++a) af[pl][a] = *reinterpret_cast<const bf16x8*>(As + (buf * 3 + pl) * PL + (wm * 128 + a * 32 + i32) * P2 + ks * 16 + 8 * kh);
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                f32x16 c = acc[a][b];
+                if (TERMS == 9) {
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][a], bf[2][b], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][a], bf[2][b], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][a], bf[1][b], c, 0, 0, 0);
+                }
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][a], bf[2][b], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][a], bf[0][b], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][a], bf[1][b], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][a], bf[1][b], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][a], bf[0][b], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][a], bf[0][b], c, 0, 0, 0);
+                acc[a][b] = c;
+            }
+    };
+    gload(0);
+    lstore(0);
+    bf16x8 bx[3][2], by[3][2], bz[3][2];
+    bload(0, bx);
+    bload(1, by);
+    __syncthreads();
+    int buf = 0;
+    // stages of 2 k-steps; B sets rotate (x,y,z) -> (z,x,y) -> (y,z,x)
+    auto stage = [&](int k0, bf16x8 (&u0)[3][2], bf16x8 (&u1)[3][2], bf16x8 (&sp)[3][2]) {
+        const bool more = k0 + KC < K;
+        const int s_ = k0 / 16;
+        if (more) gload(k0 + KC);
+        bload(s_ + 2, sp);
+        kstep(buf, 0, u0);
+        bload(s_ + 3, u0);
+        kstep(buf, 1, u1);
+        if (more) lstore(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    };
+    for (int k0 = 0; k0 < K;) {
+        stage(k0, bx, by, bz); k0 += KC; if (k0 >= K) break;
+        stage(k0, bz, bx, by); k0 += KC; if (k0 >= K) break;
+        stage(k0, by, bz, bx); k0 += KC;
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 128 + a * 32 + 8 * (r / 4) + kh * 4 + (r % 4);
+                const int col = n0 + wn * 64 + b * 32 + i32;
+                C[(long long)row * N + col] = acc[a][b][r];
+            }
+}
+
 int main() {
     const int M = 8192, N = 4096, K = 1024;
     std::vector<float> hA((size_t)M * K), hB((size_t)N * K), hC((size_t)M * N);
@@ -491,9 +612,12 @@ int main() {
     if (getenv("TRACE")) CK(hipMemcpyToSymbol(HIP_SYMBOL(g_trace), &dtr, sizeof dtr));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm4<6>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BM * KCP4 * 4));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm4<9>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BM * KCP4 * 4));
-    for (int ver = 1; ver <= 4; ++ver)
+    const int lds5 = 2 * 3 * BM5 * P2 * 2;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm5<6>), hipFuncAttributeMaxDynamicSharedMemorySize, lds5));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm5<9>), hipFuncAttributeMaxDynamicSharedMemorySize, lds5));
+    for (int ver = 3; ver <= 5; ++ver)
     for (int terms : {6, 9}) {
-        const dim3 grid(N / BN, M / BM);
+        const dim3 grid(N / BN, M / (ver == 5 ? BM5 : BM));
         for (int rep = 0; rep < 3; ++rep) {
             CK(hipEventRecord(e0));
             for (int i = 0; i < 10; ++i) {
@@ -506,9 +630,12 @@ int main() {
                 } else if (ver == 3) {
                     if (terms == 6) hipLaunchKernelGGL(gemm3<6>, grid, dim3(256), 0, 0, A, Bf, C, M, N, K);
                     else hipLaunchKernelGGL(gemm3<9>, grid, dim3(256), 0, 0, A, Bf, C, M, N, K);
-                } else {
+                } else if (ver == 4) {
                     if (terms == 6) hipLaunchKernelGGL(gemm4<6>, grid, dim3(256), 2 * BM * KCP4 * 4, 0, A, Bf, C, M, N, K);
                     else hipLaunchKernelGGL(gemm4<9>, grid, dim3(256), 2 * BM * KCP4 * 4, 0, A, Bf, C, M, N, K);
+                } else {
+                    if (terms == 6) hipLaunchKernelGGL(gemm5<6>, grid, dim3(256), lds5, 0, A, Bf, C, M, N, K);
+                    else hipLaunchKernelGGL(gemm5<9>, grid, dim3(256), lds5, 0, A, Bf, C, M, N, K);
                 }
             }
             CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
