@@ -1130,7 +1130,7 @@ int encoder_fwd(ac_handle* h, hipStream_t st, const float* sig, const float* rel
     Act2 x, y;
     int rc;
     // a 32-channel ResBlock activates its raw input itself (rb_fused.h): no ELU'd flavour needed in HBM
-    auto rb_self_elu = [&](int C) { return C == 32 && c.residual_kernel_size == 3 && c.compress == 2; };
+    auto rb_self_elu = [&](int C) { return (C == 32 || C == 64) && c.residual_kernel_size == 3 && c.compress == 2; };
     if (thin_ok(c, c.kernel_size))
         rc = stem_fwd(h, st, sig, rel_len, B, T, Out{ws.take(), rb_self_elu(c.num_filters) ? nullptr : ws.take()}, &x);
     else
@@ -1187,7 +1187,7 @@ int decoder_fwd(ac_handle* h, hipStream_t st, const long long* toks, int B, int 
     x = y;
     for (int i = 0; i < c.num_ratios; ++i) {
         const int cup = h->dec_up[i].N / c.upsampling_ratios[i];
-        const bool self_elu = cup == 32 && c.residual_kernel_size == 3 && c.compress == 2;   // rb_fused.h activates raw rows itself
+        const bool self_elu = (cup == 32 || cup == 64) && c.residual_kernel_size == 3 && c.compress == 2;   // rb_fused.h activates raw rows itself
         rc = convtr_fwd(h, st, h->dec_up[i], x.elu, c.upsampling_ratios[i], Out{ws.take(), self_elu ? nullptr : ws.take()}, B, &y);
         if (rc) return rc;
         ws.give(x);
