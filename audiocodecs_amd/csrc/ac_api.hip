@@ -288,7 +288,7 @@ struct Packer {
     // tap_gemm6.h weight operand: exact truncation split of every weight into three bf16 terms, packed in MFMA
     // B-fragment order  [n-tile of 32][k-step of 16][plane][lane 64][8]
     void pack6(const PackedGemm& g) {
-        if (g.N % 64 || g.Ktot % 32 || h->w6_of.count(g.w_off)) return;
+        if ((g.N % 64 && g.N % 96) || g.Ktot % 32 || h->w6_of.count(g.w_off)) return;
         const size_t n_el = (size_t)g.N * g.Ktot;
         const size_t off = reserve((3 * n_el + 1) / 2);
         std::vector<uint16_t> planes(3 * n_el);
@@ -602,7 +602,7 @@ int run_tap(ac_handle* h, hipStream_t st, TapGemmParams& p) {
     const double bytes = inb + (double)p.B * p.M * p.N * 4.0 * ((p.y ? 1 : 0) + (p.y_elu ? 1 : 0)) + (double)p.N * p.Ktot * 4.0;
     // split-operand kernel on the bf16 pipe (tap_gemm6.h) where the shape allows and the weights were packed for it
     const __bf16* w6 = nullptr;
-    if (fast && !h->gemm_fp32 && p.N % 64 == 0) {
+    if (fast && !h->gemm_fp32 && (p.N % 64 == 0 || p.N % 96 == 0)) {
         auto it = h->w6_of.find((size_t)(p.w - h->blob));
         bool ok6 = it != h->w6_of.end();
         for (int i = 0; ok6 && i < p.nseg; ++i) ok6 = p.seg[i].kofs % 32 == 0;
@@ -626,19 +626,20 @@ int run_tap(ac_handle* h, hipStream_t st, TapGemmParams& p) {
         }                                                                                                   \
     } while (0)
     if (w6) {
-        const bool wide = p.N % 128 == 0;
         p.mtiles = cdiv(p.M, 128);
-        p.ntiles = p.N / (wide ? 128 : 64);
-        const long long blocks = (long long)p.B * p.mtiles * p.ntiles;
-        if (wide) {
-            if ((rc = ensure_lds(h, reinterpret_cast<const void*>(tap_gemm6_kernel<2>), Tap6Cfg<2>::lds_bytes))) return rc;
-            ProfScope ps(h, st, (std::string("tap_gemm6_kernel<2>") + shape).c_str(), flops, bytes);
-            hipLaunchKernelGGL(tap_gemm6_kernel<2>, dim3((unsigned)blocks), dim3(256), Tap6Cfg<2>::lds_bytes, st, p, w6);
-        } else {
-            if ((rc = ensure_lds(h, reinterpret_cast<const void*>(tap_gemm6_kernel<1>), Tap6Cfg<1>::lds_bytes))) return rc;
-            ProfScope ps(h, st, (std::string("tap_gemm6_kernel<1>") + shape).c_str(), flops, bytes);
-            hipLaunchKernelGGL(tap_gemm6_kernel<1>, dim3((unsigned)blocks), dim3(256), Tap6Cfg<1>::lds_bytes, st, p, w6);
-        }
+#define TAP6_CASE(WGM, WGN, WMT, WN)                                                                                    \
+    do {                                                                                                                \
+        using Cfg6 = Tap6Cfg<WGM, WGN, WMT, WN>;                                                                        \
+        p.ntiles = p.N / Cfg6::BN;                                                                                      \
+        const long long blocks = (long long)p.B * p.mtiles * p.ntiles;                                                  \
+        if ((rc = ensure_lds(h, reinterpret_cast<const void*>(tap_gemm6_kernel<WGM, WGN, WMT, WN>), Cfg6::lds_bytes))) return rc; \
+        ProfScope ps(h, st, (std::string("tap_gemm6_kernel<" #WGM ", " #WGN ", " #WMT ", " #WN ">") + shape).c_str(), flops, bytes); \
+        hipLaunchKernelGGL((tap_gemm6_kernel<WGM, WGN, WMT, WN>), dim3((unsigned)blocks), dim3(256), Cfg6::lds_bytes, st, p, w6);   \
+    } while (0)
+        if (p.N % 128 == 0) TAP6_CASE(2, 2, 2, 2);
+        else if (p.N % 96 == 0) TAP6_CASE(4, 1, 1, 3);
+        else TAP6_CASE(2, 2, 2, 1);
+#undef TAP6_CASE
         HIPCHK(h, hipGetLastError());
         return AC_OK;
     }

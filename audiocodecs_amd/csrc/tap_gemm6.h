@@ -12,7 +12,8 @@
 //     and loaded from L2 straight into registers one k-step ahead;
 //   * the activation operand is loaded exactly like in tap_gemm4 (buffer loads with per-slot constant offsets,
 //     clip-edge rules) and split ONCE, while it is staged into a double-buffered LDS slab of three bf16 planes.
-// Workgroup = 4 waves (2 x 2), wave tile 64 x 32*WN, BM = 128, BN = 64*WN, KC = 32 (two k-steps) per stage.
+// Workgroup = 4 waves as WGM x WGN, wave tile 32*WMT x 32*WN, BM = 128, KC = 32 (two k-steps) per stage:
+//   <2,2,2,2> BN = 128;  <2,2,2,1> BN = 64;  <4,1,1,3> BN = 96 (the 96 / 192-wide DAC layers).
 // Requirements beyond tap_gemm4's: N % 32 == 0 and every segment's kofs % 32 == 0 (k-steps align with stages).
 // The exact-product kernel tap_gemm4 stays selectable (environment AC_GEMM=fp32) and serves every other shape.
 #pragma once
@@ -25,9 +26,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int T6_PITCH = 40;        // bf16 per LDS row (32 + 8): 80-byte rows keep 16-byte alignment, spread banks
 
-template <int WN>
+template <int WGM, int WGN, int WMT, int WN>
 struct Tap6Cfg {
-    static constexpr int BM = 128, BN = 64 * WN, NT = 256;
+    static_assert(WGM * WGN == 4 && WGM * WMT == 4, "4 waves, 128 rows");
+    static constexpr int BM = 128, BN = 32 * WGN * WN, NT = 256;
     static constexpr int MAXJ = 8;
     static constexpr int A_ROWS = BM + MAXJ - 1;
     static constexpr int A_SLOTS = (A_ROWS * (KC / 4) + NT - 1) / NT;
@@ -38,16 +40,16 @@ struct Tap6Cfg {
     static constexpr size_t lds_bytes = main_bytes > epi_bytes ? main_bytes : epi_bytes;
 };
 
-template <int WN>
+template <int WGM, int WGN, int WMT, int WN>
 __global__ __launch_bounds__(256, 2) void tap_gemm6_kernel(const TapGemmParams p, const __bf16* __restrict__ wp) {
-    using Cfg = Tap6Cfg<WN>;
+    using Cfg = Tap6Cfg<WGM, WGN, WMT, WN>;
     constexpr int BM = Cfg::BM, BN = Cfg::BN, NT = Cfg::NT, A_SLOTS = Cfg::A_SLOTS, PLANE = Cfg::PLANE;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __bf16* As0 = reinterpret_cast<__bf16*>(smem);            // [2 buffers][3 planes][A_ROWS][T6_PITCH]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WGN, wn = wave % WGN;
     const int i32 = lane & 31, kh = lane >> 5;                // MFMA operand: row / column i32, k = 8*kh .. 8*kh + 7
 
     int id;
@@ -60,9 +62,9 @@ __global__ __launch_bounds__(256, 2) void tap_gemm6_kernel(const TapGemmParams p
     const int b = id / p.mtiles;
     const int m0 = mt * BM, n0 = nt * BN;
 
-    f32x16 acc[2][WN];
+    f32x16 acc[WMT][WN];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < WMT; ++a)
 #pragma unroll
         for (int c = 0; c < WN; ++c)
 #pragma unroll
@@ -187,16 +189,16 @@ __global__ __launch_bounds__(256, 2) void tap_gemm6_kernel(const TapGemmParams p
     store_a(As0);
     __syncthreads();
     int abuf = 0;
-    const int a_frag = (wm * 64 + i32) * T6_PITCH + 8 * kh;    // + (a*32 + j)*T6_PITCH + ks*16, + plane*PLANE
-    auto read_a = [&](const __bf16* Ac, int ks, bf16x8 (&af)[3][2]) {
+    const int a_frag = (wm * WMT * 32 + i32) * T6_PITCH + 8 * kh;    // + (a*32 + j)*T6_PITCH + ks*16, + plane*PLANE
+    auto read_a = [&](const __bf16* Ac, int ks, bf16x8 (&af)[3][WMT]) {
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
-            for (int a = 0; a < 2; ++a) af[pl][a] = *reinterpret_cast<const bf16x8*>(Ac + pl * PLANE + a * 32 * T6_PITCH + ks * 16);
+            for (int a = 0; a < WMT; ++a) af[pl][a] = *reinterpret_cast<const bf16x8*>(Ac + pl * PLANE + a * 32 * T6_PITCH + ks * 16);
     };
-    auto mfma_step = [&](const bf16x8 (&af)[3][2], const bf16x8 (&bf)[3][WN]) {
+    auto mfma_step = [&](const bf16x8 (&af)[3][WMT], const bf16x8 (&bf)[3][WN]) {
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < WMT; ++a)
 #pragma unroll
             for (int c = 0; c < WN; ++c) {
                 f32x16 v = acc[a][c];
@@ -231,7 +233,7 @@ __global__ __launch_bounds__(256, 2) void tap_gemm6_kernel(const TapGemmParams p
             if (new_chunk) load_a(nsi, nc0, nj);
         }
         const __bf16* Ac = As0 + abuf * 3 * PLANE + a_frag + cur_j * T6_PITCH;
-        bf16x8 af0[3][2], af1[3][2];
+        bf16x8 af0[3][WMT], af1[3][WMT];
         read_a(Ac, 0, af0);
         read_a(Ac, 1, af1);                                    // the second k-step's fragments travel under the first one's MFMAs
         mfma_step(af0, u0);
@@ -257,13 +259,13 @@ __global__ __launch_bounds__(256, 2) void tap_gemm6_kernel(const TapGemmParams p
     float* Cs = smem;
     constexpr int CP = Cfg::CP;
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < WMT; ++a)
 #pragma unroll
         for (int c = 0; c < WN; ++c) {
             const int n = (wn * WN + c) * 32 + i32;
             const float bv = (p.bias && n0 + n < p.N) ? p.bias[n0 + n] : 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) Cs[(wm * 64 + a * 32 + 8 * (r / 4) + 4 * kh + (r % 4)) * CP + n] = acc[a][c][r] + bv;
+            for (int r = 0; r < 16; ++r) Cs[((wm * WMT + a) * 32 + 8 * (r / 4) + 4 * kh + (r % 4)) * CP + n] = acc[a][c][r] + bv;
         }
     __syncthreads();
     const long long yoff = (long long)b * p.y_bs;
