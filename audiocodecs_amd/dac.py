@@ -106,6 +106,10 @@ class _NativeDac:
 
     def __del__(self):
         try:
+            import sys
+
+            if sys.is_finalizing():   # interpreter shutdown: the HIP runtime may already be gone, the OS reclaims the rest
+                return
             if getattr(self, "h", None):
                 self.lib.ac_destroy(self.h)
                 self.h = None

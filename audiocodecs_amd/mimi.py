@@ -63,6 +63,10 @@ class _NativeMimi:
 
     def __del__(self):
         try:
+            import sys
+
+            if sys.is_finalizing():   # interpreter shutdown: the HIP runtime may already be gone, the OS reclaims the rest
+                return
             if getattr(self, "h", None):
                 self.lib.ac_destroy(self.h)
                 self.h = None
