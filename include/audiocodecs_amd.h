@@ -20,8 +20,11 @@
  *    ac_last_error() returns a human-readable message for the last failure on that handle;
  *  - a handle is not thread-safe; one handle per process/GPU like the reference's one codec/rank;
  *    the handle's device (ac_config.device) must be the current HIP device when its entry points run;
- *  - activations are fp32 ("parity mode": fp32 MFMA v_mfma_f32_16x16x4_f32, exact fp32 products and
- *    accumulation); tokens are int64 like the reference's.
+ *  - activations, weights and results are fp32, accumulation is fp32, tokens are int64 like the reference's.  The
+ *    large GEMMs and the LSTM products run "split-operand" arithmetic on the bf16 matrix pipe: every fp32 operand is
+ *    written exactly as three bf16 terms and 6 of the 9 exact partial products are accumulated in fp32 (error equal
+ *    to fp32 arithmetic); the environment variable AC_GEMM=fp32 selects kernels with exact fp32
+ *    products (v_mfma_f32_16x16x4_f32) instead.
  */
 #ifndef AUDIOCODECS_AMD_H
 #define AUDIOCODECS_AMD_H
