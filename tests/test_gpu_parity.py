@@ -232,3 +232,27 @@ def test_persistent_and_per_step_lstm_agree(checkpoints, monkeypatch):
     assert rms((ra - rb).cpu().numpy()) < 2e-6
     big = noise(4243, 70, 3200).cuda()          # 70 clips: two cooperative launches (64 + 6)
     assert rms((fast.sig_to_feats(big) - slow.sig_to_feats(big)).cpu().numpy()) < 2e-6
+
+
+def test_split_operand_and_exact_product_kernels_agree(checkpoints, golden, monkeypatch):
+    """Default: GEMMs / LSTM products in split-operand arithmetic on the bf16 pipe (tap_gemm6.h, lstm_persist6.h).
+    AC_GEMM=fp32: exact fp32 products (tap_gemm4.h, lstm_persist.h).  Same function up to fp32-level rounding, and the
+    exact-product build also reproduces the reference's tokens."""
+    from audiocodecs_amd import Encodec
+
+    z, meta = golden
+    cfg, sd = checkpoints("full", 0)
+    sig = noise(5151, 3, 24000).cuda()
+    fast = Encodec(24000, num_codebooks=8, state_dict=sd, config=cfg).eval()
+    fa, ta = fast.sig_to_feats(sig), fast.sig_to_toks(sig)
+    monkeypatch.setenv("AC_GEMM", "fp32")
+    exact = Encodec(24000, num_codebooks=8, state_dict=sd, config=cfg).eval()
+    fb, tb = exact.sig_to_feats(sig), exact.sig_to_toks(sig)
+    assert rms((fa - fb).cpu().numpy()) < 3e-6
+    assert float((ta == tb).float().mean()) > 0.995
+    assert rms((fast.toks_to_sig(ta) - exact.toks_to_sig(ta)).cpu().numpy()) < 3e-6
+    case = next(c for c in CASES if c["name"] == "full_noise_b2")
+    inp = make_input(case, GOLDEN_DIR)
+    toks = exact.sig_to_toks(inp["sig"].cuda())
+    n, bad, excused = tokens_match_up_to_ties(toks.cpu().numpy(), z["full_noise_b2.toks"].astype(np.int64), z["full_noise_b2.margin64"])
+    assert bad == 0
