@@ -22,6 +22,7 @@
 #include "tap_gemm6.h"
 #include "thin.h"
 #include "rb_fused.h"
+#include "rb_fused6.h"
 #include "mimi.h"
 #include "dac.h"
 
@@ -44,6 +45,8 @@ struct ResBlockPlan {
     int C;
     PackedGemm c3;     // k3 conv C -> C/2
     PackedGemm fused;  // [ELU(h) | x] * [W1; Ws] + (b1 + bs)
+    size_t w3f_off = 0, wff_off = 0;   // rb_fused6.h fragment images of the two matrices (float offsets into the blob)
+    bool has6 = false;
 };
 
 struct LstmPlan {
@@ -320,6 +323,62 @@ struct Packer {
         std::memcpy(&blob[off], planes.data(), planes.size() * 2);
         h->w6_of[g.w_off] = off;
     }
+    // exact truncation split of one weight into three bf16 terms (tap_gemm6.h)
+    static void split3h(float v, uint16_t (&o)[3]) {
+        uint32_t b;
+        std::memcpy(&b, &v, 4);
+        const uint32_t bh = b & 0xffff0000u;
+        float fh;
+        std::memcpy(&fh, &bh, 4);
+        const float r1 = v - fh;
+        uint32_t b1;
+        std::memcpy(&b1, &r1, 4);
+        const uint32_t bm = b1 & 0xffff0000u;
+        float fm;
+        std::memcpy(&fm, &bm, 4);
+        const float r2 = r1 - fm;
+        uint32_t b2;
+        std::memcpy(&b2, &r2, 4);
+        o[0] = (uint16_t)(bh >> 16);
+        o[1] = (uint16_t)(bm >> 16);
+        o[2] = (uint16_t)(b2 >> 16);
+    }
+    // v_mfma_f32_16x16x32_bf16 operand fragments of a row-major [N][Ksrc] matrix in the blob:
+    //   [n-tile of 16][k-step of 32][plane 3][lane 64][8 bf16],  lane (n = lane & 15, k = 8 * (lane >> 4) + e);
+    // kmap[k'] = source column of padded column k', or -1 for a zero column
+    size_t frag16(size_t src_off, int N, int Ksrc, const std::vector<int>& kmap) {
+        const int ksteps = (int)kmap.size() / 32;
+        const size_t n_el = (size_t)N * kmap.size();
+        const size_t off = reserve((3 * n_el + 1) / 2);
+        std::vector<uint16_t> planes(3 * n_el);
+        for (int nt = 0; nt < N / 16; ++nt)
+            for (int s = 0; s < ksteps; ++s)
+                for (int l = 0; l < 64; ++l)
+                    for (int e = 0; e < 8; ++e) {
+                        const int k = kmap[s * 32 + 8 * (l >> 4) + e];
+                        uint16_t t[3] = {0, 0, 0};
+                        if (k >= 0) split3h(blob[src_off + (size_t)(nt * 16 + (l & 15)) * Ksrc + k], t);
+                        const size_t base = (((size_t)nt * ksteps + s) * 3) * 512 + (size_t)l * 8 + e;
+                        planes[base] = t[0];
+                        planes[base + 512] = t[1];
+                        planes[base + 1024] = t[2];
+                    }
+        std::memcpy(&blob[off], planes.data(), planes.size() * 2);
+        return off;
+    }
+    // rb_fused6.h images of a residual block (k3 conv C -> C/2, then [1x1 over the hidden | optional shortcut over x])
+    void rb6(ResBlockPlan& rb, bool sc) {
+        const int C = rb.C, hid = C / 2;
+        if ((C != 32 && C != 64) || rb.c3.N != hid || rb.c3.Ktot != 3 * C || rb.fused.N != C || rb.fused.Ktot != hid + (sc ? C : 0)) return;
+        std::vector<int> k3(3 * C), kf;
+        for (int k = 0; k < 3 * C; ++k) k3[k] = k;
+        const int hcp = hid < 32 ? 32 : hid;
+        for (int k = 0; k < hcp; ++k) kf.push_back(k < hid ? k : -1);
+        for (int k = 0; sc && k < C; ++k) kf.push_back(hid + k);
+        rb.w3f_off = frag16(rb.c3.w_off, hid, rb.c3.Ktot, k3);
+        rb.wff_off = frag16(rb.fused.w_off, C, rb.fused.Ktot, kf);
+        rb.has6 = true;
+    }
     // plain conv (stride 1 or k = 2*stride): packed[n][tap*cin + ci] = w[n][ci][tap]
     bool conv(const ConvSpec& s, PackedGemm& g, bool bias = true) {
         std::vector<float> w;
@@ -382,6 +441,7 @@ struct Packer {
         rb.fused.b_off = reserve(C);
         for (int n = 0; n < C; ++n) blob[rb.fused.b_off + n] = (*b1)[n] + (*bs)[n];
         pack6(rb.fused);
+        rb6(rb, true);
         return true;
     }
     bool lstm(const std::string& prefix, int D, int layers, LstmPlan& lp) {
@@ -739,13 +799,44 @@ int launch_rb_fused(ac_handle* h, hipStream_t st, const ResBlockPlan& rb, const 
     return AC_OK;
 }
 
+// split-operand version of the fused block (rb_fused6.h); reads the raw rows only and activates them itself
+template <int C, bool SC>
+int launch_rb_fused6(ac_handle* h, hipStream_t st, const ResBlockPlan& rb, const Act2& x, Out out, int B, int pad = PAD_REFLECT) {
+    using Cfg = Rb6Cfg<C, SC>;
+    RbFused6Params p{};
+    p.xr = x.raw.p;
+    p.w3f = reinterpret_cast<const __bf16*>(h->blob + rb.w3f_off);
+    p.wff = reinterpret_cast<const __bf16*>(h->blob + rb.wff_off);
+    p.b3 = h->blob + rb.c3.b_off;
+    p.bf = h->blob + rb.fused.b_off;
+    p.y = out.raw;
+    p.y_elu = out.elu;
+    p.B = B;
+    p.L = x.raw.L;
+    p.Lp = x.raw.L > 2 ? x.raw.L : 3;
+    p.ntiles = cdiv(x.raw.L, Cfg::BM);
+    p.pad = pad;
+    if (int rc = ensure_lds(h, reinterpret_cast<const void*>(rb_fused6_kernel<C, SC>), Cfg::lds_bytes)) return rc;
+    const long long total = (long long)B * p.ntiles;
+    const int per_cu = C == 64 ? 2 : 3;
+    const int grid = (int)std::min<long long>(total, (long long)per_cu * 256);   // persistent
+    const double L = x.raw.L;
+    ProfScope ps(h, st, !SC ? "rb_fused6_kernel<64, false>" : C == 32 ? "rb_fused6_kernel<32, true>" : "rb_fused6_kernel<64, true>",
+                 2.0 * B * L * ((double)(C / 2) * 3 * C + (double)C * (C / 2 + (SC ? C : 0))),
+                 (double)B * L * C * 4.0 * (1 + (out.raw ? 1 : 0) + (out.elu ? 1 : 0)));
+    hipLaunchKernelGGL((rb_fused6_kernel<C, SC>), dim3(grid), dim3(256), Cfg::lds_bytes, st, p);
+    return AC_OK;
+}
+
 // ResBlock: hbuf = ELU(conv3(ELU(x)));  out = [hbuf | x] * [W1; Ws] + (b1 + bs)
 int resblock_fwd(ac_handle* h, hipStream_t st, const ResBlockPlan& rb, const Act2& x, float* hbuf, Out out, int B, Act2* y) {
     // thin stages: one fused kernel, hidden activation never leaves the CU
     if ((rb.C == 32 || rb.C == 64) && h->cfg.residual_kernel_size == 3 && h->cfg.compress == 2 && x.raw.ts == rb.C &&
         x.raw.bs == (long long)x.raw.L * rb.C && aligned16(x.raw.p) &&
         (!x.elu.p || (x.elu.ts == rb.C && x.elu.bs == x.raw.bs && aligned16(x.elu.p)))) {
-        int rc = rb.C == 32 ? launch_rb_fused<32, 128, 1>(h, st, rb, x, out, B) : launch_rb_fused<64, 64, 2>(h, st, rb, x, out, B);   // <C, rows per tile, column split>
+        int rc;
+        if (rb.has6 && !h->gemm_fp32) rc = rb.C == 32 ? launch_rb_fused6<32, true>(h, st, rb, x, out, B) : launch_rb_fused6<64, true>(h, st, rb, x, out, B);
+        else rc = rb.C == 32 ? launch_rb_fused<32, 128, 1>(h, st, rb, x, out, B) : launch_rb_fused<64, 64, 2>(h, st, rb, x, out, B);   // <C, rows per tile, column split>
         if (rc) return rc;
         HIPCHK(h, hipGetLastError());
         const long long bs = (long long)x.raw.L * rb.C;

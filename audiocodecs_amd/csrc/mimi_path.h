@@ -89,7 +89,8 @@ int mimi_resblock(ac_handle* h, hipStream_t st, const ResBlockPlan& rb, const Ac
     const long long bs = (long long)x.raw.L * rb.C;
     if (rb.C == 64 && c.residual_kernel_size == 3 && c.compress == 2 && x.raw.ts == rb.C && x.raw.bs == bs && aligned16(x.raw.p) &&
         (!x.elu.p || (x.elu.ts == rb.C && x.elu.bs == bs && aligned16(x.elu.p)))) {
-        int rc = launch_rb_fused<64, 64, 2, false>(h, st, rb, x, out, B, PAD_ZERO);
+        int rc = rb.has6 && !h->gemm_fp32 ? launch_rb_fused6<64, false>(h, st, rb, x, out, B, PAD_ZERO)
+                                          : launch_rb_fused<64, 64, 2, false>(h, st, rb, x, out, B, PAD_ZERO);
         if (rc) return rc;
         HIPCHK(h, hipGetLastError());
         y->raw = Act{out.raw, bs, rb.C, x.raw.L, rb.C};
@@ -421,8 +422,11 @@ int mimi_finalize(ac_handle* h, Packer& pk) {
     auto resblock = [&](const std::string& pre, int ch, ResBlockPlan& rb) {
         rb.C = ch;
         const int hid = ch / c.compress;
-        return pk.conv(ConvSpec{pre + ".block.1.conv", 0, ch, hid, c.residual_kernel_size, 1}, rb.c3) &&
-               pk.conv(ConvSpec{pre + ".block.3.conv", 0, hid, ch, 1, 1}, rb.fused);
+        if (!pk.conv(ConvSpec{pre + ".block.1.conv", 0, ch, hid, c.residual_kernel_size, 1}, rb.c3) ||
+            !pk.conv(ConvSpec{pre + ".block.3.conv", 0, hid, ch, 1, 1}, rb.fused))
+            return false;
+        if (c.residual_kernel_size == 3 && c.compress == 2) pk.rb6(rb, false);
+        return true;
     };
     int i = 1, ch = F;
     for (int r = n - 1, j = 0; ok && r >= 0; --r, ++j) {

@@ -1,0 +1,243 @@
+// rb_fused6: the fused SEANet residual block of rb_fused.h (same block, same padding rules, same tile walk)
+//     y = shortcut(x) + conv_1x1(ELU(conv_k3(ELU(x))))
+// in split-operand arithmetic on the bf16 matrix pipe (tap_gemm6.h: every fp32 value = hi + mid + lo, three exact
+// bf16 terms; 6 of the 9 exact partial products, fp32 accumulate).  rb_fused.h runs at 0.45-0.57 of the fp32-MFMA
+// peak and is bound by it; the same products cost 0.375x on v_mfma_f32_16x16x32_bf16.
+//   * x is read ONCE per tile (raw rows; ELU is applied while staging), split once, and kept in LDS as bf16 planes:
+//     Xe = ELU(x) with the 2-row causal halo for the k3 conv, Xr = raw rows for the shortcut conv;
+//   * weights: split offline, packed in MFMA fragment order, register-resident for the whole kernel
+//       w3f[n-tile of 16][k-step of 32][plane 3][lane 64][8 bf16]      k = tap * C + ci
+//       wff[n-tile of 16][k-step of 32][plane 3][lane 64][8 bf16]      k = hidden (zero-padded to 32) | x
+//   * the MFMA computes the TRANSPOSED tile (M = output channels from the weight fragment, N = 16 time rows from
+//     the x fragment), so a lane's 4 accumulator registers are 4 CONSECUTIVE channels of one time row: the hidden
+//     activation goes back to LDS as one 8-byte store per plane, the block output straight to HBM as 16-byte stores
+//     (no output tile in LDS, no barrier around it).
+// Workgroup = 4 waves, 64 time rows per tile; C = 64: waves split the output channels two ways (their share of the
+// weights is 144 VGPRs), C = 32: every wave owns 16 rows and all channels (no barrier between the two stages).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "tap_gemm6.h"
+
+namespace ac {
+
+struct RbFused6Params {
+    const float* xr;        // [B][L][C] raw input
+    const __bf16* w3f;      // fragment-packed k3 conv
+    const __bf16* wff;      // fragment-packed [1x1 over the hidden | shortcut over x]
+    const float* b3;        // [C/2]
+    const float* bf;        // [C]  (b_1x1 + b_shortcut)
+    float* y;               // optional raw output [B][L][C]
+    float* y_elu;           // optional ELU'd output
+    int B, L, Lp;           // Lp: reflect base length (L, or 3 when L <= 2: [HF]:148-155)
+    int ntiles;             // tiles per clip
+    int pad;                // PAD_REFLECT (EnCodec) / PAD_ZERO (Mimi)
+};
+
+template <int C, bool SC>
+struct Rb6Cfg {
+    static constexpr int BM = 64;
+    static constexpr int HC = C / 2, HCP = HC < 32 ? 32 : HC;          // hidden width, padded to one k-step
+    static constexpr int NSPLIT = C / 32;                               // waves along the output channels
+    static constexpr int MW = 4 / NSPLIT;                               // wave groups along time
+    static constexpr int MS = BM / MW / 16;                             // 16-row time tiles per wave
+    static constexpr int NA = HC / NSPLIT / 16, NB = C / NSPLIT / 16;   // 16-channel tiles per wave (stage A / B)
+    static constexpr int KSA = 3 * C / 32;                              // k-steps of stage A
+    static constexpr int KSH = HCP / 32, KSB = KSH + (SC ? C / 32 : 0); // k-steps of stage B: hidden, then x
+    static constexpr int XP = C + 8, HP = HCP + 8;                      // LDS row pitches in bf16 (16-byte multiples, banks spread)
+    static constexpr int XE_ROWS = BM + 2;
+    static constexpr int XE_PLANE = XE_ROWS * XP, XR_PLANE = SC ? BM * XP : 0, H_PLANE = BM * HP;
+    static constexpr int SLOTS = (XE_ROWS * (C / 4) + 255) / 256;
+    static constexpr size_t lds_bytes = (size_t)3 * (XE_PLANE + XR_PLANE + H_PLANE) * 2;
+};
+
+// exact truncation split, value bits left in the upper half of each word
+__device__ __forceinline__ void split3(float v, unsigned& h, unsigned& m, unsigned& l) {
+    h = __float_as_uint(v) & 0xffff0000u;
+    const float r1 = v - __uint_as_float(h);
+    m = __float_as_uint(r1) & 0xffff0000u;
+    l = __float_as_uint(r1 - __uint_as_float(m));
+}
+
+// 4 fp32 -> 4 bf16 per plane, stored as 8 bytes at element offset `o` of each plane
+__device__ __forceinline__ void split_store4(const f32x4 v, __bf16* p0, int plane, int o) {
+    unsigned h[4], m[4], l[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) split3(v[i], h[i], m[i], l[i]);
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    *reinterpret_cast<u32x2*>(p0 + o) = u32x2{(h[0] >> 16) | h[1], (h[2] >> 16) | h[3]};
+    *reinterpret_cast<u32x2*>(p0 + plane + o) = u32x2{(m[0] >> 16) | m[1], (m[2] >> 16) | m[3]};
+    *reinterpret_cast<u32x2*>(p0 + 2 * plane + o) = u32x2{(l[0] >> 16) | (l[1] & 0xffff0000u), (l[2] >> 16) | (l[3] & 0xffff0000u)};
+}
+
+// acc (+)= W x^T over one k-step: 6 partial products, small terms first.  w / x: [plane]
+__device__ __forceinline__ f32x4 mma6(const bf16x8 (&w)[3], const bf16x8 (&x)[3], f32x4 v) {
+    v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[2], x[0], v, 0, 0, 0);   // l h
+    v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[0], x[2], v, 0, 0, 0);   // h l
+    v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[1], x[1], v, 0, 0, 0);   // m m
+    v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[1], x[0], v, 0, 0, 0);   // m h
+    v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[0], x[1], v, 0, 0, 0);   // h m
+    v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[0], x[0], v, 0, 0, 0);   // h h
+    return v;
+}
+
+template <int C, bool SC>
+__global__ __launch_bounds__(256, C == 64 ? 2 : 3) void rb_fused6_kernel(const RbFused6Params p) {
+    using Cfg = Rb6Cfg<C, SC>;
+    constexpr int BM = Cfg::BM, HC = Cfg::HC, XP = Cfg::XP, HP = Cfg::HP;
+    constexpr int MS = Cfg::MS, NA = Cfg::NA, NB = Cfg::NB, KSA = Cfg::KSA, KSH = Cfg::KSH, KSB = Cfg::KSB;
+    constexpr int NSPLIT = Cfg::NSPLIT, SLOTS = Cfg::SLOTS;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __bf16* Xe = reinterpret_cast<__bf16*>(smem);                  // [3][XE_ROWS][XP]
+    __bf16* Xr = Xe + 3 * Cfg::XE_PLANE;                           // [3][BM][XP]       (SC only)
+    __bf16* Hs = Xr + 3 * Cfg::XR_PLANE;                           // [3][BM][HP]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int mg = wave / NSPLIT, ng = wave % NSPLIT;
+    const int li = lane & 15, kq = lane >> 4;
+    const int total = p.B * p.ntiles;
+    const int r0 = mg * (BM / Cfg::MW);                            // this wave's first time row in the tile
+    const int na0 = ng * NA * 16, nb0 = ng * NB * 16;              // this wave's first output channel (stage A / B)
+
+    // ---- this wave's weight fragments -> registers (once)
+    bf16x8 w3r[KSA][NA][3], wfr[KSB][NB][3];
+    f32x4 b3v[NA], bfv[NB];
+#pragma unroll
+    for (int c = 0; c < NA; ++c) {
+        b3v[c] = *reinterpret_cast<const f32x4*>(p.b3 + na0 + c * 16 + 4 * kq);
+#pragma unroll
+        for (int ks = 0; ks < KSA; ++ks)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                w3r[ks][c][pl] = *reinterpret_cast<const bf16x8*>(p.w3f + ((((long long)(na0 / 16 + c) * KSA + ks) * 3 + pl) * 64 + lane) * 8);
+    }
+#pragma unroll
+    for (int c = 0; c < NB; ++c) {
+        bfv[c] = *reinterpret_cast<const f32x4*>(p.bf + nb0 + c * 16 + 4 * kq);
+#pragma unroll
+        for (int ks = 0; ks < KSB; ++ks)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                wfr[ks][c][pl] = *reinterpret_cast<const bf16x8*>(p.wff + ((((long long)(nb0 / 16 + c) * KSB + ks) * 3 + pl) * 64 + lane) * 8);
+    }
+    // hidden columns HC .. HCP-1 (C = 32) are K padding: zero once, the matching weight fragments are zero too
+    if (HC < Cfg::HCP)
+        for (int e = tid; e < 3 * BM * (Cfg::HCP - HC); e += 256) {
+            const int pl = e / (BM * (Cfg::HCP - HC)), r = e % (BM * (Cfg::HCP - HC));
+            Hs[pl * Cfg::H_PLANE + (r / (Cfg::HCP - HC)) * HP + HC + r % (Cfg::HCP - HC)] = (__bf16)0.f;
+        }
+
+    f32x4 rx[SLOTS];
+    auto load_tile = [&](int tile) {
+        const int b = tile / p.ntiles, t0 = (tile % p.ntiles) * BM;
+        const float* xr = p.xr + (long long)b * p.L * C;
+#pragma unroll
+        for (int i = 0; i < SLOTS; ++i) {
+            const int e = tid + i * 256;
+            const int row = e / (C / 4), q = e % (C / 4);
+            rx[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (row < Cfg::XE_ROWS) {
+                int j = t0 - 2 + row;                            // causal pad of 2: reflect ([HF]:157-176) or zeros
+                if (p.pad == PAD_REFLECT) j = j < 0 ? -j : (j >= p.Lp ? 2 * (p.Lp - 1) - j : j);
+                if (j >= 0 && j < p.L) rx[i] = *reinterpret_cast<const f32x4*>(xr + (long long)j * C + 4 * q);
+            }
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < SLOTS; ++i) {
+            const int e = tid + i * 256;
+            const int row = e / (C / 4), q = e % (C / 4);
+            if (row < Cfg::XE_ROWS) {
+                split_store4(elu4(rx[i]), Xe, Cfg::XE_PLANE, row * XP + 4 * q);
+                // rows 2.. of the slab are the tile's own rows (never reflected: their source index is t0 + row - 2 >= 0)
+                if (SC && row >= 2) split_store4(rx[i], Xr, Cfg::XR_PLANE, (row - 2) * XP + 4 * q);
+            }
+        }
+    };
+
+    int tile = blockIdx.x;
+    if (tile >= total) return;
+    load_tile(tile);
+    store_tile();
+    __syncthreads();
+    for (; tile < total; tile += gridDim.x) {
+        const int next = tile + gridDim.x;
+        if (next < total) load_tile(next);                      // in flight during both MFMA stages
+        // ---- stage A: hidden = ELU(conv_k3(xe) + b3) -> Hs planes
+        {
+            f32x4 acc[MS][NA];
+#pragma unroll
+            for (int a = 0; a < MS; ++a)
+#pragma unroll
+                for (int c = 0; c < NA; ++c) acc[a][c] = b3v[c];
+#pragma unroll
+            for (int ks = 0; ks < KSA; ++ks) {
+                const int j = ks / (C / 32), kc = ks % (C / 32);
+                bf16x8 xf[MS][3];
+#pragma unroll
+                for (int a = 0; a < MS; ++a)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl)
+                        xf[a][pl] = *reinterpret_cast<const bf16x8*>(Xe + pl * Cfg::XE_PLANE + (r0 + a * 16 + li + j) * XP + kc * 32 + 8 * kq);
+#pragma unroll
+                for (int a = 0; a < MS; ++a)
+#pragma unroll
+                    for (int c = 0; c < NA; ++c) acc[a][c] = mma6(w3r[ks][c], xf[a], acc[a][c]);
+            }
+#pragma unroll
+            for (int a = 0; a < MS; ++a)
+#pragma unroll
+                for (int c = 0; c < NA; ++c)
+                    split_store4(elu4(acc[a][c]), Hs, Cfg::H_PLANE, (r0 + a * 16 + li) * HP + na0 + c * 16 + 4 * kq);
+        }
+        if (NSPLIT > 1) __syncthreads();                        // C = 32: a wave reads back only its own rows
+        // ---- stage B: y = [W1 | Ws] * [hidden | x]^T + bf
+        f32x4 acc[MS][NB];
+#pragma unroll
+        for (int a = 0; a < MS; ++a)
+#pragma unroll
+            for (int c = 0; c < NB; ++c) acc[a][c] = bfv[c];
+#pragma unroll
+        for (int ks = 0; ks < KSB; ++ks) {
+            bf16x8 xf[MS][3];
+#pragma unroll
+            for (int a = 0; a < MS; ++a)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    xf[a][pl] = ks < KSH ? *reinterpret_cast<const bf16x8*>(Hs + pl * Cfg::H_PLANE + (r0 + a * 16 + li) * HP + ks * 32 + 8 * kq)
+                                         : *reinterpret_cast<const bf16x8*>(Xr + pl * Cfg::XR_PLANE + (r0 + a * 16 + li) * XP + (ks - KSH) * 32 + 8 * kq);
+#pragma unroll
+            for (int a = 0; a < MS; ++a)
+#pragma unroll
+                for (int c = 0; c < NB; ++c) acc[a][c] = mma6(wfr[ks][c], xf[a], acc[a][c]);
+        }
+        // ---- output: lane (li, kq) holds channels nb0 + 16c + 4kq .. +3 of time row r0 + 16a + li
+        {
+            const int b = tile / p.ntiles, t0 = (tile % p.ntiles) * BM;
+            const long long ob = (long long)b * p.L * C;
+#pragma unroll
+            for (int a = 0; a < MS; ++a) {
+                const int t = t0 + r0 + a * 16 + li;
+                if (t < p.L) {
+#pragma unroll
+                    for (int c = 0; c < NB; ++c) {
+                        const long long o = ob + (long long)t * C + nb0 + c * 16 + 4 * kq;
+                        f32x4 v = acc[a][c];
+                        if (!SC) {                               // identity shortcut: x + block(x)
+                            const f32x4 xv = *reinterpret_cast<const f32x4*>(p.xr + o);
+                            v = f32x4{__fadd_rn(xv.x, v.x), __fadd_rn(xv.y, v.y), __fadd_rn(xv.z, v.z), __fadd_rn(xv.w, v.w)};
+                        }
+                        if (p.y) *reinterpret_cast<f32x4*>(p.y + o) = v;
+                        if (p.y_elu) *reinterpret_cast<f32x4*>(p.y_elu + o) = elu4(v);
+                    }
+                }
+            }
+        }
+        __syncthreads();                                        // every wave is done reading the slabs
+        if (next < total) store_tile();
+        __syncthreads();
+    }
+}
+
+}  // namespace ac
