@@ -816,6 +816,7 @@ int launch_rb_fused6(ac_handle* h, hipStream_t st, const ResBlockPlan& rb, const
     p.Lp = x.raw.L > 2 ? x.raw.L : 3;
     p.ntiles = cdiv(x.raw.L, Cfg::BM);
     p.pad = pad;
+    if (const char* d = std::getenv("AC_RB6_DBG")) p.dbg = std::atoi(d);
     if (int rc = ensure_lds(h, reinterpret_cast<const void*>(rb_fused6_kernel<C, SC>), Cfg::lds_bytes)) return rc;
     const long long total = (long long)B * p.ntiles;
     const int per_cu = C == 64 ? 2 : 3;

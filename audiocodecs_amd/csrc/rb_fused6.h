@@ -31,6 +31,8 @@ struct RbFused6Params {
     int B, L, Lp;           // Lp: reflect base length (L, or 3 when L <= 2: [HF]:148-155)
     int ntiles;             // tiles per clip
     int pad;                // PAD_REFLECT (EnCodec) / PAD_ZERO (Mimi)
+    int dbg;                // developer timing modes (AC_RB6_DBG): 1 no stage-A MFMAs, 2 no stage-B MFMAs, 4 no staging,
+                            // 8 no output stores, 16 no loads -- results are wrong in every mode but 0
 };
 
 template <int C, bool SC>
@@ -49,6 +51,8 @@ struct Rb6Cfg {
     static constexpr int SLOTS = (XE_ROWS * (C / 4) + 255) / 256;
     static constexpr size_t lds_bytes = (size_t)3 * (XE_PLANE + XR_PLANE + H_PLANE) * 2;
 };
+
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 
 // exact truncation split, value bits left in the upper half of each word
 __device__ __forceinline__ void split3(float v, unsigned& h, unsigned& m, unsigned& l) {
@@ -127,27 +131,31 @@ __global__ __launch_bounds__(256, C == 64 ? 2 : 3) void rb_fused6_kernel(const R
             Hs[pl * Cfg::H_PLANE + (r / (Cfg::HCP - HC)) * HP + HC + r % (Cfg::HCP - HC)] = (__bf16)0.f;
         }
 
+    // per-slot constants: slab row / column group of this thread; rows beyond the slab never load (offset out of range)
+    int s_row[SLOTS], s_q4[SLOTS];
+#pragma unroll
+    for (int i = 0; i < SLOTS; ++i) {
+        const int e = tid + i * 256;
+        s_row[i] = e / (C / 4);
+        s_q4[i] = 16 * (e % (C / 4));
+    }
+    const int clip_bytes = p.L * C * 4;                         // buffer range: loads past the clip return 0, stores are dropped
     f32x4 rx[SLOTS];
     auto load_tile = [&](int tile) {
         const int b = tile / p.ntiles, t0 = (tile % p.ntiles) * BM;
-        const float* xr = p.xr + (long long)b * p.L * C;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.xr + (long long)b * p.L * C), 0, clip_bytes, 0x00020000);
 #pragma unroll
         for (int i = 0; i < SLOTS; ++i) {
-            const int e = tid + i * 256;
-            const int row = e / (C / 4), q = e % (C / 4);
-            rx[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (row < Cfg::XE_ROWS) {
-                int j = t0 - 2 + row;                            // causal pad of 2: reflect ([HF]:157-176) or zeros
-                if (p.pad == PAD_REFLECT) j = j < 0 ? -j : (j >= p.Lp ? 2 * (p.Lp - 1) - j : j);
-                if (j >= 0 && j < p.L) rx[i] = *reinterpret_cast<const f32x4*>(xr + (long long)j * C + 4 * q);
-            }
+            int j = t0 - 2 + s_row[i];                           // causal pad of 2: reflect ([HF]:157-176) or zeros
+            if (p.pad == PAD_REFLECT) j = j < 0 ? -j : (j >= p.Lp ? 2 * (p.Lp - 1) - j : j);
+            const bool ok = s_row[i] < Cfg::XE_ROWS && j >= 0 && j < p.L;
+            rx[i] = bufload16(rs, ok ? j * (C * 4) + s_q4[i] : 0x7fff0000, 0);
         }
     };
     auto store_tile = [&]() {
 #pragma unroll
         for (int i = 0; i < SLOTS; ++i) {
-            const int e = tid + i * 256;
-            const int row = e / (C / 4), q = e % (C / 4);
+            const int row = s_row[i], q = s_q4[i] / 16;
             if (row < Cfg::XE_ROWS) {
                 split_store4(elu4(rx[i]), Xe, Cfg::XE_PLANE, row * XP + 4 * q);
                 // rows 2.. of the slab are the tile's own rows (never reflected: their source index is t0 + row - 2 >= 0)
@@ -163,7 +171,7 @@ __global__ __launch_bounds__(256, C == 64 ? 2 : 3) void rb_fused6_kernel(const R
     __syncthreads();
     for (; tile < total; tile += gridDim.x) {
         const int next = tile + gridDim.x;
-        if (next < total) load_tile(next);                      // in flight during both MFMA stages
+        if (next < total && !(p.dbg & 16)) load_tile(next);     // in flight during both MFMA stages
         // ---- stage A: hidden = ELU(conv_k3(xe) + b3) -> Hs planes
         {
             f32x4 acc[MS][NA];
@@ -171,6 +179,7 @@ __global__ __launch_bounds__(256, C == 64 ? 2 : 3) void rb_fused6_kernel(const R
             for (int a = 0; a < MS; ++a)
 #pragma unroll
                 for (int c = 0; c < NA; ++c) acc[a][c] = b3v[c];
+            if (!(p.dbg & 1))
 #pragma unroll
             for (int ks = 0; ks < KSA; ++ks) {
                 const int j = ks / (C / 32), kc = ks % (C / 32);
@@ -198,6 +207,7 @@ __global__ __launch_bounds__(256, C == 64 ? 2 : 3) void rb_fused6_kernel(const R
         for (int a = 0; a < MS; ++a)
 #pragma unroll
             for (int c = 0; c < NB; ++c) acc[a][c] = bfv[c];
+        if (!(p.dbg & 2))
 #pragma unroll
         for (int ks = 0; ks < KSB; ++ks) {
             bf16x8 xf[MS][3];
@@ -212,30 +222,34 @@ __global__ __launch_bounds__(256, C == 64 ? 2 : 3) void rb_fused6_kernel(const R
 #pragma unroll
                 for (int c = 0; c < NB; ++c) acc[a][c] = mma6(wfr[ks][c], xf[a], acc[a][c]);
         }
+        __syncthreads();                                        // every wave is done reading the slabs
+        // the next tile is staged BEFORE this tile's output stores are issued: the wait for its loads must not
+        // cover the stores (the memory counter retires in order)
+        if (next < total && !(p.dbg & 4)) store_tile();
         // ---- output: lane (li, kq) holds channels nb0 + 16c + 4kq .. +3 of time row r0 + 16a + li
-        {
+        if (!(p.dbg & 8)) {
             const int b = tile / p.ntiles, t0 = (tile % p.ntiles) * BM;
             const long long ob = (long long)b * p.L * C;
+            const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)(p.y ? p.y + ob : nullptr), 0, p.y ? clip_bytes : 0, 0x00020000);
+            const __amdgpu_buffer_rsrc_t re = __builtin_amdgcn_make_buffer_rsrc((void*)(p.y_elu ? p.y_elu + ob : nullptr), 0, p.y_elu ? clip_bytes : 0, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.xr + ob), 0, clip_bytes, 0x00020000);
 #pragma unroll
             for (int a = 0; a < MS; ++a) {
                 const int t = t0 + r0 + a * 16 + li;
-                if (t < p.L) {
+                const int orow = t < p.L ? t * (C * 4) : 0x7fff0000;   // rows past the clip: out of range, dropped
 #pragma unroll
-                    for (int c = 0; c < NB; ++c) {
-                        const long long o = ob + (long long)t * C + nb0 + c * 16 + 4 * kq;
-                        f32x4 v = acc[a][c];
-                        if (!SC) {                               // identity shortcut: x + block(x)
-                            const f32x4 xv = *reinterpret_cast<const f32x4*>(p.xr + o);
-                            v = f32x4{__fadd_rn(xv.x, v.x), __fadd_rn(xv.y, v.y), __fadd_rn(xv.z, v.z), __fadd_rn(xv.w, v.w)};
-                        }
-                        if (p.y) *reinterpret_cast<f32x4*>(p.y + o) = v;
-                        if (p.y_elu) *reinterpret_cast<f32x4*>(p.y_elu + o) = elu4(v);
+                for (int c = 0; c < NB; ++c) {
+                    const int o = orow + (nb0 + c * 16 + 4 * kq) * 4;
+                    f32x4 v = acc[a][c];
+                    if (!SC) {                                   // identity shortcut: x + block(x)
+                        const f32x4 xv = bufload16(rs, o, 0);
+                        v = f32x4{__fadd_rn(xv.x, v.x), __fadd_rn(xv.y, v.y), __fadd_rn(xv.z, v.z), __fadd_rn(xv.w, v.w)};
                     }
+                    if (p.y) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), ry, o, 0, 0);
+                    if (p.y_elu) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, elu4(v)), re, o, 0, 0);
                 }
             }
         }
-        __syncthreads();                                        // every wave is done reading the slabs
-        if (next < total) store_tile();
         __syncthreads();
     }
 }

@@ -8,10 +8,19 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int NACC, int SHAPE>
+// DATA 0: smooth operands (few significand bits set); DATA 1: random bf16 in [-1, 1) with random significands -- the
+// matrix pipe's clock (power management) depends on the operand bits, so the second figure is the practical ceiling
+template <int NACC, int SHAPE, int DATA = 0>
 __global__ __launch_bounds__(256) void k(float* out, int iters) {
     bf16x8 a, b;
     for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(threadIdx.x * 0.001f + i); b[i] = (__bf16)(1.0f + i * 0.01f); }
+    if (DATA == 1) {
+        unsigned s = (blockIdx.x * 256u + threadIdx.x) * 2654435761u + 12345u;
+        for (int i = 0; i < 8; ++i) {
+            s = s * 1664525u + 1013904223u; a[i] = (__bf16)(((s >> 8) & 0xffff) / 32768.0f - 1.0f);
+            s = s * 1664525u + 1013904223u; b[i] = (__bf16)(((s >> 8) & 0xffff) / 32768.0f - 1.0f);
+        }
+    }
     f32x16 acc[NACC];
     f32x4 acc4[NACC];
     for (int n = 0; n < NACC; ++n) { for (int r = 0; r < 16; ++r) acc[n][r] = 0.f; for (int r = 0; r < 4; ++r) acc4[n][r] = 0.f; }
@@ -29,22 +38,23 @@ __global__ __launch_bounds__(256) void k(float* out, int iters) {
     if (s == 12345.f) out[0] = s;
 }
 
-template <int NACC, int SHAPE>
+template <int NACC, int SHAPE, int DATA = 0>
 void run(int occ) {
     float* out; CK(hipMalloc(&out, 4));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const int iters = 2000;
-    hipLaunchKernelGGL((k<NACC, SHAPE>), dim3(256 * occ), dim3(256), 0, 0, out, 10);
+    hipLaunchKernelGGL((k<NACC, SHAPE, DATA>), dim3(256 * occ), dim3(256), 0, 0, out, 10);
     CK(hipEventRecord(e0));
-    hipLaunchKernelGGL((k<NACC, SHAPE>), dim3(256 * occ), dim3(256), 0, 0, out, iters);
+    hipLaunchKernelGGL((k<NACC, SHAPE, DATA>), dim3(256 * occ), dim3(256), 0, 0, out, iters);
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     const double flops = (double)256 * occ * 4 * iters * 8 * NACC * (SHAPE == 32 ? 32768.0 : 16384.0);
-    printf("%s, %d accumulators, %d workgroup(s)/CU: %.1f TFLOP/s bf16\n", SHAPE == 32 ? "32x32x16" : "16x16x32", NACC, occ, flops / (ms * 1e-3) / 1e12);
+    printf("%s, %s operands, %d accumulators, %d workgroup(s)/CU: %.1f TFLOP/s bf16\n", SHAPE == 32 ? "32x32x16" : "16x16x32", DATA ? "random" : "smooth", NACC, occ, flops / (ms * 1e-3) / 1e12);
 }
 
 int main() {
     run<1, 32>(1); run<2, 32>(1); run<4, 32>(1); run<4, 32>(2); run<1, 32>(2);
     run<1, 16>(1); run<4, 16>(1); run<4, 16>(2);
+    run<4, 32, 1>(1); run<4, 32, 1>(2); run<4, 16, 1>(1); run<4, 16, 1>(2);
     return 0;
 }
