@@ -23,6 +23,7 @@
 #include "thin.h"
 #include "rb_fused.h"
 #include "rb_fused6.h"
+#include "thin_conv6.h"
 #include "mimi.h"
 #include "dac.h"
 
@@ -141,6 +142,7 @@ struct ac_handle {
     std::vector<const void*> lds_opted;
     // split-operand weights (tap_gemm6.h): float offset of a packed fp32 matrix -> float offset of its bf16 planes
     std::map<size_t, size_t> w6_of;
+    std::map<size_t, size_t> t6_of;   // thin_conv6.h fragment images of the [64][128] layers, keyed like w6_of
     bool gemm_fp32 = false;         // AC_GEMM=fp32: exact-product kernels only
     // persistent LSTM (lstm_persist.h): control words, device shape, opt-out (AC_LSTM=step)
     unsigned* lp_ctl = nullptr;
@@ -366,6 +368,13 @@ struct Packer {
         std::memcpy(&blob[off], planes.data(), planes.size() * 2);
         return off;
     }
+    // thin_conv6.h image of a [64][128] layer
+    void pack_t6(const PackedGemm& g) {
+        if (g.N != 64 || g.Ktot != 128 || !g.has_bias || h->t6_of.count(g.w_off)) return;
+        std::vector<int> km(128);
+        for (int k = 0; k < 128; ++k) km[k] = k;
+        h->t6_of[g.w_off] = frag16(g.w_off, 64, 128, km);
+    }
     // rb_fused6.h images of a residual block (k3 conv C -> C/2, then [1x1 over the hidden | optional shortcut over x])
     void rb6(ResBlockPlan& rb, bool sc) {
         const int C = rb.C, hid = C / 2;
@@ -398,6 +407,7 @@ struct Packer {
             std::copy(b->begin(), b->end(), blob.begin() + g.b_off);
         }
         pack6(g);
+        pack_t6(g);
         return true;
     }
     // transposed conv, k = 2*s: out row m = [x[m-1] | x[m]] * Wp,  n = p*cout + co,
@@ -420,6 +430,7 @@ struct Packer {
         for (int p = 0; p < s.s; ++p)
             for (int co = 0; co < s.cout; ++co) blob[g.b_off + (size_t)p * s.cout + co] = (*b)[co];
         pack6(g);
+        pack_t6(g);
         return true;
     }
     bool resblock(const ConvSpec& c3, const ConvSpec& c1, const ConvSpec& sc, ResBlockPlan& rb) {
@@ -724,11 +735,48 @@ struct Act2 {       // a layer output in up to two flavours (same shape/strides)
     Act raw{}, elu{};
 };
 
+// the [64][128] layers on 64-float super-rows (thin_conv6.h); returns 1 when the shape does not qualify
+int try_thin6(ac_handle* h, hipStream_t st, const PackedGemm& g, const Act& x, int width, int edge, Out out, int B) {
+    if (h->gemm_fp32 || g.N != 64 || g.Ktot != 128 || x.C != width || x.ts != width || x.bs != (long long)x.L * width ||
+        (x.L * width) % 64 || x.L * width < 256 || !aligned16(x.p) || (long long)x.L * width * 4 > 0x70000000LL)
+        return 1;
+    auto it = h->t6_of.find(g.w_off);
+    if (it == h->t6_of.end()) return 1;
+    ThinConv6Params p{};
+    p.x = x.p;
+    p.wf = reinterpret_cast<const __bf16*>(h->blob + it->second);
+    p.bias = h->blob + g.b_off;
+    p.y = out.raw;
+    p.y_elu = out.elu;
+    p.B = B;
+    p.Ls = x.L * width / 64;
+    p.M = p.Ls;
+    p.ntiles = cdiv(p.M, T6_BM);
+    p.edge = edge;
+    const long long total = (long long)B * p.ntiles;
+    const int grid = (int)std::min<long long>(total, 4 * 256);   // persistent, four workgroups per CU
+    ProfScope ps(h, st, "thin_conv6_kernel", 2.0 * B * p.M * 64.0 * 128.0,
+                 (double)B * p.M * 256.0 * (1 + (out.raw ? 1 : 0) + (out.elu ? 1 : 0)));
+    hipLaunchKernelGGL(thin_conv6_kernel, dim3(grid), dim3(256), T6_LDS, st, p);
+    return AC_OK;
+}
+
 // conv (stride 1 or k = 2*stride), causal reflect padding.
 int conv_fwd(ac_handle* h, hipStream_t st, const PackedGemm& g, const Act& x, int k, int s, const float* rel_len, Out out,
              long long out_bs, long long out_rs, int B, Act2* y) {
     const int M = cdiv(x.L, s);
     const int extra = M * s - x.L;
+    if (s == 2 && k == 4 && !rel_len && extra == 0 && x.L >= 4 && out_rs == 64 && out_bs == (long long)M * 64) {
+        const int rc = try_thin6(h, st, g, x, 32, 1, out, B);
+        if (rc <= 0) {
+            if (y && !rc) {
+                y->raw = Act{out.raw, out_bs, out_rs, M, g.N};
+                y->elu = Act{out.elu, out_bs, out_rs, M, g.N};
+            }
+            if (!rc) HIPCHK(h, hipGetLastError());
+            return rc;
+        }
+    }
     TapGemmParams p{};
     p.nseg = 1;
     if (s != 1 && k != 2 * s) return fail(h, AC_EINVAL, "strided conv needs kernel == 2*stride (got k=%d, s=%d)", k, s);
@@ -752,6 +800,17 @@ int conv_fwd(ac_handle* h, hipStream_t st, const PackedGemm& g, const Act& x, in
 
 int convtr_fwd(ac_handle* h, hipStream_t st, const PackedGemm& g, const Act& x, int s, Out out, int B, Act2* y) {
     const int cout = g.N / s;
+    if (s == 2) {
+        const int rc = try_thin6(h, st, g, x, 64, 0, out, B);
+        if (rc <= 0) {
+            if (!rc) {
+                y->raw = Act{out.raw, (long long)x.L * s * cout, cout, x.L * s, cout};
+                y->elu = Act{out.elu, (long long)x.L * s * cout, cout, x.L * s, cout};
+                HIPCHK(h, hipGetLastError());
+            }
+            return rc;
+        }
+    }
     TapGemmParams p{};
     p.nseg = 1;
     p.seg[0] = make_seg(x, 1, 2, PAD_ZERO, 0, 0, nullptr);
