@@ -354,6 +354,124 @@ __global__ __launch_bounds__(256) void gemm3(const float* A, const __bf16* Bf, f
             }
 }
 
+// v6: v3 with 8 waves and a 128 x 256 tile: the A slab is split ONCE per 256 output columns (half the split / staging
+// VALU work per MFMA: VALU and MFMA issue of co-resident waves serialise on this chip), one workgroup per CU.
+template <int TERMS>
+__global__ __launch_bounds__(512) void gemm6(const float* A, const __bf16* Bf, float* C, int M, int N, int K) {
+    __shared__ __attribute__((aligned(16))) __bf16 As[2][3][BM * P2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;               // 2 x 4 waves of 64 x 64: 128 x 256 tile
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * 256;
+    const int i32 = lane & 31, kh = lane >> 5;
+    const int ksteps = K / 16;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    f32x4 ra[2];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int e = tid + 512 * i, row = e >> 3, q = e & 7;
+            ra[i] = *reinterpret_cast<const f32x4*>(A + (long long)(m0 + row) * K + k0 + 4 * q);
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int e = tid + 512 * i, row = e >> 3, q = e & 7;
+            unsigned h[4], m[4], l[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float v = ra[i][j];
+                const unsigned bh = __float_as_uint(v) & 0xffff0000u;
+                const float r1 = v - __uint_as_float(bh);
+                const unsigned bm = __float_as_uint(r1) & 0xffff0000u;
+                h[j] = bh; m[j] = bm; l[j] = __float_as_uint(r1 - __uint_as_float(bm));
+            }
+            unsigned* dh = reinterpret_cast<unsigned*>(&As[buf][0][row * P2 + 4 * q]);
+            unsigned* dm = reinterpret_cast<unsigned*>(&As[buf][1][row * P2 + 4 * q]);
+            unsigned* dl = reinterpret_cast<unsigned*>(&As[buf][2][row * P2 + 4 * q]);
+            dh[0] = (h[0] >> 16) | h[1]; dh[1] = (h[2] >> 16) | h[3];
+            dm[0] = (m[0] >> 16) | m[1]; dm[1] = (m[2] >> 16) | m[3];
+            dl[0] = (l[0] >> 16) | (l[1] & 0xffff0000u); dl[1] = (l[2] >> 16) | (l[3] & 0xffff0000u);
+        }
+    };
+    // B fragments of this wave's two n-tiles for k-step s: [b][plane]
+    const __bf16* bbase = Bf + ((long long)((n0 + wn * 64) / 32) * ksteps) * (3 * 64 * 8) + lane * 8;
+    auto bload = [&](int s_, bf16x8 (&bf)[3][2]) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                bf[pl][b] = *reinterpret_cast<const bf16x8*>(bbase + (((long long)b * ksteps + s_) * 3 + pl) * (64 * 8));
+    };
+    const bool trace_on = false;
+    gload(0);
+    lstore(0);
+    bf16x8 bcur[3][2], bnxt[3][2];
+    bload(0, bcur);
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = 0; k0 < K; k0 += KC) {
+        const bool more = k0 + KC < K;
+        if (more) gload(k0 + KC);
+#pragma unroll
+        for (int ks = 0; ks < KC / 16; ++ks) {
+            const int s_ = k0 / 16 + ks;
+            TRC(s_, 0);
+            if (s_ + 1 < ksteps) bload(s_ + 1, bnxt);
+            bf16x8 af[3][2];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                for (int a = 0; a < 2; ++a) af[pl][a] = *reinterpret_cast<const bf16x8*>(&As[buf][pl][(wm * 64 + a * 32 + i32) * P2 + ks * 16 + 8 * kh]);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            TRC(s_, 1);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    f32x16 c = acc[a][b];
+                    if (TERMS == 9) {
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][a], bcur[2][b], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][a], bcur[2][b], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][a], bcur[1][b], c, 0, 0, 0);
+                    }
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][a], bcur[2][b], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][a], bcur[0][b], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][a], bcur[1][b], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][a], bcur[1][b], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][a], bcur[0][b], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][a], bcur[0][b], c, 0, 0, 0);
+                    acc[a][b] = c;
+                }
+            TRC(s_, 2);
+            if (ks == 0 && more) lstore(buf ^ 1);
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) bcur[pl][b] = bnxt[pl][b];
+            TRC(s_, 3);
+        }
+        __syncthreads();
+        buf ^= 1;
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + a * 32 + 8 * (r / 4) + kh * 4 + (r % 4);
+                const int col = n0 + wn * 64 + b * 32 + i32;
+                C[(long long)row * N + col] = acc[a][b][r];
+            }
+}
+
 // v4: like v3 (weights pre-split, fragment order, straight from L2) but the A slab stays fp32 in LDS (4 B/element
 // instead of 6: KC = 64 fits double-buffered, one barrier per 96 MFMAs) and is split after the fragment read --
 // the split VALU work then sits between the MFMAs of the same basic block instead of in front of a barrier.
@@ -615,9 +733,9 @@ int main() {
     const int lds5 = 2 * 3 * BM5 * P2 * 2;
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm5<6>), hipFuncAttributeMaxDynamicSharedMemorySize, lds5));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm5<9>), hipFuncAttributeMaxDynamicSharedMemorySize, lds5));
-    for (int ver = 3; ver <= 5; ++ver)
+    for (int ver = 3; ver <= 6; ++ver)
     for (int terms : {6, 9}) {
-        const dim3 grid(N / BN, M / (ver == 5 ? BM5 : BM));
+        const dim3 grid(N / (ver == 6 ? 256 : BN), M / (ver == 5 ? BM5 : BM));
         for (int rep = 0; rep < 3; ++rep) {
             CK(hipEventRecord(e0));
             for (int i = 0; i < 10; ++i) {
@@ -633,6 +751,9 @@ int main() {
                 } else if (ver == 4) {
                     if (terms == 6) hipLaunchKernelGGL(gemm4<6>, grid, dim3(256), 2 * BM * KCP4 * 4, 0, A, Bf, C, M, N, K);
                     else hipLaunchKernelGGL(gemm4<9>, grid, dim3(256), 2 * BM * KCP4 * 4, 0, A, Bf, C, M, N, K);
+                } else if (ver == 6) {
+                    if (terms == 6) hipLaunchKernelGGL(gemm6<6>, grid, dim3(512), 0, 0, A, Bf, C, M, N, K);
+                    else hipLaunchKernelGGL(gemm6<9>, grid, dim3(512), 0, 0, A, Bf, C, M, N, K);
                 } else {
                     if (terms == 6) hipLaunchKernelGGL(gemm5<6>, grid, dim3(256), lds5, 0, A, Bf, C, M, N, K);
                     else hipLaunchKernelGGL(gemm5<9>, grid, dim3(256), lds5, 0, A, Bf, C, M, N, K);
