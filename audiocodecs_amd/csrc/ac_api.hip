@@ -24,6 +24,7 @@
 #include "rb_fused.h"
 #include "rb_fused6.h"
 #include "thin_conv6.h"
+#include "rb_fused6_128.h"
 #include "mimi.h"
 #include "dac.h"
 
@@ -378,7 +379,7 @@ struct Packer {
     // rb_fused6.h images of a residual block (k3 conv C -> C/2, then [1x1 over the hidden | optional shortcut over x])
     void rb6(ResBlockPlan& rb, bool sc) {
         const int C = rb.C, hid = C / 2;
-        if ((C != 32 && C != 64) || rb.c3.N != hid || rb.c3.Ktot != 3 * C || rb.fused.N != C || rb.fused.Ktot != hid + (sc ? C : 0)) return;
+        if ((C != 32 && C != 64 && C != 128) || rb.c3.N != hid || rb.c3.Ktot != 3 * C || rb.fused.N != C || rb.fused.Ktot != hid + (sc ? C : 0)) return;
         std::vector<int> k3(3 * C), kf;
         for (int k = 0; k < 3 * C; ++k) k3[k] = k;
         const int hcp = hid < 32 ? 32 : hid;
@@ -888,8 +889,48 @@ int launch_rb_fused6(ac_handle* h, hipStream_t st, const ResBlockPlan& rb, const
     return AC_OK;
 }
 
+// the 128-channel block as one 8-wave workgroup per CU (rb_fused6_128.h)
+template <bool SC>
+int launch_rb128_fused6(ac_handle* h, hipStream_t st, const ResBlockPlan& rb, const Act2& x, Out out, int B, int pad = PAD_REFLECT) {
+    using Cfg = Rb128Cfg<SC>;
+    RbFused6Params p{};
+    p.xr = x.raw.p;
+    p.w3f = reinterpret_cast<const __bf16*>(h->blob + rb.w3f_off);
+    p.wff = reinterpret_cast<const __bf16*>(h->blob + rb.wff_off);
+    p.b3 = h->blob + rb.c3.b_off;
+    p.bf = h->blob + rb.fused.b_off;
+    p.y = out.raw;
+    p.y_elu = out.elu;
+    p.B = B;
+    p.L = x.raw.L;
+    p.Lp = x.raw.L > 2 ? x.raw.L : 3;
+    p.ntiles = cdiv(x.raw.L, Cfg::BM);
+    p.pad = pad;
+    if (int rc = ensure_lds(h, reinterpret_cast<const void*>(rb128_fused6_kernel<SC>), Cfg::lds_bytes)) return rc;
+    const long long total = (long long)B * p.ntiles;
+    const int grid = (int)std::min<long long>(total, 256);   // persistent, one workgroup per CU
+    const double L = x.raw.L;
+    ProfScope ps(h, st, SC ? "rb128_fused6_kernel<true>" : "rb128_fused6_kernel<false>",
+                 2.0 * B * L * (64.0 * 384 + 128.0 * (64 + (SC ? 128 : 0))),
+                 (double)B * L * 128 * 4.0 * (1 + (out.raw ? 1 : 0) + (out.elu ? 1 : 0)));
+    hipLaunchKernelGGL((rb128_fused6_kernel<SC>), dim3(grid), dim3(512), Cfg::lds_bytes, st, p);
+    return AC_OK;
+}
+// can the 128-channel block run fused?  (the producer then writes the raw flavour only)
+bool rb128_ok(const ac_handle* h, const ResBlockPlan& rb) { return rb.C == 128 && rb.has6 && !h->gemm_fp32; }
+
 // ResBlock: hbuf = ELU(conv3(ELU(x)));  out = [hbuf | x] * [W1; Ws] + (b1 + bs)
 int resblock_fwd(ac_handle* h, hipStream_t st, const ResBlockPlan& rb, const Act2& x, float* hbuf, Out out, int B, Act2* y) {
+    if (rb128_ok(h, rb) && h->cfg.residual_kernel_size == 3 && h->cfg.compress == 2 && x.raw.ts == 128 &&
+        x.raw.bs == (long long)x.raw.L * 128 && aligned16(x.raw.p) && (long long)x.raw.L * 512 < 0x70000000LL) {
+        int rc = launch_rb128_fused6<true>(h, st, rb, x, out, B);
+        if (rc) return rc;
+        HIPCHK(h, hipGetLastError());
+        const long long bs = (long long)x.raw.L * 128;
+        y->raw = Act{out.raw, bs, 128, x.raw.L, 128};
+        y->elu = Act{out.elu, bs, 128, x.raw.L, 128};
+        return AC_OK;
+    }
     // thin stages: one fused kernel, hidden activation never leaves the CU
     if ((rb.C == 32 || rb.C == 64) && h->cfg.residual_kernel_size == 3 && h->cfg.compress == 2 && x.raw.ts == rb.C &&
         x.raw.bs == (long long)x.raw.L * rb.C && aligned16(x.raw.p) &&
@@ -1282,7 +1323,9 @@ int encoder_fwd(ac_handle* h, hipStream_t st, const float* sig, const float* rel
     Act2 x, y;
     int rc;
     // a 32-channel ResBlock activates its raw input itself (rb_fused.h): no ELU'd flavour needed in HBM
-    auto rb_self_elu = [&](int C) { return (C == 32 || C == 64) && c.residual_kernel_size == 3 && c.compress == 2; };
+    auto rb_self_elu = [&](int C) {
+        return (C == 32 || C == 64 || (C == 128 && !dbg && c.num_ratios > 2 && rb128_ok(h, h->enc_rb[2]))) && c.residual_kernel_size == 3 && c.compress == 2;
+    };
     if (thin_ok(c, c.kernel_size))
         rc = stem_fwd(h, st, sig, rel_len, B, T, Out{ws.take(), rb_self_elu(c.num_filters) ? nullptr : ws.take()}, &x);
     else
@@ -1339,7 +1382,8 @@ int decoder_fwd(ac_handle* h, hipStream_t st, const long long* toks, int B, int 
     x = y;
     for (int i = 0; i < c.num_ratios; ++i) {
         const int cup = h->dec_up[i].N / c.upsampling_ratios[i];
-        const bool self_elu = (cup == 32 || cup == 64) && c.residual_kernel_size == 3 && c.compress == 2;   // rb_fused.h activates raw rows itself
+        const bool self_elu = (cup == 32 || cup == 64 || (cup == 128 && !dbg && rb128_ok(h, h->dec_rb[i]))) && c.residual_kernel_size == 3 &&
+                              c.compress == 2;   // rb_fused.h / rb_fused6*.h activate raw rows themselves
         rc = convtr_fwd(h, st, h->dec_up[i], x.elu, c.upsampling_ratios[i], Out{ws.take(), self_elu ? nullptr : ws.take()}, B, &y);
         if (rc) return rc;
         ws.give(x);

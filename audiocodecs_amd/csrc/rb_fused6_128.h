@@ -1,0 +1,182 @@
+// rb128_fused6: the fused residual block of rb_fused6.h for C = 128 (hidden 64), where the two weight images
+// (k3 conv [64][384], [1x1 | shortcut] [128][192]) are 295 KB as bf16 planes -- they fit the register file of a CU only
+// when EIGHT waves share them (144 VGPRs each, one workgroup of 512 threads per CU):
+//   stage A  hidden = ELU(W3 * [xe(t-2) | xe(t-1) | xe(t)] + b3):  wave (ng = w & 3, kg = w >> 2) owns hidden channels
+//            16 ng .. +15 and HALF of K (k-steps 6 kg .. 6 kg + 5); the kg = 1 partial sums travel through LDS (fp32);
+//   stage B  y = [W1 | Ws] * [hidden | x] + bf:  wave w owns output channels 16 w .. +15 and all of K.
+// Everything else as in rb_fused6.h: x is read once per 64-row tile (raw rows, ELU while staging), split once into
+// bf16 planes in LDS, transposed MFMA tiles (a lane holds 4 consecutive channels of one time row), 16-byte stores
+// straight to HBM, the next tile is staged before the current tile's output stores are issued.  Unfused, the block
+// was two tap-GEMM launches with the hidden tensor and a second read of x in HBM (1.58 ms per block at 64 x 10 s).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "rb_fused6.h"
+
+namespace ac {
+
+template <bool SC>
+struct Rb128Cfg {
+    static constexpr int C = 128, HC = 64, BM = 64, NT = 512;
+    static constexpr int KSA = 12, KSA_W = 6;                           // k-steps of stage A, per wave
+    static constexpr int KSH = 2, KSB = KSH + (SC ? 4 : 0);             // k-steps of stage B: hidden, then x
+    static constexpr int TT = BM / 16;                                  // 16-row time tiles (every wave covers all of them)
+    static constexpr int XP = C + 8, HP = HC + 8;
+    static constexpr int XE_ROWS = BM + 2;
+    static constexpr int XE_PLANE = XE_ROWS * XP, XR_PLANE = SC ? BM * XP : 0, H_PLANE = BM * HP;
+    static constexpr int PSP = HC + 4;                                  // partial-sum row pitch (floats)
+    static constexpr int SLOTS = (XE_ROWS * (C / 4) + NT - 1) / NT;
+    static constexpr size_t lds_bytes = (size_t)3 * (XE_PLANE + XR_PLANE + H_PLANE) * 2 + (size_t)BM * PSP * 4;
+};
+
+template <bool SC>
+__global__ __launch_bounds__(512, 1) void rb128_fused6_kernel(const RbFused6Params p) {
+    using Cfg = Rb128Cfg<SC>;
+    constexpr int C = Cfg::C, BM = Cfg::BM, NT = Cfg::NT, XP = Cfg::XP, HP = Cfg::HP, TT = Cfg::TT;
+    constexpr int KSA_W = Cfg::KSA_W, KSH = Cfg::KSH, KSB = Cfg::KSB, SLOTS = Cfg::SLOTS, PSP = Cfg::PSP;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __bf16* Xe = reinterpret_cast<__bf16*>(smem);                  // [3][XE_ROWS][XP]
+    __bf16* Xr = Xe + 3 * Cfg::XE_PLANE;                           // [3][BM][XP]       (SC only)
+    __bf16* Hs = Xr + 3 * Cfg::XR_PLANE;                           // [3][BM][HP]
+    float* Ps = reinterpret_cast<float*>(Hs + 3 * Cfg::H_PLANE);   // [BM][PSP] partial sums of the upper K half
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ng = wave & 3, kg = wave >> 2;
+    const int li = lane & 15, kq = lane >> 4;
+    const int total = p.B * p.ntiles;
+
+    // ---- this wave's weight fragments -> registers (once)
+    bf16x8 w3r[KSA_W][3], wfr[KSB][3];
+#pragma unroll
+    for (int i = 0; i < KSA_W; ++i)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+            w3r[i][pl] = *reinterpret_cast<const bf16x8*>(p.w3f + ((((long long)ng * Cfg::KSA + kg * KSA_W + i) * 3 + pl) * 64 + lane) * 8);
+#pragma unroll
+    for (int ks = 0; ks < KSB; ++ks)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+            wfr[ks][pl] = *reinterpret_cast<const bf16x8*>(p.wff + ((((long long)wave * KSB + ks) * 3 + pl) * 64 + lane) * 8);
+    const f32x4 b3v = *reinterpret_cast<const f32x4*>(p.b3 + ng * 16 + 4 * kq);
+    const f32x4 bfv = *reinterpret_cast<const f32x4*>(p.bf + wave * 16 + 4 * kq);
+
+    int s_row[SLOTS], s_q4[SLOTS];
+#pragma unroll
+    for (int i = 0; i < SLOTS; ++i) {
+        const int e = tid + i * NT;
+        s_row[i] = e / (C / 4);
+        s_q4[i] = 16 * (e % (C / 4));
+    }
+    const int clip_bytes = p.L * C * 4;
+    f32x4 rx[SLOTS];
+    auto load_tile = [&](int tile) {
+        const int b = tile / p.ntiles, t0 = (tile % p.ntiles) * BM;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.xr + (long long)b * p.L * C), 0, clip_bytes, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < SLOTS; ++i) {
+            int j = t0 - 2 + s_row[i];                           // causal pad of 2: reflect ([HF]:157-176) or zeros
+            if (p.pad == PAD_REFLECT) j = j < 0 ? -j : (j >= p.Lp ? 2 * (p.Lp - 1) - j : j);
+            const bool ok = s_row[i] < Cfg::XE_ROWS && j >= 0 && j < p.L;
+            rx[i] = bufload16(rs, ok ? j * (C * 4) + s_q4[i] : 0x7fff0000, 0);
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < SLOTS; ++i) {
+            const int row = s_row[i], q = s_q4[i] / 16;
+            if (row < Cfg::XE_ROWS) {
+                split_store4(elu4(rx[i]), Xe, Cfg::XE_PLANE, row * XP + 4 * q);
+                if (SC && row >= 2) split_store4(rx[i], Xr, Cfg::XR_PLANE, (row - 2) * XP + 4 * q);
+            }
+        }
+    };
+
+    int tile = blockIdx.x;
+    if (tile >= total) return;
+    load_tile(tile);
+    store_tile();
+    __syncthreads();
+    for (; tile < total; tile += gridDim.x) {
+        const int next = tile + gridDim.x;
+        if (next < total) load_tile(next);                      // in flight during both MFMA stages
+        // ---- stage A: this wave's half of K for hidden channels 16 ng ..
+        {
+            f32x4 acc[TT];
+#pragma unroll
+            for (int a = 0; a < TT; ++a) acc[a] = kg == 0 ? b3v : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < KSA_W; ++i) {
+                const int ks = kg * KSA_W + i;                   // k-step of 32 over k = tap * 128 + ci
+                const int j = ks >> 2, kc = ks & 3;
+#pragma unroll
+                for (int a0 = 0; a0 < TT; a0 += 2) {             // two time tiles at a time: 24 fragment registers live
+                    bf16x8 xf[2][3];
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+#pragma unroll
+                        for (int pl = 0; pl < 3; ++pl)
+                            xf[a][pl] = *reinterpret_cast<const bf16x8*>(Xe + pl * Cfg::XE_PLANE + ((a0 + a) * 16 + li + j) * XP + kc * 32 + 8 * kq);
+#pragma unroll
+                    for (int a = 0; a < 2; ++a) acc[a0 + a] = mma6(w3r[i], xf[a], acc[a0 + a]);
+                }
+            }
+            if (kg == 1) {
+#pragma unroll
+                for (int a = 0; a < TT; ++a) *reinterpret_cast<f32x4*>(&Ps[(a * 16 + li) * PSP + ng * 16 + 4 * kq]) = acc[a];
+            }
+            __syncthreads();
+            if (kg == 0) {
+#pragma unroll
+                for (int a = 0; a < TT; ++a) {
+                    const f32x4 u = *reinterpret_cast<const f32x4*>(&Ps[(a * 16 + li) * PSP + ng * 16 + 4 * kq]);
+                    const f32x4 v = f32x4{acc[a].x + u.x, acc[a].y + u.y, acc[a].z + u.z, acc[a].w + u.w};
+                    split_store4(elu4(v), Hs, Cfg::H_PLANE, (a * 16 + li) * HP + ng * 16 + 4 * kq);
+                }
+            }
+        }
+        __syncthreads();
+        // ---- stage B: y = [W1 | Ws] * [hidden | x]^T + bf, output channels 16 wave ..
+        f32x4 acc[TT];
+#pragma unroll
+        for (int a = 0; a < TT; ++a) acc[a] = bfv;
+#pragma unroll
+        for (int ks = 0; ks < KSB; ++ks) {
+#pragma unroll
+            for (int a0 = 0; a0 < TT; a0 += 2) {
+                bf16x8 xf[2][3];
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl)
+                        xf[a][pl] = ks < KSH ? *reinterpret_cast<const bf16x8*>(Hs + pl * Cfg::H_PLANE + ((a0 + a) * 16 + li) * HP + ks * 32 + 8 * kq)
+                                             : *reinterpret_cast<const bf16x8*>(Xr + pl * Cfg::XR_PLANE + ((a0 + a) * 16 + li) * XP + (ks - KSH) * 32 + 8 * kq);
+#pragma unroll
+                for (int a = 0; a < 2; ++a) acc[a0 + a] = mma6(wfr[ks], xf[a], acc[a0 + a]);
+            }
+        }
+        __syncthreads();                                        // every wave is done reading the slabs
+        if (next < total) store_tile();                         // staged before the output stores are issued (rb_fused6.h)
+        {
+            const int b = tile / p.ntiles, t0 = (tile % p.ntiles) * BM;
+            const long long ob = (long long)b * p.L * C;
+            const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)(p.y ? p.y + ob : nullptr), 0, p.y ? clip_bytes : 0, 0x00020000);
+            const __amdgpu_buffer_rsrc_t re = __builtin_amdgcn_make_buffer_rsrc((void*)(p.y_elu ? p.y_elu + ob : nullptr), 0, p.y_elu ? clip_bytes : 0, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.xr + ob), 0, clip_bytes, 0x00020000);
+#pragma unroll
+            for (int a = 0; a < TT; ++a) {
+                const int t = t0 + a * 16 + li;
+                const int o = (t < p.L ? t * (C * 4) : 0x7fff0000) + (wave * 16 + 4 * kq) * 4;   // rows past the clip: dropped
+                f32x4 v = acc[a];
+                if (!SC) {                                       // identity shortcut: x + block(x)
+                    const f32x4 xv = bufload16(rs, o, 0);
+                    v = f32x4{__fadd_rn(xv.x, v.x), __fadd_rn(xv.y, v.y), __fadd_rn(xv.z, v.z), __fadd_rn(xv.w, v.w)};
+                }
+                if (p.y) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), ry, o, 0, 0);
+                if (p.y_elu) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, elu4(v)), re, o, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace ac
