@@ -1312,6 +1312,15 @@ int check_ready(ac_handle* h) {
     return AC_OK;
 }
 
+// The kernels address one clip's activation with 32-bit byte offsets (buffer descriptors): the widest per-clip tensor
+// (64 floats per sample; DAC: up to 128) must stay below 2 GB -- 7.3 M samples (5 min at 24 kHz) per clip and call,
+// DAC 3.6 M (83 s at 44.1 kHz).
+int check_len(ac_handle* h, long long samples) {
+    const long long lim = 0x70000000LL / (h->arch == ARCH_DAC ? 512 : 256) - 1;
+    if (samples > lim) return fail(h, AC_EINVAL, "clip of %lld samples is too long for one call (limit %lld): split it", samples, lim);
+    return AC_OK;
+}
+
 // encoder: sig -> feats [B][N][H] written to `feats`.
 // Flavours: a tensor is written raw where a shortcut / LSTM / caller reads it, ELU'd where the next
 // conv reads it (all SEANet convs but the first are preceded by nn.ELU), both where both happen.
@@ -1673,6 +1682,7 @@ int ac_encode_feats(ac_handle* h, const float* sig, const float* rel_len, int B,
     int rc = check_ready(h);
     if (rc) return rc;
     if (!sig || !feats || B < 1 || T < 1) return fail(h, AC_EINVAL, "ac_encode_feats: bad argument (B=%d, T=%d)", B, T);
+    if ((rc = check_len(h, T))) return rc;
     if (h->arch == ARCH_DAC) return dac_encode_impl(h, sig, B, T, 0, feats, nullptr, nullptr, nullptr, ws, ws_bytes, (hipStream_t)stream);
     WsPtrs p;
     rc = carve(h, any_plan_ws(h, B, T, 0, true), ws, ws_bytes, &p);
@@ -1686,6 +1696,7 @@ int ac_encode(ac_handle* h, const float* sig, const float* rel_len, int B, int T
     if (rc) return rc;
     if (!sig || !toks || B < 1 || T < 1) return fail(h, AC_EINVAL, "ac_encode: bad argument (B=%d, T=%d)", B, T);
     if (K < 1 || K > num_q(h)) return fail(h, AC_EINVAL, "ac_encode: K=%d outside [1, %d]", K, num_q(h));
+    if ((rc = check_len(h, T))) return rc;
     if (h->arch == ARCH_DAC)
         return dac_encode_impl(h, sig, B, T, K, nullptr, nullptr, reinterpret_cast<long long*>(toks), nullptr, ws, ws_bytes, (hipStream_t)stream);
     WsPtrs p;
@@ -1755,6 +1766,7 @@ int ac_decode(ac_handle* h, const int64_t* toks, int B, int N, int K, float* sig
     if (rc) return rc;
     if (!sig || !toks || B < 1 || N < 1) return fail(h, AC_EINVAL, "ac_decode: bad argument (B=%d, N=%d)", B, N);
     if (K < 1 || K > num_q(h)) return fail(h, AC_EINVAL, "ac_decode: K=%d outside [1, %d]", K, num_q(h));
+    if ((rc = check_len(h, ac_num_samples(h, N)))) return rc;
     if (h->arch == ARCH_DAC) {
         hipStream_t st = (hipStream_t)stream;
         const int Bc = dac_chunk_clips(h, B, 0, N, false);
@@ -1830,6 +1842,7 @@ int ac_encode_quantized(ac_handle* h, const float* sig, int B, int T, int K, int
     if (rc) return rc;
     if (h->arch != ARCH_DAC) return fail(h, AC_EINVAL, "ac_encode_quantized: DAC handles only (others: ac_encode + ac_dequantize_ws)");
     if (!sig || !toks || !qfeats || B < 1 || T < 1 || K < 1 || K > num_q(h)) return fail(h, AC_EINVAL, "ac_encode_quantized: bad argument");
+    if ((rc = check_len(h, T))) return rc;
     return dac_encode_impl(h, sig, B, T, K, nullptr, nullptr, reinterpret_cast<long long*>(toks), qfeats, ws, ws_bytes, (hipStream_t)stream);
 }
 
@@ -1838,6 +1851,7 @@ int ac_encode_feats_latent(ac_handle* h, const float* sig, int B, int T, float* 
     if (rc) return rc;
     if (h->arch != ARCH_DAC) return fail(h, AC_EINVAL, "ac_encode_feats_latent: DAC handles only");
     if (!sig || !feats_latent || B < 1 || T < 1) return fail(h, AC_EINVAL, "ac_encode_feats_latent: bad argument");
+    if ((rc = check_len(h, T))) return rc;
     return dac_encode_impl(h, sig, B, T, 0, nullptr, feats_latent, nullptr, nullptr, ws, ws_bytes, (hipStream_t)stream);
 }
 

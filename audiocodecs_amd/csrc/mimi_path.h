@@ -87,6 +87,15 @@ int mimi_linear(ac_handle* h, hipStream_t st, const PackedGemm& g, const float* 
 int mimi_resblock(ac_handle* h, hipStream_t st, const ResBlockPlan& rb, const Act2& x, float* hbuf, Out out, int B, Act2* y) {
     const ac_mimi_config& c = h->mcfg;
     const long long bs = (long long)x.raw.L * rb.C;
+    if (rb128_ok(h, rb) && c.residual_kernel_size == 3 && c.compress == 2 && x.raw.ts == 128 && x.raw.bs == bs && aligned16(x.raw.p) &&
+        bs * 4 < 0x70000000LL) {
+        int rc = launch_rb128_fused6<false>(h, st, rb, x, out, B, PAD_ZERO);
+        if (rc) return rc;
+        HIPCHK(h, hipGetLastError());
+        y->raw = Act{out.raw, bs, rb.C, x.raw.L, rb.C};
+        y->elu = Act{out.elu, bs, rb.C, x.raw.L, rb.C};
+        return AC_OK;
+    }
     if (rb.C == 64 && c.residual_kernel_size == 3 && c.compress == 2 && x.raw.ts == rb.C && x.raw.bs == bs && aligned16(x.raw.p) &&
         (!x.elu.p || (x.elu.ts == rb.C && x.elu.bs == bs && aligned16(x.elu.p)))) {
         int rc = rb.has6 && !h->gemm_fp32 ? launch_rb_fused6<64, false>(h, st, rb, x, out, B, PAD_ZERO)
@@ -107,7 +116,11 @@ int mimi_resblock(ac_handle* h, hipStream_t st, const ResBlockPlan& rb, const Ac
     return mimi_conv(h, st, rb.fused, hv.elu, 1, 1, PAD_ZERO, out, B, y, e);
 }
 
-bool mimi_rb_self_elu(const ac_mimi_config& c, int C) { return C == 64 && c.residual_kernel_size == 3 && c.compress == 2; }
+// blocks that activate their raw input themselves: the producer writes one flavour (128 channels: the fused split-operand
+// kernel only, and not while the test hook wants every module's raw output)
+bool mimi_rb_self_elu(const ac_handle* h, const ac_mimi_config& c, int C) {
+    return (C == 64 || (C == 128 && !h->gemm_fp32 && !h->dbg)) && c.residual_kernel_size == 3 && c.compress == 2;
+}
 
 int layernorm_fwd(ac_handle* h, hipStream_t st, const float* x, size_t w_off, size_t b_off, float* y, long long rows, int H, float eps) {
     if (H > 64 * LN_MAXV) return fail(h, AC_EINVAL, "hidden size %d exceeds the LayerNorm kernel limit", H);
@@ -315,7 +328,7 @@ int mimi_encoder_fwd(ac_handle* h, hipStream_t st, const float* sig, int B, int 
     int rc;
     if (F % 4 == 0 && F <= 64 && c.kernel_size <= THIN_MAXK)
         rc = thin_stem(h, st, m.enc_stem, F, c.kernel_size, PAD_ZERO, sig, nullptr, B, T,
-                       Out{ws.take(), mimi_rb_self_elu(c, F) ? nullptr : ws.take()}, &x);
+                       Out{ws.take(), mimi_rb_self_elu(h, c, F) ? nullptr : ws.take()}, &x);
     else
         rc = mimi_conv(h, st, m.enc_stem, xin, c.kernel_size, 1, PAD_ZERO, Out{ws.take(), ws.take()}, B, &x);
     if (rc) return rc;
@@ -331,7 +344,7 @@ int mimi_encoder_fwd(ac_handle* h, hipStream_t st, const float* sig, int B, int 
         x = y;
         const bool last = i == c.num_ratios - 1;     // the last down-sampler feeds ELU -> final conv only
         const int cout = m.enc_down[i].N;
-        Out o = last ? Out{dbg ? ws.take() : nullptr, ws.take()} : Out{ws.take(), mimi_rb_self_elu(c, cout) ? nullptr : ws.take()};
+        Out o = last ? Out{dbg ? ws.take() : nullptr, ws.take()} : Out{ws.take(), mimi_rb_self_elu(h, c, cout) ? nullptr : ws.take()};
         rc = mimi_conv(h, st, m.enc_down[i], x.elu, 2 * ratio, ratio, PAD_ZERO, o, B, &y);
         if (rc) return rc;
         ws.give(x);
@@ -384,7 +397,7 @@ int mimi_decoder_fwd(ac_handle* h, hipStream_t st, const float* qfeats, int B, i
     if (dbg) { capture(h, st, x.raw, B); ws.give(x.raw.p); x.raw.p = nullptr; }
     for (int i = 0; i < c.num_ratios; ++i) {
         const int cup = m.dec_up[i].N / c.upsampling_ratios[i];
-        rc = convtr_fwd(h, st, m.dec_up[i], x.elu, c.upsampling_ratios[i], Out{ws.take(), mimi_rb_self_elu(c, cup) ? nullptr : ws.take()}, B, &y);
+        rc = convtr_fwd(h, st, m.dec_up[i], x.elu, c.upsampling_ratios[i], Out{ws.take(), mimi_rb_self_elu(h, c, cup) ? nullptr : ws.take()}, B, &y);
         if (rc) return rc;
         ws.give(x);
         x = y;

@@ -183,7 +183,9 @@ size_t ac_decode_workspace_bytes(const ac_handle* h, int B, int N);
  * rel_len_dev: NULL, or [B] fp32 relative lengths (SpeechBrain style): sample t of clip b is
  * zeroed before the encoder iff not (float)t < (float)T * rel_len[b]   (encodec.py:84-89,
  * [HF] modeling_encodec.py:589-590).  Tokens are produced for all N frames regardless.
- * K = number of codebooks (quantizer stages), 1 <= K <= num_quantizers. */
+ * K = number of codebooks (quantizer stages), 1 <= K <= num_quantizers.
+ * One clip per call is limited to 7 340 031 samples (DAC handles: 3 670 015): per-clip activations are addressed with
+ * 32-bit byte offsets; longer clips return AC_EINVAL ("split it") -- the codecs are causal / chunkable on the host. */
 int ac_encode(ac_handle* h, const float* sig_dev, const float* rel_len_dev, int B, int T, int K,
               int64_t* toks_dev, void* workspace_dev, size_t workspace_bytes, void* stream);
 
