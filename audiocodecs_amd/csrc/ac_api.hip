@@ -514,18 +514,19 @@ struct Packer {
                                     for (int e = 0; e < 4; ++e)
                                         blob[lp.persist_off + m * mat + ((((size_t)idx * 4 + w) * 4 + n) * 8 + ks) * 256 + lane * 4 + e] =
                                             (*mats[m])[(size_t)(n * D + idx * 16 + (lane & 15)) * D + (w * 8 + ks) * 16 + 4 * (lane >> 4) + e];
-            // lstm_persist6_kernel: [hh0, ih1, hh1][32 slices][4 waves][4 gates][4 k-steps of 32][3 planes][64 lanes][8 bf16]
+            // lstm_persist6_kernel: [hh0, ih1, hh1, ih0][32 slices][4 waves][4 gates][4 k-steps of 32][3 planes][64 lanes][8 bf16]
             const size_t mat6 = (size_t)LP_SLICES * 4 * 4 * 4 * 3 * 512;
-            lp.persist6_off = reserve((3 * mat6 + 1) / 2);
-            std::vector<uint16_t> pl6(3 * mat6);
-            for (int m = 0; m < 3; ++m)
+            lp.persist6_off = reserve((4 * mat6 + 1) / 2);
+            std::vector<uint16_t> pl6(4 * mat6);
+            const std::vector<float>* mats6[4] = {mats[0], mats[1], mats[2], get(prefix + ".weight_ih_l0", (size_t)4 * D * D)};
+            for (int m = 0; m < 4; ++m)
                 for (int idx = 0; idx < LP_SLICES; ++idx)
                     for (int w = 0; w < 4; ++w)
                         for (int n = 0; n < 4; ++n)
                             for (int ks = 0; ks < 4; ++ks)
                                 for (int lane = 0; lane < 64; ++lane)
                                     for (int e = 0; e < 8; ++e) {
-                                        const float v = (*mats[m])[(size_t)(n * D + idx * 16 + (lane & 15)) * D + w * 128 + ks * 32 + 8 * (lane >> 4) + e];
+                                        const float v = (*mats6[m])[(size_t)(n * D + idx * 16 + (lane & 15)) * D + w * 128 + ks * 32 + 8 * (lane >> 4) + e];
                                         uint32_t b;
                                         std::memcpy(&b, &v, 4);
                                         const uint32_t bh = b & 0xffff0000u;
@@ -1050,8 +1051,11 @@ int lstm_fwd(ac_handle* h, hipStream_t st, const LstmPlan& lp, const Act& x, con
     const int D = lp.D, T = x.L, L = lp.layers;
     if (D % 64 != 0 || D > 512) return fail(h, AC_EINVAL, "LSTM width %d unsupported (need 64, 128, 256 or 512)", D);
     if (L < 1 || L > 2) return fail(h, AC_EINVAL, "%d LSTM layers unsupported (1 or 2)", L);
+    const bool persist = lp.has_persist && h->lp_ctl && h->num_cus == 256 && !h->lstm_step_only && x.ts == D;
+    static const bool fuse_env = !(std::getenv("AC_LSTM_FUSE_IN") && std::getenv("AC_LSTM_FUSE_IN")[0] == '0');
+    const bool fuse_in = persist && !h->gemm_fp32 && fuse_env && aligned16(x.p) && x.bs % 4 == 0;   // lstm_persist6.h computes W_ih0 * x[t] itself
     // layer-0 input projection for all t: gin[t][b][4D]
-    {
+    if (!fuse_in) {
         TapGemmParams p{};
         p.nseg = 1;
         p.seg[0] = make_seg(x, 1, 1, PAD_ZERO, 0, 0, nullptr);
@@ -1069,10 +1073,10 @@ int lstm_fwd(ac_handle* h, hipStream_t st, const LstmPlan& lp, const Act& x, con
     }
     const int nroles = 2 * L - 1, nlaunch = T + 2 * (L - 1);
     const long long BD = (long long)((B + 31) / 32 * 32) * D, B4D = (long long)B * 4 * D;   // h lives in A-fragment tiles of 16 clips
-    if (lp.has_persist && h->lp_ctl && h->num_cus == 256 && !h->lstm_step_only && x.ts == D) {
+    if (persist) {
         // one cooperative launch per 64 clips walks all T steps (lstm_persist.h)
         const int chunks = cdiv(B, 64);
-        ProfScope ps(h, st, "lstm_persist_kernel", 2.0 * T * (double)B * 4 * D * D * nroles,
+        ProfScope ps(h, st, "lstm_persist_kernel", 2.0 * T * (double)B * 4 * D * D * (nroles + (fuse_in ? 1 : 0)),
                      (double)T * ((double)B * 4 * D * 4 + 3.0 * B * D * 4) + 12.0 * D * D * 4, chunks);
         for (int c0 = 0; c0 < B; c0 += 64) {
             LstmPersistParams q{};
@@ -1100,6 +1104,8 @@ int lstm_fwd(ac_handle* h, hipStream_t st, const LstmPlan& lp, const Act& x, con
                 q6.base = q;
                 q6.base.h_ts = (long long)((B + 31) / 32 * 2) * LP6_GROUP_BYTES;
                 q6.w_pk6 = reinterpret_cast<const __bf16*>(h->blob + lp.persist6_off);
+                q6.bias0 = h->blob + lp.ih[0].b_off;
+                q6.fuse_in = fuse_in ? 1 : 0;
                 HIPCHK(h, hipMemsetAsync(h->lp_ctl, 0, LP_CTL_WORDS * sizeof(unsigned), st));
                 void* args6[] = {&q6};
                 HIPCHK(h, hipLaunchCooperativeKernel(reinterpret_cast<const void*>(lstm_persist6_kernel), dim3(256), dim3(256), args6, 0, st));

@@ -11,6 +11,7 @@
 #pragma once
 #include "lstm_persist.h"
 #include "tap_gemm6.h"
+#include "rb_fused6.h"
 
 namespace ac {
 
@@ -19,7 +20,11 @@ constexpr long long LP6_GROUP_BYTES = (long long)LP_SLICES * LP6_SLICE_BYTES;   
 
 struct LstmPersist6Params {
     LstmPersistParams base;     // hseq0 / hseq1 are byte buffers of bf16 plane blocks here; h_ts = bytes per time step
-    const __bf16* w_pk6;
+    const __bf16* w_pk6;        // [hh0, ih1, hh1, ih0] register images
+    const float* bias0;         // fuse_in: b_ih0 + b_hh0 [4D]
+    int fuse_in;                // 1: the layer-0 slices compute W_ih0 * x[t] themselves (x = base.skip, fp32 [B][T][D]) instead of
+                                //    reading a pre-computed gin0 -- the [T*B][4D] projection GEMM and its HBM round trip disappear;
+                                //    layer 0 has the slack (its step is shorter than layer 1's, which bounds the kernel)
 };
 
 __global__ __launch_bounds__(256) void lstm_persist6_kernel(const LstmPersist6Params pp) {
@@ -49,7 +54,7 @@ __global__ __launch_bounds__(256) void lstm_persist6_kernel(const LstmPersist6Pa
         const long long mat = (long long)LP_SLICES * 4 * 4 * 4 * 3 * 512;      // bf16 elements per matrix
         const __bf16* base = pp.w_pk6 + ((long long)idx * 4 + wave) * (4 * 4 * 3 * 512) + lane * 8;
         const __bf16* pa = base + (layer == 0 ? 0 : mat);
-        const __bf16* pb = base + 2 * mat;
+        const __bf16* pb = base + (layer == 0 ? 3 : 2) * mat;  // layer 0 (fuse_in): W_ih0
 #pragma unroll
         for (int n = 0; n < 4; ++n)
 #pragma unroll
@@ -57,7 +62,7 @@ __global__ __launch_bounds__(256) void lstm_persist6_kernel(const LstmPersist6Pa
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl) {
                     wa[n][ks][pl] = *reinterpret_cast<const bf16x8*>(pa + ((n * 4 + ks) * 3 + pl) * 512);
-                    if (layer) wb[n][ks][pl] = *reinterpret_cast<const bf16x8*>(pb + ((n * 4 + ks) * 3 + pl) * 512);
+                    if (layer || pp.fuse_in) wb[n][ks][pl] = *reinterpret_cast<const bf16x8*>(pb + ((n * 4 + ks) * 3 + pl) * 512);
                     else wb[n][ks][pl] = wa[n][ks][pl];
                 }
     }
@@ -76,9 +81,10 @@ __global__ __launch_bounds__(256) void lstm_persist6_kernel(const LstmPersist6Pa
     const int eu = u0 + ej;
     float cstate = 0.f;
     float bq[4] = {0.f, 0.f, 0.f, 0.f};
-    if (layer == 1) {
+    const bool fuse0 = layer == 0 && pp.fuse_in;
+    if (layer == 1 || fuse0) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) bq[q] = p.bias1[q * D + eu];
+        for (int q = 0; q < 4; ++q) bq[q] = (layer ? p.bias1 : pp.bias0)[q * D + eu];
     }
     const int hpos = ec * 32 + ej * 2;                         // byte offset of (clip, unit) inside a plane of the slice block
 
@@ -109,6 +115,47 @@ __global__ __launch_bounds__(256) void lstm_persist6_kernel(const LstmPersist6Pa
             }
     };
     f32x4 accP[4];
+    // layer 0 (fuse_in): accP = W_ih0 * x[t].  x is fp32 in HBM; a lane's 8 floats per k-step travel through LDS as two
+    // 16-byte LDS-DMA pieces that the SAME lane reads back (lane-linear image, no cross-lane hand-over: the issuing wave's
+    // own vmcnt wait orders them), fetched one step ahead without holding registers, and are split here.
+    __shared__ __attribute__((aligned(16))) float xs_lds[4][8][256];        // [wave][piece = 2 ks + half][lane * 4]
+    const bool xlive = g * 16 + li < p.B;
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.skip + (long long)(p.clip0 + g * 16) * p.skip_bs), 0, (int)(((long long)(p.B - g * 16 < 16 ? p.B - g * 16 : 16)) * p.skip_bs * 4), 0x00020000);
+    const int xoff = xlive ? (int)((long long)li * p.skip_bs * 4) + (wave * 128 + 8 * kq) * 4 : 0x7fff0000;
+    auto fetch0 = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void*)&xs_lds[wave][i][0], 16,
+                                                     xlive ? xoff + (t * D + (i >> 1) * 32 + (i & 1) * 4) * 4 : 0x7fff0000, 0, 0, 0);
+    };
+    auto project0 = [&](int t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // the pieces of x[t] have landed
+        bf16x8 a[4][3];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(&xs_lds[wave][2 * ks][lane * 4]);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(&xs_lds[wave][2 * ks + 1][lane * 4]);
+            unsigned h[8], m[8], l[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { split3(v0[e], h[e], m[e], l[e]); split3(v1[e], h[4 + e], m[4 + e], l[4 + e]); }
+            u32x4_t ph, pm, pl;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                ph[e] = (h[2 * e] >> 16) | h[2 * e + 1];
+                pm[e] = (m[2 * e] >> 16) | m[2 * e + 1];
+                pl[e] = (l[2 * e] >> 16) | (l[2 * e + 1] & 0xffff0000u);
+            }
+            a[ks][0] = __builtin_bit_cast(bf16x8, ph);
+            a[ks][1] = __builtin_bit_cast(bf16x8, pm);
+            a[ks][2] = __builtin_bit_cast(bf16x8, pl);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                    // reads done before the next fetch overwrites the pieces
+        if (t + 1 < p.T) fetch0(t + 1);
+#pragma unroll
+        for (int n = 0; n < 4; ++n) accP[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        mac(a, wb, accP);
+    };
     auto project = [&](int t) -> bool {
         if (wave == 0) { const bool ok = lp_wait(flags0, (unsigned)(t + 1), tmo, lane, p.dbg); if (lane == 0) s_okp = ok; }
         __syncthreads();
@@ -123,16 +170,17 @@ __global__ __launch_bounds__(256) void lstm_persist6_kernel(const LstmPersist6Pa
 #pragma unroll
     for (int n = 0; n < 4; ++n) accP[n] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (layer == 1 && !project(0)) return;
+    if (fuse0) { fetch0(0); project0(0); }
 
     for (int t = 0; t < p.T; ++t) {
         float gpre[4] = {bq[0], bq[1], bq[2], bq[3]};
         float skipv = 0.f;
         if (live) {
-            if (layer == 0) {
+            if (layer == 0 && !pp.fuse_in) {
                 const float* gp = p.gin0 + (long long)t * p.gin_ts + erow * (4 * D);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) gpre[q] = gp[q * D + eu];
-            } else if (p.skip) {
+            } else if (layer == 1 && p.skip) {
                 skipv = p.skip[erow * p.skip_bs + (long long)t * D + eu];
             }
         }
@@ -182,6 +230,8 @@ __global__ __launch_bounds__(256) void lstm_persist6_kernel(const LstmPersist6Pa
                 if (p.yout_elu) p.yout_elu[o] = elu1(yv);
             }
             if (t + 1 < p.T && !project(t + 1)) return;
+        } else if (fuse0 && t + 1 < p.T) {
+            project0(t + 1);
         }
     }
 }
