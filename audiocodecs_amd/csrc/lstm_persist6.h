@@ -12,6 +12,7 @@
 #include "lstm_persist.h"
 #include "tap_gemm6.h"
 #include "rb_fused6.h"
+#include <type_traits>
 
 namespace ac {
 
@@ -26,6 +27,14 @@ struct LstmPersist6Params {
                                 //    reading a pre-computed gin0 -- the [T*B][4D] projection GEMM and its HBM round trip disappear;
                                 //    layer 0 has the slack (its step is shorter than layer 1's, which bounds the kernel)
 };
+
+// workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every outstanding global access (its
+// release fence), i.e. it would drain the LDS-DMA fetch that is meant to stay in flight across it
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
 
 __global__ __launch_bounds__(256) void lstm_persist6_kernel(const LstmPersist6Params pp) {
     const LstmPersistParams& p = pp.base;
@@ -46,7 +55,12 @@ __global__ __launch_bounds__(256) void lstm_persist6_kernel(const LstmPersist6Pa
     const int G = (p.B + 15) >> 4;
     if (slot >= 32 || g >= G) return;
     if ((p.dbg & 1) && (slot >> 4) == 1) return;
-    const int layer = slot >> 4, idx = (x & 1) * 16 + (slot & 15), u0 = idx * 16;
+    const int layer_rt = slot >> 4, idx = (x & 1) * 16 + (slot & 15), u0 = idx * 16;
+    // the two roles are compiled as separate bodies (the layer is a compile-time constant inside): at 510 of 512 registers
+    // the allocator needs every dead path of the other role gone -- a spill inside the step loop is a scratch access
+    // on the same in-order memory counter as the exchange loads and the LDS-DMA fetch
+    auto body = [&](auto layer_tag) {
+    constexpr int layer = decltype(layer_tag)::value;
 
     // ---- weights -> registers: [gate][k-step of 32][plane]
     bf16x8 wa[4][4][3], wb[4][4][3];                          // layer 0: wa = W_hh0;  layer 1: wa = W_ih1, wb = W_hh1
@@ -189,7 +203,7 @@ __global__ __launch_bounds__(256) void lstm_persist6_kernel(const LstmPersist6Pa
         for (int n = 0; n < 4; ++n) acc[n] = accP[n];
         if (t > 0) {
             if (wave == 0) { const bool ok = lp_wait(layer ? flags1 : flags0, (unsigned)t, tmo, lane, p.dbg); if (lane == 0) s_okr = ok; }
-            __syncthreads();
+            lds_barrier();
             if (!s_okr) return;
             bf16x8 a[4][3];
             load_a(hmine, t - 1, a);
@@ -200,7 +214,7 @@ __global__ __launch_bounds__(256) void lstm_persist6_kernel(const LstmPersist6Pa
         for (int n = 0; n < 4; ++n)
 #pragma unroll
             for (int r = 0; r < 4; ++r) part[wave][n][kq * 4 + r][li] = acc[n][r];
-        __syncthreads();
+        lds_barrier();
         float pre[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) pre[q] = gpre[q] + ((part[0][q][ec][ej] + part[1][q][ec][ej]) + (part[2][q][ec][ej] + part[3][q][ec][ej]));
@@ -234,6 +248,9 @@ __global__ __launch_bounds__(256) void lstm_persist6_kernel(const LstmPersist6Pa
             project0(t + 1);
         }
     }
+    };
+    if (layer_rt == 0) body(std::integral_constant<int, 0>{});
+    else body(std::integral_constant<int, 1>{});
 }
 
 }  // namespace ac
