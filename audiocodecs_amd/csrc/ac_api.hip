@@ -1107,6 +1107,10 @@ int lstm_fwd(ac_handle* h, hipStream_t st, const LstmPlan& lp, const Act& x, con
                 q6.bias0 = h->blob + lp.ih[0].b_off;
                 q6.fuse_in = fuse_in ? 1 : 0;
                 HIPCHK(h, hipMemsetAsync(h->lp_ctl, 0, LP_CTL_WORDS * sizeof(unsigned), st));
+                // the exchange validates itself: every element of the h buffers starts as the "not yet written" pattern
+                const size_t hbytes = (size_t)T * (size_t)q6.base.h_ts;
+                HIPCHK(h, hipMemsetAsync(ws.hseq0, 0xFF, hbytes, st));
+                HIPCHK(h, hipMemsetAsync(ws.hseq1, 0xFF, hbytes, st));
                 void* args6[] = {&q6};
                 HIPCHK(h, hipLaunchCooperativeKernel(reinterpret_cast<const void*>(lstm_persist6_kernel), dim3(256), dim3(256), args6, 0, st));
                 continue;

@@ -39,9 +39,8 @@ __device__ __forceinline__ void lds_barrier() {
 __global__ __launch_bounds__(256) void lstm_persist6_kernel(const LstmPersist6Params pp) {
     const LstmPersistParams& p = pp.base;
     constexpr int D = LP_D;
-    __shared__ float part[4][4][16][17];
+    __shared__ float part[2][4][4][16][17];      // by step parity: one barrier per step separates its write from its reads
     __shared__ unsigned s_x, s_slot;
-    __shared__ int s_okp, s_okr;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, kq = lane >> 4;
     unsigned* tmo = p.ctl + LP_CTL_TIMEOUT;
@@ -80,9 +79,6 @@ __global__ __launch_bounds__(256) void lstm_persist6_kernel(const LstmPersist6Pa
                     else wb[n][ks][pl] = wa[n][ks][pl];
                 }
     }
-    unsigned* flags0 = p.ctl + LP_CTL_FLAGS + ((g * 2 + 0) * LP_SLICES) * LP_FLAG_STRIDE;
-    unsigned* flags1 = p.ctl + LP_CTL_FLAGS + ((g * 2 + 1) * LP_SLICES) * LP_FLAG_STRIDE;
-    unsigned* myflag = (layer ? flags1 : flags0) + idx * LP_FLAG_STRIDE;
     char* h0b = reinterpret_cast<char*>(p.hseq0);
     char* h1b = reinterpret_cast<char*>(p.hseq1);
     char* hmine = layer ? h1b : h0b;
@@ -128,6 +124,28 @@ __global__ __launch_bounds__(256) void lstm_persist6_kernel(const LstmPersist6Pa
                 acc[n] = v;
             }
     };
+    // SELF-VALIDATING exchange.  The host fills hseq0 / hseq1 with 0xFF bytes before the launch; every published bf16 term
+    // has |v| < 2, i.e. bit 14 (the exponent's top bit) clear, the fill pattern has it set.  A consumer therefore needs no
+    // flag: it loads the operand and looks at bit 14 of every element -- the data says itself whether it has arrived, in
+    // whatever order the memory system performs the loads.  One round trip instead of flag poll + dependent load; a wave
+    // retries only its own K quarter.  Spins are bounded by the timeout word as before.
+    auto load_valid = [&](const char* seq, int t, bf16x8 (&a)[4][3]) -> bool {
+        for (unsigned spins = 0;; ++spins) {
+            load_a(seq, t, a);
+            unsigned bad = 0;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    const u32x4_t w = __builtin_bit_cast(u32x4_t, a[ks][pl]);
+                    bad |= (w.x | w.y) | (w.z | w.w);
+                }
+            if (__all((bad & 0x40004000u) == 0u) || (p.dbg & 4)) return true;
+            if ((spins & 63) == 63 && __hip_atomic_load(tmo, LP_RLX)) return false;
+            if (spins > (1u << 18)) { __hip_atomic_store(tmo, 1u, LP_RLX); return false; }
+            __builtin_amdgcn_s_sleep(4);
+        }
+    };
     f32x4 accP[4];
     // layer 0 (fuse_in): accP = W_ih0 * x[t].  x is fp32 in HBM; a lane's 8 floats per k-step travel through LDS as two
     // 16-byte LDS-DMA pieces that the SAME lane reads back (lane-linear image, no cross-lane hand-over: the issuing wave's
@@ -171,11 +189,8 @@ __global__ __launch_bounds__(256) void lstm_persist6_kernel(const LstmPersist6Pa
         mac(a, wb, accP);
     };
     auto project = [&](int t) -> bool {
-        if (wave == 0) { const bool ok = lp_wait(flags0, (unsigned)(t + 1), tmo, lane, p.dbg); if (lane == 0) s_okp = ok; }
-        __syncthreads();
-        if (!s_okp) return false;
         bf16x8 a[4][3];
-        load_a(h0b, t, a);
+        if (!load_valid(h0b, t, a)) return false;
 #pragma unroll
         for (int n = 0; n < 4; ++n) accP[n] = f32x4{0.f, 0.f, 0.f, 0.f};
         mac(a, wa, accP);
@@ -202,26 +217,24 @@ __global__ __launch_bounds__(256) void lstm_persist6_kernel(const LstmPersist6Pa
 #pragma unroll
         for (int n = 0; n < 4; ++n) acc[n] = accP[n];
         if (t > 0) {
-            if (wave == 0) { const bool ok = lp_wait(layer ? flags1 : flags0, (unsigned)t, tmo, lane, p.dbg); if (lane == 0) s_okr = ok; }
-            lds_barrier();
-            if (!s_okr) return;
             bf16x8 a[4][3];
-            load_a(hmine, t - 1, a);
+            if (!load_valid(hmine, t - 1, a)) return;
             if (layer == 0) mac(a, wa, acc);
             else mac(a, wb, acc);
         }
+        float (&pt)[4][4][16][17] = part[t & 1];
 #pragma unroll
         for (int n = 0; n < 4; ++n)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) part[wave][n][kq * 4 + r][li] = acc[n][r];
+            for (int r = 0; r < 4; ++r) pt[wave][n][kq * 4 + r][li] = acc[n][r];
         lds_barrier();
         float pre[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) pre[q] = gpre[q] + ((part[0][q][ec][ej] + part[1][q][ec][ej]) + (part[2][q][ec][ej] + part[3][q][ec][ej]));
+        for (int q = 0; q < 4; ++q) pre[q] = gpre[q] + ((pt[0][q][ec][ej] + pt[1][q][ec][ej]) + (pt[2][q][ec][ej] + pt[3][q][ec][ej]));
         const float ig = sigmoidf_(pre[0]), fg = sigmoidf_(pre[1]), gg = tanhf_(pre[2]), og = sigmoidf_(pre[3]);
         cstate = fg * cstate + ig * gg;
         const float hn = og * tanhf_(cstate);
-        // ---- publish h[t]: this thread's value as three exact bf16 terms, then the flag
+        // ---- publish h[t]: this thread's value as three exact bf16 terms (no flag, no wait: see load_valid)
         {
             const unsigned bh = __float_as_uint(hn) & 0xffff0000u;
             const float r1 = hn - __uint_as_float(bh);
@@ -233,9 +246,6 @@ __global__ __launch_bounds__(256) void lstm_persist6_kernel(const LstmPersist6Pa
             __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(bm >> 16), rs, 512 + hpos, 0, LP_SC1);
             __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(bl >> 16), rs, 1024 + hpos, 0, LP_SC1);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) __hip_atomic_store(myflag, (unsigned)(t + 1), LP_RLX);
         if (layer == 1) {
             if (live) {
                 const float yv = hn + skipv;
