@@ -170,6 +170,20 @@ def test_odd_batches_against_oracle(B, T, codecs, checkpoints):
     assert rms((rec - orec).numpy()) < 1e-5
 
 
+@pytest.mark.parametrize("B,T", [(80, 24000), (130, 9600)])
+def test_batches_beyond_one_lstm_launch(B, T, codecs):
+    """More than 64 clips: the persistent LSTM runs once per 64-clip chunk (the self-validating h buffers are re-filled
+    before every launch); clips are independent units, so any split of the batch gives the same ids and samples."""
+    codec = codecs("full", 0)
+    sig = noise(2000 + B, B, T).cuda()
+    toks = codec.sig_to_toks(sig)
+    parts = torch.cat([codec.sig_to_toks(sig[i : i + 16]) for i in range(0, B, 16)])
+    assert torch.equal(toks, parts)
+    rec = codec.toks_to_sig(toks)
+    recp = torch.cat([codec.toks_to_sig(toks[i : i + 16]) for i in range(0, B, 16)])
+    assert torch.equal(rec, recp)
+
+
 def test_rest_of_codec_api(codecs, checkpoints):
     from oracle import encodec_oracle as O
 
