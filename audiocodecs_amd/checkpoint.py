@@ -136,7 +136,14 @@ def fold_weight_norm(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
             g = v.detach().to(torch.float32).cpu()
             vv = sd[prefix + ".parametrizations.weight.original1"].detach().to(torch.float32).cpu()
             out[prefix + ".weight"] = torch._weight_norm(vv, g, 0).contiguous()
-        elif ".parametrizations.weight.original1" in k:
+        elif k.endswith(".weight_g") and k[: -len("_g")] + "_v" in sd:
+            # old-style torch.nn.utils.weight_norm naming -- what checkpoints saved before the parametrization API
+            # (and the Hub's model.safetensors, which transformers renames at load time) carry
+            prefix = k[: -len(".weight_g")]
+            g = v.detach().to(torch.float32).cpu()
+            vv = sd[prefix + ".weight_v"].detach().to(torch.float32).cpu()
+            out[prefix + ".weight"] = torch._weight_norm(vv, g, 0).contiguous()
+        elif ".parametrizations.weight.original1" in k or (k.endswith(".weight_v") and k[: -len("_v")] + "_g" in sd):
             continue
         else:
             out[k] = v.detach().cpu().contiguous()

@@ -110,7 +110,7 @@ struct ProfRec {
 
 }  // namespace
 
-enum { ARCH_ENCODEC = 0, ARCH_MIMI = 1, ARCH_DAC = 2 };
+enum { ARCH_ENCODEC = 0, ARCH_MIMI = 1, ARCH_DAC = 2, ARCH_WAVTOK = 3 };
 
 struct ac_handle {
     int arch = ARCH_ENCODEC;
@@ -144,11 +144,15 @@ struct ac_handle {
     // split-operand weights (tap_gemm6.h): float offset of a packed fp32 matrix -> float offset of its bf16 planes
     std::map<size_t, size_t> w6_of;
     std::map<size_t, size_t> t6_of;   // thin_conv6.h fragment images of the [64][128] layers, keyed like w6_of
+    bool has_enc = true, has_dec = true;   // a half the caller's mode never runs may be left out (encodec.py:67-71)
     bool gemm_fp32 = false;         // AC_GEMM=fp32: exact-product kernels only
     // persistent LSTM (lstm_persist.h): control words, device shape, opt-out (AC_LSTM=step)
     unsigned* lp_ctl = nullptr;
     int num_cus = 0;
     bool lstm_step_only = false;
+    // sticky status words (lstm_persist.h ST_*): host-pinned, device-mapped -- read on the host without synchronising
+    unsigned* sticky = nullptr;       // host view
+    unsigned* sticky_dev = nullptr;   // device view of the same words
     // profiling
     bool prof = false;
     bool prof_detail = false;   // AC_PROF_DETAIL=1: one record per tap-GEMM shape
@@ -1076,8 +1080,25 @@ int lstm_fwd(ac_handle* h, hipStream_t st, const LstmPlan& lp, const Act& x, con
     if (persist) {
         // one cooperative launch per 64 clips walks all T steps (lstm_persist.h)
         const int chunks = cdiv(B, 64);
-        ProfScope ps(h, st, "lstm_persist_kernel", 2.0 * T * (double)B * 4 * D * D * (nroles + (fuse_in ? 1 : 0)),
+        int* poison = reinterpret_cast<int*>(ws.c);   // the cell-state buffer of the per-step kernels is free on this path
+        if (!h->gemm_fp32) HIPCHK(h, hipMemsetAsync(poison, 0x7f, (size_t)B * sizeof(int), st));
+        ProfScope ps(h, st, h->gemm_fp32 ? "lstm_persist_kernel" : "lstm_persist6_kernel", 2.0 * T * (double)B * 4 * D * D * (nroles + (fuse_in ? 1 : 0)),
                      (double)T * ((double)B * 4 * D * 4 + 3.0 * B * D * 4) + 12.0 * D * D * 4, chunks);
+        auto tail = [&](int c0, int nb, const int* pz) {
+            LstmTailParams tp{};
+            tp.ctl = h->lp_ctl;
+            tp.sticky = h->sticky_dev;
+            tp.poison = pz;
+            tp.yout = out.raw;
+            tp.yout_elu = out.elu;
+            tp.y_bs = (long long)T * D;
+            tp.clip0 = c0;
+            tp.B = nb;
+            tp.T = T;
+            tp.D = D;
+            tp.xcds_used = 8;
+            hipLaunchKernelGGL(lstm_tail_kernel, dim3(nb, 4), dim3(256), 0, st, tp);
+        };
         for (int c0 = 0; c0 < B; c0 += 64) {
             LstmPersistParams q{};
             q.gin0 = ws.gin;
@@ -1106,6 +1127,7 @@ int lstm_fwd(ac_handle* h, hipStream_t st, const LstmPlan& lp, const Act& x, con
                 q6.w_pk6 = reinterpret_cast<const __bf16*>(h->blob + lp.persist6_off);
                 q6.bias0 = h->blob + lp.ih[0].b_off;
                 q6.fuse_in = fuse_in ? 1 : 0;
+                q6.poison = poison;
                 HIPCHK(h, hipMemsetAsync(h->lp_ctl, 0, LP_CTL_WORDS * sizeof(unsigned), st));
                 // the exchange validates itself: every element of the h buffers starts as the "not yet written" pattern
                 const size_t hbytes = (size_t)T * (size_t)q6.base.h_ts;
@@ -1113,12 +1135,15 @@ int lstm_fwd(ac_handle* h, hipStream_t st, const LstmPlan& lp, const Act& x, con
                 HIPCHK(h, hipMemsetAsync(ws.hseq1, 0xFF, hbytes, st));
                 void* args6[] = {&q6};
                 HIPCHK(h, hipLaunchCooperativeKernel(reinterpret_cast<const void*>(lstm_persist6_kernel), dim3(256), dim3(256), args6, 0, st));
+                tail(c0, q.B, poison);
                 continue;
             }
             HIPCHK(h, hipMemsetAsync(h->lp_ctl, 0, LP_CTL_WORDS * sizeof(unsigned), st));
             void* args[] = {&q};
             HIPCHK(h, hipLaunchCooperativeKernel(reinterpret_cast<const void*>(lstm_persist_kernel), dim3(256), dim3(256), args, 0, st));
+            tail(c0, q.B, nullptr);
         }
+        HIPCHK(h, hipGetLastError());
         y->raw = Act{out.raw, (long long)T * D, D, T, D};
         y->elu = Act{out.elu, (long long)T * D, D, T, D};
         return AC_OK;
@@ -1235,6 +1260,7 @@ int rvq_decode_fwd(ac_handle* h, hipStream_t st, const long long* toks, int F, i
     p.tk0 = 0;
     p.os = p.H;
     const long long n = (long long)F * (p.H / 4);
+    p.bad = h->sticky_dev ? h->sticky_dev + ST_BAD_TOKEN : nullptr;
     ProfScope ps(h, st, "rvq_decode_kernel", (double)F * p.H * K, (double)F * K * 8 + (double)F * p.H * 4 * (K + 1));
     hipLaunchKernelGGL(rvq_decode_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p);
     HIPCHK(h, hipGetLastError());
@@ -1316,9 +1342,29 @@ int carve(ac_handle* h, const Workspace& w, void* ws, size_t ws_bytes, WsPtrs* o
     return AC_OK;
 }
 
+// Failures a kernel can only detect on the device surface here, at the NEXT entry point of the handle (no entry point
+// synchronises): the failed call's outputs were set to NaN by the device, never left unwritten.
 int check_ready(ac_handle* h) {
     if (!h) return AC_EINVAL;
     if (!h->finalized) return fail(h, AC_ESTATE, "ac_finalize has not been called");
+    if (h->sticky) {
+        volatile unsigned* s = h->sticky;
+        if (s[ST_LSTM_TIMEOUT] || s[ST_LSTM_PLACEMENT]) {
+            const unsigned a = s[ST_LSTM_TIMEOUT], b = s[ST_LSTM_PLACEMENT];
+            s[ST_LSTM_TIMEOUT] = 0;
+            s[ST_LSTM_PLACEMENT] = 0;
+            h->lstm_step_only = true;   // self-heal: the per-step kernels need no co-residency
+            return fail(h, AC_EHIP,
+                        "an EARLIER call's persistent LSTM launch failed (%u bounded waits expired, %u launches without 32 workgroups on "
+                        "every XCD -- is the GPU shared?): that call's outputs were set to NaN; the handle now uses the per-step LSTM "
+                        "kernels, repeat the call", a, b);
+        }
+        if (s[ST_BAD_TOKEN]) {
+            const unsigned a = s[ST_BAD_TOKEN];
+            s[ST_BAD_TOKEN] = 0;
+            return fail(h, AC_EINVAL, "an EARLIER ac_decode / ac_dequantize call got %u token ids outside [0, codebook_size): those frames were set to NaN", a);
+        }
+    }
     return AC_OK;
 }
 
@@ -1343,7 +1389,7 @@ int encoder_fwd(ac_handle* h, hipStream_t st, const float* sig, const float* rel
     int rc;
     // a 32-channel ResBlock activates its raw input itself (rb_fused.h): no ELU'd flavour needed in HBM
     auto rb_self_elu = [&](int C) {
-        return (C == 32 || C == 64 || (C == 128 && !dbg && c.num_ratios > 2 && rb128_ok(h, h->enc_rb[2]))) && c.residual_kernel_size == 3 && c.compress == 2;
+        return (C == 32 || C == 64 || (C == 128 && c.num_ratios > 2 && rb128_ok(h, h->enc_rb[2]))) && c.residual_kernel_size == 3 && c.compress == 2;
     };
     if (thin_ok(c, c.kernel_size))
         rc = stem_fwd(h, st, sig, rel_len, B, T, Out{ws.take(), rb_self_elu(c.num_filters) ? nullptr : ws.take()}, &x);
@@ -1401,7 +1447,7 @@ int decoder_fwd(ac_handle* h, hipStream_t st, const long long* toks, int B, int 
     x = y;
     for (int i = 0; i < c.num_ratios; ++i) {
         const int cup = h->dec_up[i].N / c.upsampling_ratios[i];
-        const bool self_elu = (cup == 32 || cup == 64 || (cup == 128 && !dbg && rb128_ok(h, h->dec_rb[i]))) && c.residual_kernel_size == 3 &&
+        const bool self_elu = (cup == 32 || cup == 64 || (cup == 128 && rb128_ok(h, h->dec_rb[i]))) && c.residual_kernel_size == 3 &&
                               c.compress == 2;   // rb_fused.h / rb_fused6*.h activate raw rows themselves
         rc = convtr_fwd(h, st, h->dec_up[i], x.elu, c.upsampling_ratios[i], Out{ws.take(), self_elu ? nullptr : ws.take()}, B, &y);
         if (rc) return rc;
@@ -1536,6 +1582,9 @@ static int upload_blob(ac_handle* h, Packer& pk, int device) {
     h->lstm_step_only = lm && std::strcmp(lm, "step") == 0;
     HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&h->lp_ctl), LP_CTL_WORDS * sizeof(unsigned)));
     HIPCHK(h, hipMemset(h->lp_ctl, 0, LP_CTL_WORDS * sizeof(unsigned)));
+    HIPCHK(h, hipHostMalloc(reinterpret_cast<void**>(&h->sticky), ST_WORDS * sizeof(unsigned), hipHostMallocMapped));
+    std::memset(h->sticky, 0, ST_WORDS * sizeof(unsigned));
+    HIPCHK(h, hipHostGetDevicePointer(reinterpret_cast<void**>(&h->sticky_dev), h->sticky, 0));
     if (h->num_cus == 256 && !h->lstm_step_only) {
         // the persistent LSTM assigns roles from XCC_ID: use it only where a 256-workgroup cooperative launch really
         // lands 32 workgroups on each of 8 XCDs (otherwise: the per-step kernel)
@@ -1572,24 +1621,36 @@ int ac_finalize(ac_handle* h) {
     const ac_config& c = h->cfg;
     Arch a = make_arch(c);
     Packer pk{h};
-    bool ok = pk.conv(a.enc_stem, h->enc_stem);
+    // a caller in encode-only / decode-only mode hands over just that half (encodec.py:67-71 deletes the other one)
+    h->has_enc = h->has_dec = false;
+    for (const auto& kv : h->host) {
+        if (kv.first.compare(0, 8, "encoder.") == 0) h->has_enc = true;
+        if (kv.first.compare(0, 8, "decoder.") == 0) h->has_dec = true;
+    }
+    if (!h->has_enc && !h->has_dec) return fail(h, AC_ESTATE, "no encoder.* or decoder.* tensor was loaded");
+    bool ok = true;
     h->enc_rb.resize(c.num_ratios);
     h->enc_down.resize(c.num_ratios);
     h->dec_up.resize(c.num_ratios);
     h->dec_rb.resize(c.num_ratios);
-    for (int i = 0; ok && i < c.num_ratios; ++i) {
-        ok = ok && pk.resblock(a.enc_rb3[i], a.enc_rb1[i], a.enc_rbs[i], h->enc_rb[i]);
-        ok = ok && pk.conv(a.enc_down[i], h->enc_down[i]);
+    if (h->has_enc) {
+        ok = pk.conv(a.enc_stem, h->enc_stem);
+        for (int i = 0; ok && i < c.num_ratios; ++i) {
+            ok = ok && pk.resblock(a.enc_rb3[i], a.enc_rb1[i], a.enc_rbs[i], h->enc_rb[i]);
+            ok = ok && pk.conv(a.enc_down[i], h->enc_down[i]);
+        }
+        ok = ok && pk.lstm(a.enc_lstm, a.D, c.num_lstm_layers, h->enc_lstm);
+        ok = ok && pk.conv(a.enc_final, h->enc_final);
     }
-    ok = ok && pk.lstm(a.enc_lstm, a.D, c.num_lstm_layers, h->enc_lstm);
-    ok = ok && pk.conv(a.enc_final, h->enc_final);
-    ok = ok && pk.conv(a.dec_first, h->dec_first);
-    ok = ok && pk.lstm(a.dec_lstm, a.D, c.num_lstm_layers, h->dec_lstm);
-    for (int i = 0; ok && i < c.num_ratios; ++i) {
-        ok = ok && pk.convtr(a.dec_up[i], h->dec_up[i]);
-        ok = ok && pk.resblock(a.dec_rb3[i], a.dec_rb1[i], a.dec_rbs[i], h->dec_rb[i]);
+    if (h->has_dec) {
+        ok = ok && pk.conv(a.dec_first, h->dec_first);
+        ok = ok && pk.lstm(a.dec_lstm, a.D, c.num_lstm_layers, h->dec_lstm);
+        for (int i = 0; ok && i < c.num_ratios; ++i) {
+            ok = ok && pk.convtr(a.dec_up[i], h->dec_up[i]);
+            ok = ok && pk.resblock(a.dec_rb3[i], a.dec_rb1[i], a.dec_rbs[i], h->dec_rb[i]);
+        }
+        ok = ok && pk.conv(a.dec_head, h->dec_head);
     }
-    ok = ok && pk.conv(a.dec_head, h->dec_head);
     if (!ok) return pk.rc;
     // codebooks: plain [K][C][H], MFMA B-fragment order, squared norms
     const int C = c.codebook_size, H = c.hidden_size, Q = c.num_quantizers;
@@ -1693,6 +1754,7 @@ int ac_encode_feats(ac_handle* h, const float* sig, const float* rel_len, int B,
     if (rc) return rc;
     if (!sig || !feats || B < 1 || T < 1) return fail(h, AC_EINVAL, "ac_encode_feats: bad argument (B=%d, T=%d)", B, T);
     if ((rc = check_len(h, T))) return rc;
+    if (!h->has_enc) return fail(h, AC_ESTATE, "ac_encode_feats: the handle was loaded without encoder weights (mode=\"decode\")");
     if (h->arch == ARCH_DAC) return dac_encode_impl(h, sig, B, T, 0, feats, nullptr, nullptr, nullptr, ws, ws_bytes, (hipStream_t)stream);
     WsPtrs p;
     rc = carve(h, any_plan_ws(h, B, T, 0, true), ws, ws_bytes, &p);
@@ -1707,6 +1769,7 @@ int ac_encode(ac_handle* h, const float* sig, const float* rel_len, int B, int T
     if (!sig || !toks || B < 1 || T < 1) return fail(h, AC_EINVAL, "ac_encode: bad argument (B=%d, T=%d)", B, T);
     if (K < 1 || K > num_q(h)) return fail(h, AC_EINVAL, "ac_encode: K=%d outside [1, %d]", K, num_q(h));
     if ((rc = check_len(h, T))) return rc;
+    if (!h->has_enc) return fail(h, AC_ESTATE, "ac_encode: the handle was loaded without encoder weights (mode=\"decode\")");
     if (h->arch == ARCH_DAC)
         return dac_encode_impl(h, sig, B, T, K, nullptr, nullptr, reinterpret_cast<long long*>(toks), nullptr, ws, ws_bytes, (hipStream_t)stream);
     WsPtrs p;
@@ -1777,6 +1840,7 @@ int ac_decode(ac_handle* h, const int64_t* toks, int B, int N, int K, float* sig
     if (!sig || !toks || B < 1 || N < 1) return fail(h, AC_EINVAL, "ac_decode: bad argument (B=%d, N=%d)", B, N);
     if (K < 1 || K > num_q(h)) return fail(h, AC_EINVAL, "ac_decode: K=%d outside [1, %d]", K, num_q(h));
     if ((rc = check_len(h, ac_num_samples(h, N)))) return rc;
+    if (!h->has_dec) return fail(h, AC_ESTATE, "ac_decode: the handle was loaded without decoder weights (mode=\"encode\")");
     if (h->arch == ARCH_DAC) {
         hipStream_t st = (hipStream_t)stream;
         const int Bc = dac_chunk_clips(h, B, 0, N, false);
@@ -1868,10 +1932,12 @@ int ac_encode_feats_latent(ac_handle* h, const float* sig, int B, int T, float* 
 int ac_lstm_status(ac_handle* h) {
     if (!h) return AC_EINVAL;
     if (!h->lp_ctl) return 0;
-    unsigned tmo = 0;
-    if (hipMemcpy(&tmo, h->lp_ctl + LP_CTL_TIMEOUT, sizeof tmo, hipMemcpyDeviceToHost) != hipSuccess) return AC_EHIP;
-    const bool usable = (h->arch == ARCH_ENCODEC) && h->enc_lstm.has_persist && h->num_cus == 256 && !h->lstm_step_only;
-    return tmo ? AC_EHIP : (usable ? 1 : 0);
+    if (hipDeviceSynchronize() != hipSuccess) return AC_EHIP;
+    const bool usable = (h->arch == ARCH_ENCODEC || h->arch == ARCH_WAVTOK) && h->enc_lstm.has_persist && h->num_cus == 256 && !h->lstm_step_only;
+    volatile unsigned* s = h->sticky;
+    if (s && (s[ST_LSTM_TIMEOUT] || s[ST_LSTM_PLACEMENT]))
+        return fail(h, AC_EHIP, "persistent LSTM: %u bounded waits expired, %u misplaced launches (outputs of those calls are NaN)", s[ST_LSTM_TIMEOUT], s[ST_LSTM_PLACEMENT]);
+    return usable ? 1 : 0;
 }
 
 int ac_debug_capture(ac_handle* h, float* buf_dev, size_t cap_floats) {
@@ -1932,6 +1998,7 @@ void ac_destroy(ac_handle* h) {
     if (!h) return;
     if (h->blob) (void)hipFree(h->blob);
     if (h->lp_ctl) (void)hipFree(h->lp_ctl);
+    if (h->sticky) (void)hipHostFree(h->sticky);
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
     delete h;
 }

@@ -303,6 +303,7 @@ int dac_from_codes(ac_handle* h, hipStream_t st, const long long* toks, int F, i
     p.tk0 = 0;
     p.os = m.H;
     const long long cnt = (long long)F * (m.H / 4);
+    p.bad = h->sticky_dev ? h->sticky_dev + ST_BAD_TOKEN : nullptr;
     ProfScope ps(h, st, "rvq_decode_kernel", (double)F * m.H * K, (double)F * K * 8 + (double)F * m.H * 4 * (K + 1));
     hipLaunchKernelGGL(rvq_decode_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, p);
     HIPCHK(h, hipGetLastError());

@@ -63,6 +63,57 @@ __global__ __launch_bounds__(256) void lstm_persist_probe_kernel(unsigned* hist)
     if (threadIdx.x == 0) atomicAdd(&hist[lp_xcc_id() & 15], 1u);
 }
 
+// Sticky status words of a handle (host-pinned, device-mapped: the host reads them without synchronising; they are
+// never cleared by a launch).  Written by lstm_tail_kernel / rvq_decode_kernel.
+enum { ST_LSTM_TIMEOUT = 0, ST_LSTM_PLACEMENT = 1, ST_BAD_TOKEN = 2, ST_NONFINITE_CLIPS = 3, ST_WORDS = 4 };
+constexpr int LP_NEVER = 0x7f7f7f7f;   // poison fill (hipMemsetAsync byte 0x7f): "this clip never went non-finite"
+
+struct LstmTailParams {
+    const unsigned* ctl;     // the launch's control words (slot counters, timeout word)
+    unsigned* sticky;        // ST_* words
+    const int* poison;       // [all clips] or null (exact-product kernel: NaN travels through the flags protocol unharmed)
+    float* yout;             // [all clips][T][D] (may be null)
+    float* yout_elu;
+    long long y_bs;
+    int clip0, B, T, D;      // the clips of this launch
+    int xcds_used;           // 2 * ceil(B / 16): XCDs whose slot counter must read 32 (the others: <= 32)
+};
+
+// Runs right behind every persistent launch on the same stream (grid = (B, 4)).
+//  * launch failed (bounded wait expired, or an XCD did not get its 32 workgroups): every output of the launch becomes
+//    NaN -- never unwritten memory -- and a sticky word is raised that the next API call on the handle reports;
+//  * a clip whose state went non-finite at step t0: its outputs from t0 on become NaN (what the reference computes).
+__global__ __launch_bounds__(256) void lstm_tail_kernel(const LstmTailParams p) {
+    const int b = blockIdx.x;
+    const unsigned tmo = p.ctl[LP_CTL_TIMEOUT];
+    bool placed = true;
+    for (int x = 0; x < 8; ++x) {
+        const unsigned n = p.ctl[LP_CTL_SLOTS + x * 16];
+        placed = placed && (x < p.xcds_used ? n == 32u : n <= 32u);
+    }
+    const bool failed = tmo != 0u || !placed;
+    if (failed && b == 0 && blockIdx.y == 0 && threadIdx.x == 0)
+        __hip_atomic_fetch_add(&p.sticky[(tmo == 2u || !placed) ? ST_LSTM_PLACEMENT : ST_LSTM_TIMEOUT], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    int t0 = p.T;
+    if (failed) t0 = 0;
+    else if (p.poison) {
+        const int q = p.poison[p.clip0 + b];
+        if (q < p.T) {
+            t0 = q;
+            if (blockIdx.y == 0 && threadIdx.x == 0)
+                __hip_atomic_fetch_add(&p.sticky[ST_NONFINITE_CLIPS], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+    if (t0 >= p.T) return;
+    const float nan = __uint_as_float(0x7fc00000u);
+    const long long n = (long long)(p.T - t0) * p.D;
+    const long long o = (long long)(p.clip0 + b) * p.y_bs + (long long)t0 * p.D;
+    for (long long i = (long long)blockIdx.y * 256 + threadIdx.x; i < n; i += 256LL * gridDim.y) {
+        if (p.yout) p.yout[o + i] = nan;
+        if (p.yout_elu) p.yout_elu[o + i] = nan;
+    }
+}
+
 // all 32 flags of (group, layer) >= want ?  polled by wave 0; returns false on timeout
 __device__ __forceinline__ bool lp_wait(unsigned* flags, unsigned want, unsigned* tmo, int lane, int dbg = 0) {
     if (dbg & 4) return true;
@@ -90,7 +141,11 @@ __global__ __launch_bounds__(256) void lstm_persist_kernel(const LstmPersistPara
     const int x = s_x & 7, slot = s_slot;
     const int g = x >> 1;                                     // clip group of this launch
     const int G = (p.B + 15) >> 4;
-    if (slot >= 32 || g >= G) return;
+    if (slot >= 32) {   // placement broken (see lstm_persist6.h)
+        if (tid == 0) __hip_atomic_store(tmo, 2u, LP_RLX);
+        return;
+    }
+    if (g >= G) return;
     if ((p.dbg & 1) && (slot >> 4) == 1) return;
     const int layer = slot >> 4, idx = (x & 1) * 16 + (slot & 15), u0 = idx * 16;
 

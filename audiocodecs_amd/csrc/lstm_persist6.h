@@ -26,6 +26,8 @@ struct LstmPersist6Params {
     int fuse_in;                // 1: the layer-0 slices compute W_ih0 * x[t] themselves (x = base.skip, fp32 [B][T][D]) instead of
                                 //    reading a pre-computed gin0 -- the [T*B][4D] projection GEMM and its HBM round trip disappear;
                                 //    layer 0 has the slack (its step is shorter than layer 1's, which bounds the kernel)
+    int* poison;                // [all clips] first time step at which a clip's state went non-finite (INT_MAX-like fill
+                                //    = never): see the publish step and lstm_tail_kernel
 };
 
 // workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every outstanding global access (its
@@ -52,7 +54,11 @@ __global__ __launch_bounds__(256) void lstm_persist6_kernel(const LstmPersist6Pa
     const int x = s_x & 7, slot = s_slot;
     const int g = x >> 1;
     const int G = (p.B + 15) >> 4;
-    if (slot >= 32 || g >= G) return;
+    if (slot >= 32) {   // more than 32 workgroups on this XCD: the placement the roles rely on does not hold -> everybody leaves
+        if (tid == 0) __hip_atomic_store(tmo, 2u, LP_RLX);
+        return;
+    }
+    if (g >= G) return;
     if ((p.dbg & 1) && (slot >> 4) == 1) return;
     const int layer_rt = slot >> 4, idx = (x & 1) * 16 + (slot & 15), u0 = idx * 16;
     // the two roles are compiled as separate bodies (the layer is a compile-time constant inside): at 510 of 512 registers
@@ -236,8 +242,15 @@ __global__ __launch_bounds__(256) void lstm_persist6_kernel(const LstmPersist6Pa
         const float hn = og * tanhf_(cstate);
         // ---- publish h[t]: this thread's value as three exact bf16 terms (no flag, no wait: see load_valid)
         {
-            const unsigned bh = __float_as_uint(hn) & 0xffff0000u;
-            const float r1 = hn - __uint_as_float(bh);
+            // A non-finite state (NaN samples in this clip) must not look like "not yet written" to the consumers: publish
+            // a finite stand-in and record the step; lstm_tail_kernel turns this clip's outputs from that step on into NaN,
+            // which is what the reference's LSTM yields (a NaN h reaches every unit one step later).  Other clips are other
+            // rows of the products: unaffected.
+            const bool nonfinite = !(fabsf(hn) < 2.0f);
+            if (nonfinite && live) atomicMin(pp.poison + erow, t);
+            const float hp = nonfinite ? 0.f : hn;
+            const unsigned bh = __float_as_uint(hp) & 0xffff0000u;
+            const float r1 = hp - __uint_as_float(bh);
             const unsigned bm = __float_as_uint(r1) & 0xffff0000u;
             const unsigned bl = __float_as_uint(r1 - __uint_as_float(bm));
             char* dst = hmine + (long long)t * p.h_ts + goff + (long long)idx * LP6_SLICE_BYTES;

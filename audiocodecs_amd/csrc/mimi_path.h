@@ -250,6 +250,7 @@ int mimi_rvq_decode(ac_handle* h, hipStream_t st, const long long* toks, int F, 
         p.tk0 = k0;
         p.os = 2 * Dq;
         const long long cnt = (long long)F * (Dq / 4);
+        p.bad = h->sticky_dev ? h->sticky_dev + ST_BAD_TOKEN : nullptr;
         ProfScope ps(h, st, "rvq_decode_kernel", (double)F * Dq * n, (double)F * n * 8 + (double)F * Dq * 4 * (n + 1));
         hipLaunchKernelGGL(rvq_decode_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, p);
         HIPCHK(h, hipGetLastError());

@@ -158,6 +158,7 @@ struct RvqDecParams {
     int F, H, C, K;
     int tK, tk0;
     int os;                 // row pitch of out (floats)
+    unsigned* bad;          // sticky counter (host-mapped) raised when an id is outside [0, C); may be null
 };
 
 __global__ __launch_bounds__(256) void rvq_decode_kernel(const RvqDecParams p) {
@@ -169,7 +170,12 @@ __global__ __launch_bounds__(256) void rvq_decode_kernel(const RvqDecParams p) {
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int k = 0; k < p.K; ++k) {
         long long idx = p.toks[f * p.tK + p.tk0 + k];
-        idx = idx < 0 ? 0 : (idx >= p.C ? p.C - 1 : idx);   // F.embedding would raise; stay in bounds
+        if (idx < 0 || idx >= p.C) {   // F.embedding raises here.  No entry point synchronises, so: the frame becomes NaN and a
+            // sticky word makes the next call on the handle return AC_EINVAL
+            if (q == 0 && p.bad) __hip_atomic_fetch_add(p.bad, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            acc.x = acc.y = acc.z = acc.w = __uint_as_float(0x7fc00000u);
+            idx = 0;
+        }
         const f32x4 v = *reinterpret_cast<const f32x4*>(p.e + ((long long)k * p.C + idx) * p.H + 4 * q);
         acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
     }

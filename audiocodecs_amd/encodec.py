@@ -116,6 +116,11 @@ class Encodec(Codec):
         if state_dict is None:
             state_dict = self._fetch_pretrained(int(orig_sample_rate / 1000))
         self._folded = checkpoint.fold_weight_norm(state_dict)
+        # encodec.py:67-71: the half of the model the mode never runs is dropped (here: never packed or uploaded)
+        if mode == "encode":
+            self._folded = {k: v for k, v in self._folded.items() if not k.startswith("decoder.")}
+        elif mode == "decode":
+            self._folded = {k: v for k, v in self._folded.items() if not k.startswith("encoder.")}
         self._natives: Dict[int, _Native] = {}
 
     @staticmethod

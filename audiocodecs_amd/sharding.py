@@ -31,13 +31,16 @@ def shard_clips(batch: torch.Tensor, rank: Optional[int] = None, world: Optional
     return batch[lo:hi]
 
 
-def gather_tokens(toks: torch.Tensor, num_clips: Optional[int] = None, group=None) -> torch.Tensor:
+def gather_tokens(toks: torch.Tensor, num_clips: Optional[int] = None, group=None, force: bool = False) -> torch.Tensor:
     """toks [b_local, N, K] int64 on every rank -> [num_clips, N, K] on every rank, in clip order.
 
     Token ids fit 16 bits for every configured codec (codebook <= 4096 < 32768), so they travel as
     int16 (4x fewer bytes on the wire) when they do; shards are padded to the common size
-    ceil(num_clips/world) so a single fixed-size all_gather suffices for ragged last shards."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    ceil(num_clips/world) so a single fixed-size all_gather suffices for ragged last shards.
+    `force=True` runs the collective even at world size 1 (exercises the RCCL path on a single GPU)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return toks
+    if dist.get_world_size(group) == 1 and not force:
         return toks
     world = dist.get_world_size(group)
     n_local = toks.shape[0]

@@ -159,6 +159,8 @@ def decoder(cfg, W, z, taps: Optional[dict] = None, explicit_lstm: bool = False)
     ratios = list(_cfg_get(cfg, "upsampling_ratios"))
     p = "decoder.layers."
     h = conv1d_causal(z, W[p + "0.conv.weight"], W[p + "0.conv.bias"])
+    if taps is not None:
+        taps["dec0"] = h
     h = lstm_skip(h, W, p + "1.lstm", _cfg_get(cfg, "num_lstm_layers"), explicit_lstm)
     if taps is not None:
         taps["dec1"] = h

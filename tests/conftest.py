@@ -17,6 +17,14 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    import parity_record
+
+    line = parity_record.write()
+    if line:
+        terminalreporter.write_line(line)
+
+
 @pytest.fixture(scope="session")
 def golden():
     z = np.load(os.path.join(GOLDEN_DIR, "encodec_golden.npz"))

@@ -10,6 +10,7 @@ from dac_cases import CASES, REC_STRIDE, make_input
 from golden_cases import noise
 from test_gpu_parity import capture, rms
 from test_oracle_golden import TAU, tokens_match_up_to_ties
+import parity_record
 
 pytestmark = pytest.mark.gpu
 
@@ -99,11 +100,12 @@ def test_golden_fixture(case, dac_golden, codecs):
         toks = codec.sig_to_toks(sig)
         assert toks.dtype == torch.int64 and list(toks.shape) == info["toks_shape"]
         gold = z[f"{name}.toks"].astype(np.int64)
-        n, bad, excused = tokens_match_up_to_ties(toks.cpu().numpy(), gold, z[f"{name}.margin64"])
-        assert bad == 0, f"{bad}/{n} tokens differ outside near-ties"
-        exact = float((toks.cpu().numpy() == gold).mean())
-        print(f"{name}: exact token match {exact:.6f}, near-tie tokens excused {excused}/{gold.size}")
-        assert exact > 0.99 or gold.size < 200
+        margin = z[f"{name}.margin64"]
+        mism, bad, excused = parity_record.tokens("dac", name, toks.cpu().numpy(), gold, margin, TAU)
+        assert bad == 0, f"{bad} tokens differ outside near-ties"
+        if margin.min() > TAU:       # no near-tie anywhere in the fixture: bit-exact
+            assert np.array_equal(toks.cpu().numpy(), gold)
+        assert mism <= excused
         feats = codec.sig_to_feats(sig).cpu().numpy()
         err = feats.reshape(-1)[::REC_STRIDE] - z[f"{name}.feats_strided"]
         assert rms(err) < 3e-5 and np.abs(err).max() < 5e-4, (rms(err), np.abs(err).max())
@@ -116,6 +118,7 @@ def test_golden_fixture(case, dac_golden, codecs):
     rec = codec.toks_to_sig(toks).cpu().numpy()
     assert list(rec.shape) == info["rec_shape"]
     err = rec.reshape(-1)[::REC_STRIDE] - z[f"{name}.rec_strided"]
+    parity_record.record("dac", name, waveform_rms_err=rms(err))
     assert rms(err) < 1e-4, rms(err)
     assert rms(err) < 3e-5, rms(err)
     assert abs(rms(rec) - info["rec_rms"]) < 1e-4

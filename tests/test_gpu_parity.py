@@ -16,6 +16,7 @@ import torch
 from conftest import GOLDEN_DIR
 from golden_cases import CASES, REC_STRIDE, make_input, noise
 from test_oracle_golden import TAU, tokens_match_up_to_ties
+import parity_record
 
 pytestmark = pytest.mark.gpu
 
@@ -107,18 +108,21 @@ def test_golden_fixture(case, golden, codecs):
         toks = codec.sig_to_toks(sig, length)
         assert toks.dtype == torch.int64 and list(toks.shape) == info["toks_shape"]
         gold = z[f"{name}.toks"].astype(np.int64)
-        n, bad, excused = tokens_match_up_to_ties(toks.cpu().numpy(), gold, z[f"{name}.margin64"])
-        assert bad == 0, f"{bad}/{n} tokens differ outside near-ties"
-        exact = float((toks.cpu().numpy() == gold).mean())
-        print(f"{name}: exact token match {exact:.6f}, near-tie tokens excused {excused}/{gold.size}")
-        assert exact > 0.995
+        margin = z[f"{name}.margin64"]
+        mism, bad, excused = parity_record.tokens("encodec", name, toks.cpu().numpy(), gold, margin, TAU)
+        assert bad == 0, f"{bad} tokens differ outside near-ties"
+        if margin.min() > TAU:       # no near-tie anywhere in the fixture: bit-exact, nothing to excuse
+            assert np.array_equal(toks.cpu().numpy(), gold)
+        assert mism <= excused       # a difference can only sit in a frame that had an fp64 near-tie
         feats = codec.sig_to_feats(sig, length).cpu().numpy()
         err = feats.reshape(-1)[::REC_STRIDE] - z[f"{name}.feats_strided"]
         assert rms(err) < 2e-5 and np.abs(err).max() < 2e-4
+        parity_record.record("encodec", name, feats_rms_err=rms(err))
         toks = torch.from_numpy(gold).cuda()  # decode the REFERENCE's tokens
     rec = codec.toks_to_sig(toks).cpu().numpy()
     assert list(rec.shape) == info["rec_shape"]
     err = rec.reshape(-1)[::REC_STRIDE] - z[f"{name}.rec_strided"]
+    parity_record.record("encodec", name, waveform_rms_err=rms(err))
     assert rms(err) < 1e-4, rms(err)          # the north-star bar
     assert rms(err) < 1e-5, rms(err)          # what fp32 parity mode actually delivers
     assert abs(rms(rec) - info["rec_rms"]) < 1e-4
@@ -139,10 +143,10 @@ def test_against_oracle_on_fresh_inputs(codecs, checkpoints):
         _, m64 = O.sig_to_toks(cfg, W64, sig.double(), length.double(), 8, True)
         orec = O.toks_to_sig(cfg, W, otoks)
     toks = codec.sig_to_toks(sig.cuda(), length.cuda())
-    n, bad, excused = tokens_match_up_to_ties(toks.cpu().numpy(), otoks.numpy(), m64.numpy())
-    assert bad == 0
-    assert float((toks.cpu() == otoks).float().mean()) > 0.995
+    mism, bad, excused = parity_record.tokens("encodec", "oracle_fresh_b3", toks.cpu().numpy(), otoks.numpy(), m64.numpy(), TAU)
+    assert bad == 0 and mism <= excused
     rec = codec.toks_to_sig(otoks.cuda()).cpu()
+    parity_record.record("encodec", "oracle_fresh_b3", waveform_rms_err=rms((rec - orec).numpy()))
     assert rms((rec - orec).numpy()) < 1e-5
     # reconstruct mode == sig_to_toks then toks_to_sig (codec.py:45-55)
     rec2 = codec(sig.cuda(), length.cuda())
@@ -164,9 +168,10 @@ def test_odd_batches_against_oracle(B, T, codecs, checkpoints):
         _, m64 = O.sig_to_toks(cfg, W64, sig.double(), None, 8, True)
         orec = O.toks_to_sig(cfg, W, otoks)
     toks = codec.sig_to_toks(sig.cuda())
-    n, bad, excused = tokens_match_up_to_ties(toks.cpu().numpy(), otoks.numpy(), m64.numpy())
-    assert bad == 0 and float((toks.cpu() == otoks).float().mean()) > 0.995
+    mism, bad, excused = parity_record.tokens("encodec", f"oracle_B{B}_T{T}", toks.cpu().numpy(), otoks.numpy(), m64.numpy(), TAU)
+    assert bad == 0 and mism <= excused
     rec = codec.toks_to_sig(otoks.cuda()).cpu()
+    parity_record.record("encodec", f"oracle_B{B}_T{T}", waveform_rms_err=rms((rec - orec).numpy()))
     assert rms((rec - orec).numpy()) < 1e-5
 
 
@@ -263,10 +268,131 @@ def test_split_operand_and_exact_product_kernels_agree(checkpoints, golden, monk
     exact = Encodec(24000, num_codebooks=8, state_dict=sd, config=cfg).eval()
     fb, tb = exact.sig_to_feats(sig), exact.sig_to_toks(sig)
     assert rms((fa - fb).cpu().numpy()) < 3e-6
-    assert float((ta == tb).float().mean()) > 0.995
+    assert float((ta == tb).float().mean()) > 0.999   # two fp32-faithful arithmetics: only fp32-level near-ties may differ
     assert rms((fast.toks_to_sig(ta) - exact.toks_to_sig(ta)).cpu().numpy()) < 3e-6
     case = next(c for c in CASES if c["name"] == "full_noise_b2")
     inp = make_input(case, GOLDEN_DIR)
     toks = exact.sig_to_toks(inp["sig"].cuda())
     n, bad, excused = tokens_match_up_to_ties(toks.cpu().numpy(), z["full_noise_b2.toks"].astype(np.int64), z["full_noise_b2.margin64"])
     assert bad == 0
+
+
+FULL_ENC_TAPS = ["enc0", "enc1", "enc3", "enc4", "enc6", "enc7", "enc9", "enc10", "enc12", "enc13"]
+FULL_DEC_TAPS = ["dec0", "dec1", "dec3", "dec4", "dec6", "dec7", "dec9", "dec10", "dec12", "dec13"]
+
+
+def test_every_module_output_full_config_production_kernels(codecs, checkpoints):
+    """FULL architecture through the production kernels (stem, rb_fused6<32/64>, rb128_fused6, thin_conv6, tap_gemm6,
+    lstm_persist6, head): arming the capture hook does not change kernel selection; every module output of a 1 s clip
+    against the oracle's taps (the oracle is pinned to the reference's hooks on the tiny config and to its end-to-end
+    outputs on this one).  A localized error shows up at its layer, not as a vague feature RMS."""
+    from oracle import encodec_oracle as O
+
+    cfg, sd = checkpoints("full", 0)
+    codec = codecs("full", 0)
+    W = O.fold_weight_norm(sd)
+    sig = noise(8080, 2, 24000)
+    taps, dtaps = {}, {}
+    with torch.no_grad():
+        O.masked_embeddings(cfg, W, sig, None, taps=taps)
+        otoks = O.sig_to_toks(cfg, W, sig)
+        orec = O.toks_to_sig(cfg, W, otoks, taps=dtaps)
+    codec.sig_to_toks(sig[:, :640].cuda())
+    nat = next(iter(codec._natives.values()))
+    assert nat.lib.ac_lstm_status(nat.h) == 1   # the persistent LSTM is what runs
+    _, flat = capture(codec, lambda: codec.sig_to_toks(sig.cuda()), 1 << 26)
+    off = 0
+    worst = {}
+    for tap in FULL_ENC_TAPS:
+        g = taps[tap].numpy()  # [B,C,L]
+        n = g.size
+        got = flat[off : off + n].reshape(g.shape[0], g.shape[2], g.shape[1]).transpose(0, 2, 1)
+        worst[tap] = float(np.abs(got - g).max() / max(1e-30, np.abs(g).max()))
+        np.testing.assert_allclose(got, g, atol=5e-6 * max(1.0, float(np.abs(g).max())), rtol=2e-5, err_msg=tap)
+        off += n
+    assert off == flat.size
+    rec, flat = capture(codec, lambda: codec.toks_to_sig(otoks.cuda()), 1 << 26)
+    off = 0
+    for tap in FULL_DEC_TAPS:
+        g = dtaps[tap].numpy()
+        n = g.size
+        got = flat[off : off + n].reshape(g.shape[0], g.shape[2], g.shape[1]).transpose(0, 2, 1)
+        worst[tap] = float(np.abs(got - g).max() / max(1e-30, np.abs(g).max()))
+        np.testing.assert_allclose(got, g, atol=5e-6 * max(1.0, float(np.abs(g).max())), rtol=2e-5, err_msg=tap)
+        off += n
+    assert off == flat.size
+    parity_record.record("encodec", "full_config_module_taps", worst_rel_err_per_tap=worst,
+                         waveform_rms_err=rms((rec.cpu() - orec).numpy()))
+    assert rms((rec.cpu() - orec).numpy()) < 1e-5
+
+
+def test_nan_clip_does_not_stall_or_poison_other_clips(codecs):
+    """One clip with a NaN sample in a batch of 4: the call takes its normal time, the other three clips are bit-identical
+    to a clean run, the NaN clip's LSTM output is NaN from the poisoned frame on (as the reference's LSTM gives), and the
+    persistent kernel's status stays clean (lstm_persist6.h publish step + lstm_tail_kernel)."""
+    import time
+
+    codec = codecs("full", 0)
+    sig = noise(9191, 4, 48000).cuda()
+    clean_t = codec.sig_to_toks(sig)
+    clean_f = codec.sig_to_feats(sig)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    codec.sig_to_feats(sig)
+    torch.cuda.synchronize()
+    t_clean = time.perf_counter() - t0
+    bad = sig.clone()
+    bad[2, 20000] = float("nan")
+    t0 = time.perf_counter()
+    f = codec.sig_to_feats(bad)
+    torch.cuda.synchronize()
+    t_bad = time.perf_counter() - t0
+    assert t_bad < 5 * t_clean + 0.05, (t_bad, t_clean)   # a stalled exchange would spin for ~0.5 s per step
+    toks = codec.sig_to_toks(bad)
+    for b in (0, 1, 3):
+        assert torch.equal(f[b], clean_f[b]) and torch.equal(toks[b], clean_t[b])
+    frame = 20000 // 320
+    assert torch.equal(f[2, : frame - 1], clean_f[2, : frame - 1])   # causal: frames before the NaN sample's receptive field
+    assert bool(torch.isnan(f[2, frame + 1 :]).all())                # ... and NaN ever after (the LSTM carries it forward)
+    assert bool((toks[2, frame + 1 :] == 0).all())                   # torch's argmax over an all-NaN row: index 0
+    nat = next(iter(codec._natives.values()))
+    assert nat.lib.ac_lstm_status(nat.h) == 1
+    assert torch.equal(codec.sig_to_toks(sig), clean_t)              # and the handle is as good as before
+
+
+def test_out_of_range_token_ids_are_reported(codecs):
+    """F.embedding raises on an id outside the codebook.  No entry point synchronises, so the decode kernel sets the
+    frame to NaN and the NEXT call on the handle fails with AC_EINVAL (once); afterwards the handle works again."""
+    from audiocodecs_amd._native import NativeError
+
+    codec = codecs("full", 0)
+    toks = torch.randint(0, 1024, (2, 6, 8), device="cuda")
+    good = codec.toks_to_qfeats(toks)
+    toks2 = toks.clone()
+    toks2[1, 3, 5] = 1024
+    q = codec.toks_to_qfeats(toks2)
+    torch.cuda.synchronize()
+    assert bool(torch.isnan(q[1, 3]).all()) and torch.equal(q[0], good[0]) and torch.equal(q[1, :3], good[1, :3])
+    with pytest.raises(NativeError, match="token ids outside"):
+        codec.toks_to_qfeats(toks)
+    assert torch.equal(codec.toks_to_qfeats(toks), good)
+
+
+def test_mode_drops_the_unused_half(checkpoints):
+    """encodec.py:67-71: mode="encode" deletes the decoder, mode="decode" the encoder.  Here the unused half is never
+    packed or uploaded; calling it reports the missing half instead of running on absent weights."""
+    from audiocodecs_amd import Encodec
+    from audiocodecs_amd._native import NativeError
+
+    cfg, sd = checkpoints("full", 0)
+    both = Encodec(24000, num_codebooks=8, state_dict=sd, config=cfg).eval()
+    enc = Encodec(24000, mode="encode", num_codebooks=8, state_dict=sd, config=cfg).eval()
+    dec = Encodec(24000, mode="decode", num_codebooks=8, state_dict=sd, config=cfg).eval()
+    sig = noise(6161, 2, 8000).cuda()
+    toks = both.sig_to_toks(sig)
+    assert torch.equal(enc(sig), toks)                       # forward() in encode mode = sig_to_toks (codec.py:45-55)
+    assert torch.equal(dec(toks), both.toks_to_sig(toks))
+    with pytest.raises(NativeError, match="without decoder weights"):
+        enc.toks_to_sig(toks)
+    with pytest.raises(NativeError, match="without encoder weights"):
+        dec.sig_to_toks(sig)
