@@ -27,7 +27,7 @@ import torch
 from . import prng
 from .config import EncodecConfig
 
-__all__ = ["conv_specs", "synthetic_state_dict", "fold_weight_norm", "mimi_conv_specs", "synthetic_mimi_state_dict", "mimi_codebook", "dac_conv_specs", "dac_snake_specs", "synthetic_dac_state_dict"]
+__all__ = ["conv_specs", "synthetic_state_dict", "fold_weight_norm", "mimi_conv_specs", "synthetic_mimi_state_dict", "mimi_codebook", "dac_conv_specs", "dac_snake_specs", "synthetic_dac_state_dict", "wavtok_encoder_specs", "wavtok_lstm_prefix", "synthetic_wavtok_state_dict"]
 
 CODEBOOK_S0 = 0.10
 CODEBOOK_RHO = 0.94
@@ -331,4 +331,104 @@ def synthetic_dac_state_dict(cfg, seed: int = 0) -> Dict[str, torch.Tensor]:
         sd[f"{p}.out_proj.weight"] = _f32(w_out)
         sd[f"{p}.out_proj.bias"] = _f32(prng.normal(seed, p + ".outb", (H,)) * 0.002)
         sd[f"{p}.codebook.weight"] = _f32(prng.normal(seed, p + ".cb", (cfg.codebook_size, D)) * (1.0 * 0.85**q))
+    return sd
+
+
+# ---------------------------------------------------------------------------------------------
+# WavTokenizer: key/shape layout of the checkpoint the reference wrapper loads through
+# `wavtokenizer.WavTokenizer.from_pretrained0802` (/root/reference/audiocodecs/wavtokenizer.py:76-78) -- the
+# `state_dict` of a Lightning checkpoint whose keys start with feature_extractor. / backbone. / head.  The backend
+# source is NOT on disk: names restate the published module tree (encodec-style SEANetEncoder under
+# feature_extractor.encodec.encoder.model.{i}, old-style weight-norm `conv.conv.weight_g/weight_v`, the codebook at
+# feature_extractor.encodec.quantizer.vq.layers.0._codebook.embed, VocosBackbone with pos_net, ISTFTHead).
+# ---------------------------------------------------------------------------------------------
+WAVTOK_CODEBOOK_S0 = 0.35
+
+
+def wavtok_encoder_specs(cfg) -> List[Tuple[str, int, int, int, int]]:
+    """(key prefix, Cin, Cout, kernel, stride) for every conv of the SEANet encoder, module-list order."""
+    F = cfg.num_filters
+    p = "feature_extractor.encodec.encoder.model"
+    specs = [(f"{p}.0", 1, F, cfg.kernel_size, 1)]
+    i, c = 1, F
+    for r in reversed(cfg.ratios):
+        hid = c // cfg.compress
+        specs.append((f"{p}.{i}.block.1", c, hid, cfg.residual_kernel_size, 1))
+        specs.append((f"{p}.{i}.block.3", hid, c, 1, 1))
+        specs.append((f"{p}.{i}.shortcut", c, c, 1, 1))
+        specs.append((f"{p}.{i + 2}", c, 2 * c, 2 * r, r))
+        i, c = i + 3, 2 * c
+    specs.append((f"{p}.{i + 2}", c, cfg.dimension, cfg.last_kernel_size, 1))
+    return specs
+
+
+def wavtok_lstm_prefix(cfg) -> str:
+    return f"feature_extractor.encodec.encoder.model.{1 + 3 * len(cfg.ratios)}.lstm"
+
+
+def synthetic_wavtok_state_dict(cfg, seed: int = 0) -> Dict[str, torch.Tensor]:
+    sd: Dict[str, torch.Tensor] = {}
+    for prefix, cin, cout, k, s in wavtok_encoder_specs(cfg):
+        w = prng.normal(seed, prefix + ".w", (cout, cin, k)) / np.sqrt(cin * k)
+        w = w * prng.uniform(seed, prefix + ".g", (cout, 1, 1), 0.9, 1.1)
+        w32 = _f32(w)
+        sd[f"{prefix}.conv.conv.bias"] = _f32(prng.normal(seed, prefix + ".b", (cout,)) * 0.02)
+        sd[f"{prefix}.conv.conv.weight_g"] = _norm_dim0(w32)
+        sd[f"{prefix}.conv.conv.weight_v"] = w32
+    D = cfg.lstm_dim
+    lp = wavtok_lstm_prefix(cfg)
+    for layer in range(cfg.num_lstm_layers):
+        for nm in ("ih", "hh"):
+            sd[f"{lp}.weight_{nm}_l{layer}"] = _f32(prng.normal(seed, f"{lp}.w{nm}{layer}", (4 * D, D)) / np.sqrt(D))
+            sd[f"{lp}.bias_{nm}_l{layer}"] = _f32(prng.normal(seed, f"{lp}.b{nm}{layer}", (4 * D,)) * 0.02)
+    q = "feature_extractor.encodec.quantizer.vq.layers.0._codebook"
+    sd[f"{q}.embed"] = _f32(prng.normal(seed, q + ".embed", (cfg.codebook_size, cfg.dimension)) * WAVTOK_CODEBOOK_S0)
+    sd[f"{q}.embed_avg"] = sd[f"{q}.embed"].clone()
+    sd[f"{q}.cluster_size"] = torch.ones(cfg.codebook_size)
+    sd[f"{q}.inited"] = torch.tensor([1.0])
+
+    C, I = cfg.backbone_dim, cfg.intermediate_dim
+
+    def conv(prefix, cin, cout, k, gain=1.0):
+        sd[f"{prefix}.weight"] = _f32(prng.normal(seed, prefix + ".w", (cout, cin, k)) * (gain / np.sqrt(cin * k)))
+        sd[f"{prefix}.bias"] = _f32(prng.normal(seed, prefix + ".b", (cout,)) * 0.02)
+
+    def norm(prefix, n):
+        sd[f"{prefix}.weight"] = _f32(prng.uniform(seed, prefix + ".w", (n,), 0.8, 1.2))
+        sd[f"{prefix}.bias"] = _f32(prng.normal(seed, prefix + ".b", (n,)) * 0.05)
+
+    def adanorm(prefix):
+        sd[f"{prefix}.scale.weight"] = _f32(prng.uniform(seed, prefix + ".s", (cfg.adanorm_num_embeddings, C), 0.8, 1.2))
+        sd[f"{prefix}.shift.weight"] = _f32(prng.normal(seed, prefix + ".h", (cfg.adanorm_num_embeddings, C)) * 0.05)
+
+    conv("backbone.embed", cfg.dimension, C, 7)
+    for i in (0, 1, 3, 4):     # ResnetBlocks of pos_net
+        pp = f"backbone.pos_net.{i}"
+        norm(f"{pp}.norm1", C)
+        conv(f"{pp}.conv1", C, C, 3)
+        norm(f"{pp}.norm2", C)
+        conv(f"{pp}.conv2", C, C, 3, gain=0.5)
+    pa = "backbone.pos_net.2"  # AttnBlock
+    norm(f"{pa}.norm", C)
+    for nm in ("q", "k", "v"):
+        conv(f"{pa}.{nm}", C, C, 1, gain=2.0 if nm != "v" else 1.0)   # q, k gain: scores spread enough for a non-flat softmax
+    conv(f"{pa}.proj_out", C, C, 1, gain=0.5)
+    norm("backbone.pos_net.5", C)
+    adanorm("backbone.norm")
+    for l in range(cfg.num_layers):
+        pl = f"backbone.convnext.{l}"
+        sd[f"{pl}.dwconv.weight"] = _f32(prng.normal(seed, pl + ".dw.w", (C, 1, 7)) / np.sqrt(7.0))
+        sd[f"{pl}.dwconv.bias"] = _f32(prng.normal(seed, pl + ".dw.b", (C,)) * 0.02)
+        adanorm(f"{pl}.norm")
+        sd[f"{pl}.pwconv1.weight"] = _f32(prng.normal(seed, pl + ".p1.w", (I, C)) / np.sqrt(C))
+        sd[f"{pl}.pwconv1.bias"] = _f32(prng.normal(seed, pl + ".p1.b", (I,)) * 0.02)
+        sd[f"{pl}.pwconv2.weight"] = _f32(prng.normal(seed, pl + ".p2.w", (C, I)) / np.sqrt(I))
+        sd[f"{pl}.pwconv2.bias"] = _f32(prng.normal(seed, pl + ".p2.b", (C,)) * 0.02)
+        sd[f"{pl}.gamma"] = _f32(prng.uniform(seed, pl + ".gamma", (C,), 0.05, 0.3))
+    norm("backbone.final_layer_norm", C)
+    sd["head.out.weight"] = _f32(prng.normal(seed, "head.out.w", (cfg.n_fft + 2, C)) * (0.7 / np.sqrt(C)))
+    sd["head.out.bias"] = _f32(prng.normal(seed, "head.out.b", (cfg.n_fft + 2,)) * 0.02)
+    # head.istft.window: torch.hann_window(n_fft) (periodic) -- a registered buffer of the upstream module
+    n = np.arange(cfg.n_fft, dtype=np.float64)
+    sd["head.istft.window"] = _f32(0.5 - 0.5 * np.cos(2.0 * np.pi * n / cfg.n_fft))
     return sd

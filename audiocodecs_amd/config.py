@@ -12,7 +12,7 @@ import math
 from dataclasses import dataclass, field
 from typing import Tuple
 
-__all__ = ["EncodecConfig", "TINY", "ENCODEC_24KHZ", "MimiConfig", "MIMI_24KHZ", "MIMI_TINY", "DacConfig", "DAC_44KHZ", "DAC_24KHZ", "DAC_16KHZ", "DAC_TINY"]
+__all__ = ["EncodecConfig", "TINY", "ENCODEC_24KHZ", "MimiConfig", "MIMI_24KHZ", "MIMI_TINY", "DacConfig", "DAC_44KHZ", "DAC_24KHZ", "DAC_16KHZ", "DAC_TINY", "WavTokenizerConfig", "WAVTOK_40", "WAVTOK_75", "WAVTOK_TINY"]
 
 
 @dataclass(frozen=True)
@@ -163,3 +163,57 @@ DAC_16KHZ = DacConfig(sampling_rate=16000, downsampling_ratios=(2, 4, 5, 8), ups
 # 1/8 width, odd stride included, every activation fits a fixture
 DAC_TINY = DacConfig(encoder_hidden_size=8, decoder_hidden_size=64, downsampling_ratios=(2, 4, 5, 8),
                      upsampling_ratios=(8, 5, 4, 2), n_codebooks=4)
+
+
+@dataclass(frozen=True)
+class WavTokenizerConfig:
+    """Architecture of WavTokenizer as the reference wrapper uses it (/root/reference/audiocodecs/wavtokenizer.py:31-135
+    loads `wavtokenizer.WavTokenizer.from_pretrained0802(config, checkpoint)` of lucadellalib/WavTokenizer -- NOT on
+    disk; field values restate the published YAML configs the wrapper names, wavtokenizer.py:37-40: PARITY UNPINNED).
+    EnCodec-style SEANet encoder (non-causal, reflect padding, weight-norm, 2-layer LSTM) -> ONE Euclidean codebook
+    4096 x 512 -> Vocos backbone (k7 embed conv, pos_net = 2 ResnetBlocks + single-head attention + 2 ResnetBlocks +
+    GroupNorm, AdaLayerNorm, ConvNeXt blocks, LayerNorm) -> iSTFT head ("same" padding)."""
+
+    sampling_rate: int = 24000
+    num_filters: int = 32
+    dimension: int = 512               # encoder output width == codebook dim == backbone input_channels
+    ratios: Tuple[int, ...] = (6, 5, 5, 4)   # `dowmsamples` of the YAML; the encoder applies them reversed
+    kernel_size: int = 7
+    last_kernel_size: int = 7
+    residual_kernel_size: int = 3
+    compress: int = 2
+    num_lstm_layers: int = 2
+    codebook_size: int = 4096
+    backbone_dim: int = 768
+    intermediate_dim: int = 2304
+    num_layers: int = 12
+    adanorm_num_embeddings: int = 4
+    num_groups: int = 32               # GroupNorm groups of pos_net
+    n_fft: int = 2400
+    bandwidth_id: int = 0              # wavtokenizer.py:94,116: always 0
+
+    @property
+    def hop_length(self) -> int:
+        return int(math.prod(self.ratios))
+
+    @property
+    def hidden_size(self) -> int:
+        return self.dimension
+
+    @property
+    def lstm_dim(self) -> int:
+        return self.num_filters * 2 ** len(self.ratios)
+
+    def num_frames(self, num_samples: int) -> int:
+        """ceil at every strided conv (extra right padding completes the last frame)."""
+        n = num_samples
+        for r in reversed(self.ratios):
+            n = -(-n // r)
+        return n
+
+
+WAVTOK_40 = WavTokenizerConfig()                                         # ...frame40_3s_nq1_code4096_dim512_kmeans200_attn.yaml
+WAVTOK_75 = WavTokenizerConfig(ratios=(8, 5, 4, 2), n_fft=1280)          # ...frame75_3s_nq1_code4096_dim512_kmeans200_attn.yaml
+# 1/8 width, hop 48: every activation fits a fixture
+WAVTOK_TINY = WavTokenizerConfig(num_filters=4, dimension=32, ratios=(4, 3, 2, 2), codebook_size=128, backbone_dim=64,
+                                 intermediate_dim=192, num_layers=2, num_groups=32, n_fft=192)
