@@ -12,7 +12,7 @@ import os
 
 import torch  # noqa: F401  (loads libamdhip64 first)
 
-__all__ = ["lib", "lib_path", "AcConfig", "AcMimiConfig", "AcDacConfig", "AcKernelStat", "NativeError", "check", "EXPORTS"]
+__all__ = ["lib", "lib_path", "AcConfig", "AcMimiConfig", "AcDacConfig", "AcWavtokConfig", "AcKernelStat", "NativeError", "check", "EXPORTS"]
 
 AC_MAX_RATIOS = 8
 # AUDIOCODECS_AMD_LIB: developer override (timing variants built by hand); the product is the in-tree library
@@ -91,6 +91,31 @@ class AcDacConfig(C.Structure):
     ]
 
 
+class AcWavtokConfig(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_int32),
+        ("sampling_rate", C.c_int32),
+        ("num_filters", C.c_int32),
+        ("dimension", C.c_int32),
+        ("num_ratios", C.c_int32),
+        ("ratios", C.c_int32 * AC_MAX_RATIOS),
+        ("kernel_size", C.c_int32),
+        ("last_kernel_size", C.c_int32),
+        ("residual_kernel_size", C.c_int32),
+        ("compress", C.c_int32),
+        ("num_lstm_layers", C.c_int32),
+        ("codebook_size", C.c_int32),
+        ("backbone_dim", C.c_int32),
+        ("intermediate_dim", C.c_int32),
+        ("num_layers", C.c_int32),
+        ("adanorm_num_embeddings", C.c_int32),
+        ("num_groups", C.c_int32),
+        ("n_fft", C.c_int32),
+        ("bandwidth_id", C.c_int32),
+        ("device", C.c_int32),
+    ]
+
+
 class AcKernelStat(C.Structure):
     _fields_ = [
         ("name", C.c_char * 96),
@@ -108,6 +133,8 @@ EXPORTS = {
     "ac_create": (_i, [C.POINTER(AcConfig), C.POINTER(_vp)]),
     "ac_mimi_create": (_i, [C.POINTER(AcMimiConfig), C.POINTER(_vp)]),
     "ac_dac_create": (_i, [C.POINTER(AcDacConfig), C.POINTER(_vp)]),
+    "ac_wavtok_create": (_i, [C.POINTER(AcWavtokConfig), C.POINTER(_vp)]),
+    "ac_decode_feats": (_i, [_vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
     "ac_load_weights": (_i, [_vp, C.c_char_p, _vp, _sz]),
     "ac_finalize": (_i, [_vp]),
     "ac_num_frames": (_i, [_vp, _i]),

@@ -215,5 +215,5 @@ class WavTokenizerConfig:
 WAVTOK_40 = WavTokenizerConfig()                                         # ...frame40_3s_nq1_code4096_dim512_kmeans200_attn.yaml
 WAVTOK_75 = WavTokenizerConfig(ratios=(8, 5, 4, 2), n_fft=1280)          # ...frame75_3s_nq1_code4096_dim512_kmeans200_attn.yaml
 # 1/8 width, hop 48: every activation fits a fixture
-WAVTOK_TINY = WavTokenizerConfig(num_filters=4, dimension=32, ratios=(4, 3, 2, 2), codebook_size=128, backbone_dim=64,
-                                 intermediate_dim=192, num_layers=2, num_groups=32, n_fft=192)
+WAVTOK_TINY = WavTokenizerConfig(num_filters=4, dimension=32, ratios=(4, 3, 2, 2), codebook_size=128, backbone_dim=256,
+                                 intermediate_dim=512, num_layers=2, num_groups=32, n_fft=192)

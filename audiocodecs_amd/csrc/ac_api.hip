@@ -27,6 +27,7 @@
 #include "rb_fused6_128.h"
 #include "mimi.h"
 #include "dac.h"
+#include "wavtok.h"
 
 using namespace ac;
 
@@ -101,6 +102,26 @@ struct DacPlan {
     int H = 0;                                         // latent width
 };
 
+struct WtResnetPlan {
+    size_t n1w = 0, n1b = 0, n2w = 0, n2b = 0;
+    PackedGemm c1, c2;
+};
+struct WtCnxPlan {
+    size_t dww = 0, dwb = 0, sc = 0, sh = 0, gamma = 0;
+    PackedGemm p1, p2;
+};
+struct WavtokPlan {
+    PackedGemm embed, qkv, proj, head, istft;
+    WtResnetPlan rn[4];                       // pos_net.0, .1, .3, .4
+    size_t an_w = 0, an_b = 0;                // pos_net.2.norm
+    size_t g5w = 0, g5b = 0;                  // pos_net.5
+    size_t nsc = 0, nsh = 0;                  // backbone.norm rows `bandwidth_id`
+    size_t flw = 0, flb = 0;                  // final_layer_norm
+    size_t w2 = 0;                            // squared window [nfft]
+    std::vector<WtCnxPlan> cnx;
+    int bins = 0, npad = 0, hop_pad = 0, taps = 0;
+};
+
 struct ProfRec {
     int name_id;
     int count;
@@ -119,6 +140,8 @@ struct ac_handle {
     MimiPlan mimi;
     ac_dac_config dcfg{};
     DacPlan dac;
+    ac_wavtok_config wcfg{};
+    WavtokPlan wt;
     std::string err;
     std::map<std::string, std::vector<float>> host;
     bool finalized = false;
@@ -144,6 +167,7 @@ struct ac_handle {
     // split-operand weights (tap_gemm6.h): float offset of a packed fp32 matrix -> float offset of its bf16 planes
     std::map<size_t, size_t> w6_of;
     std::map<size_t, size_t> t6_of;   // thin_conv6.h fragment images of the [64][128] layers, keyed like w6_of
+    bool noncausal = false;                // WavTokenizer's SEANet encoder: centred padding (right = total/2, left = total - right)
     bool has_enc = true, has_dec = true;   // a half the caller's mode never runs may be left out (encodec.py:67-71)
     bool gemm_fp32 = false;         // AC_GEMM=fp32: exact-product kernels only
     // persistent LSTM (lstm_persist.h): control words, device shape, opt-out (AC_LSTM=step)
@@ -631,7 +655,9 @@ int launch_tap4(ac_handle* h, const TapGemmParams& p0, hipStream_t st) {
 
 // One segment of the A operand for a conv reading `x` (time steps of C channels).  Inputs are
 // already activated by their producer (TapGemmParams::y_elu), so no segment carries ELU.
-TapSeg make_seg(const Act& x, int s, int J, int pad /*PAD_**/, int extra, int kofs, const float* rel_len) {
+// `left` < 0: causal (all (J-1)*s padding steps on the left); otherwise `left` / `right` padding steps (non-causal SEANet of
+// WavTokenizer: right = total/2, left = total - right; `extra` completes the last frame on the right in both cases).
+TapSeg make_seg(const Act& x, int s, int J, int pad /*PAD_**/, int extra, int kofs, const float* rel_len, int left = -1, int right = 0) {
     TapSeg g{};
     g.x = x.p;
     g.bs = x.bs;
@@ -644,14 +670,14 @@ TapSeg make_seg(const Act& x, int s, int J, int pad /*PAD_**/, int extra, int ko
         if ((1 << sh) == x.C) g.cin_shift = sh;
     g.s = s;
     g.J = J;
-    const int pad_left = (J - 1) * s;
-    const int max_pad = std::max(pad_left, extra);
+    const int pad_left = left < 0 ? (J - 1) * s : left;
+    const int max_pad = std::max(pad_left, right + extra);
     g.Lp = (pad == PAD_REFLECT && x.L <= max_pad) ? max_pad + 1 : x.L;
-    g.lim = pad != PAD_ZERO ? x.L + extra : x.L;
+    g.lim = pad != PAD_ZERO ? x.L + right + extra : x.L;
     g.reflect = pad;
     g.elu = 0;
     g.kofs = kofs;
-    g.pad = pad_left;     // causal: every tap to the left
+    g.pad = pad_left;
     g.dil = 1;
     return g;
 }
@@ -772,7 +798,7 @@ int conv_fwd(ac_handle* h, hipStream_t st, const PackedGemm& g, const Act& x, in
              long long out_bs, long long out_rs, int B, Act2* y) {
     const int M = cdiv(x.L, s);
     const int extra = M * s - x.L;
-    if (s == 2 && k == 4 && !rel_len && extra == 0 && x.L >= 4 && out_rs == 64 && out_bs == (long long)M * 64) {
+    if (s == 2 && k == 4 && !rel_len && extra == 0 && x.L >= 4 && out_rs == 64 && out_bs == (long long)M * 64 && !h->noncausal) {
         const int rc = try_thin6(h, st, g, x, 32, 1, out, B);
         if (rc <= 0) {
             if (y && !rc) {
@@ -786,7 +812,12 @@ int conv_fwd(ac_handle* h, hipStream_t st, const PackedGemm& g, const Act& x, in
     TapGemmParams p{};
     p.nseg = 1;
     if (s != 1 && k != 2 * s) return fail(h, AC_EINVAL, "strided conv needs kernel == 2*stride (got k=%d, s=%d)", k, s);
-    p.seg[0] = make_seg(x, s, s == 1 ? k : 2, PAD_REFLECT, extra, 0, rel_len);
+    if (h->noncausal) {   // padding_total = k - s; right = total / 2, left = total - right
+        const int total = k - s, right = total / 2;
+        p.seg[0] = make_seg(x, s, s == 1 ? k : 2, PAD_REFLECT, extra, 0, rel_len, total - right, right);
+    } else {
+        p.seg[0] = make_seg(x, s, s == 1 ? k : 2, PAD_REFLECT, extra, 0, rel_len);
+    }
     p.w = h->blob + g.w_off;
     p.bias = g.has_bias ? h->blob + g.b_off : nullptr;
     p.y = out.raw;
@@ -878,7 +909,8 @@ int launch_rb_fused6(ac_handle* h, hipStream_t st, const ResBlockPlan& rb, const
     p.y_elu = out.elu;
     p.B = B;
     p.L = x.raw.L;
-    p.Lp = x.raw.L > 2 ? x.raw.L : 3;
+    p.lpad = h->noncausal ? 1 : 2;
+    p.Lp = x.raw.L > p.lpad ? x.raw.L : p.lpad + 1;
     p.ntiles = cdiv(x.raw.L, Cfg::BM);
     p.pad = pad;
     if (const char* d = std::getenv("AC_RB6_DBG")) p.dbg = std::atoi(d);
@@ -908,7 +940,8 @@ int launch_rb128_fused6(ac_handle* h, hipStream_t st, const ResBlockPlan& rb, co
     p.y_elu = out.elu;
     p.B = B;
     p.L = x.raw.L;
-    p.Lp = x.raw.L > 2 ? x.raw.L : 3;
+    p.lpad = h->noncausal ? 1 : 2;
+    p.Lp = x.raw.L > p.lpad ? x.raw.L : p.lpad + 1;
     p.ntiles = cdiv(x.raw.L, Cfg::BM);
     p.pad = pad;
     if (int rc = ensure_lds(h, reinterpret_cast<const void*>(rb128_fused6_kernel<SC>), Cfg::lds_bytes)) return rc;
@@ -937,7 +970,8 @@ int resblock_fwd(ac_handle* h, hipStream_t st, const ResBlockPlan& rb, const Act
         return AC_OK;
     }
     // thin stages: one fused kernel, hidden activation never leaves the CU
-    if ((rb.C == 32 || rb.C == 64) && h->cfg.residual_kernel_size == 3 && h->cfg.compress == 2 && x.raw.ts == rb.C &&
+    // (rb_fused.h, the exact-product version, knows the causal halo only)
+    if ((rb.C == 32 || rb.C == 64) && !(h->noncausal && (!rb.has6 || h->gemm_fp32)) && h->cfg.residual_kernel_size == 3 && h->cfg.compress == 2 && x.raw.ts == rb.C &&
         x.raw.bs == (long long)x.raw.L * rb.C && aligned16(x.raw.p) &&
         (!x.elu.p || (x.elu.ts == rb.C && x.elu.bs == x.raw.bs && aligned16(x.elu.p)))) {
         int rc;
@@ -977,7 +1011,7 @@ int resblock_fwd(ac_handle* h, hipStream_t st, const ResBlockPlan& rb, const Act
 bool thin_ok(const ac_config& c, int k) { return c.num_filters % 4 == 0 && c.num_filters <= 64 && k <= THIN_MAXK; }
 
 int thin_stem(ac_handle* h, hipStream_t st, const PackedGemm& g, int F, int k, int pad, const float* sig, const float* rel_len, int B, int T,
-              Out out, Act2* y, int padl = -1, const float* alpha = nullptr, const float* alpha_inv = nullptr) {
+              Out out, Act2* y, int padl = -1, const float* alpha = nullptr, const float* alpha_inv = nullptr, int Lp = -1) {
     ThinParams p{};
     p.padl = padl < 0 ? k - 1 : padl;
     p.alpha = alpha;
@@ -992,7 +1026,7 @@ int thin_stem(ac_handle* h, hipStream_t st, const PackedGemm& g, int F, int k, i
     p.T = T;
     p.F = F;
     p.k = k;
-    p.Lp = T > k - 1 ? T : k;
+    p.Lp = Lp > 0 ? Lp : (T > k - 1 ? T : k);
     p.pad = pad;
     {
         ProfScope ps(h, st, "stem_kernel", 2.0 * B * (double)T * F * k,
@@ -1006,7 +1040,12 @@ int thin_stem(ac_handle* h, hipStream_t st, const PackedGemm& g, int F, int k, i
 }
 
 int stem_fwd(ac_handle* h, hipStream_t st, const float* sig, const float* rel_len, int B, int T, Out out, Act2* y) {
-    return thin_stem(h, st, h->enc_stem, h->cfg.num_filters, h->cfg.kernel_size, PAD_REFLECT, sig, rel_len, B, T, out, y);
+    const int k = h->cfg.kernel_size;
+    if (h->noncausal) {   // centred: right = (k-1)/2, left = k-1-right; small-input rule on max(left, right)
+        const int right = (k - 1) / 2, left = k - 1 - right;
+        return thin_stem(h, st, h->enc_stem, h->cfg.num_filters, k, PAD_REFLECT, sig, rel_len, B, T, out, y, left, nullptr, nullptr, T > left ? T : left + 1);
+    }
+    return thin_stem(h, st, h->enc_stem, h->cfg.num_filters, k, PAD_REFLECT, sig, rel_len, B, T, out, y);
 }
 
 int thin_head(ac_handle* h, hipStream_t st, const PackedGemm& g, int F, int k, int pad, const Act& x, int B, float* sig, int padl = -1,
@@ -1240,7 +1279,8 @@ int rvq_encode_fwd(ac_handle* h, hipStream_t st, const float* feats, int F, int 
         case 81: RVQ_CASE(8, 1); break;
         case 83: RVQ_CASE(8, 3); break;
         case 161: RVQ_CASE(16, 1); break;
-        default: return fail(h, AC_EINVAL, "hidden_size %d unsupported by the RVQ kernel (need 16*{1,2,4,8,16})", p.H);
+        case 321: RVQ_CASE(32, 1); break;
+        default: return fail(h, AC_EINVAL, "hidden_size %d unsupported by the RVQ kernel (need 16*{1,2,4,8,16,32})", p.H);
     }
 #undef RVQ_CASE
     HIPCHK(h, hipGetLastError());
@@ -1389,6 +1429,7 @@ int encoder_fwd(ac_handle* h, hipStream_t st, const float* sig, const float* rel
     int rc;
     // a 32-channel ResBlock activates its raw input itself (rb_fused.h): no ELU'd flavour needed in HBM
     auto rb_self_elu = [&](int C) {
+        if (h->noncausal && h->gemm_fp32) return false;   // non-causal blocks are fused in split-operand arithmetic only
         return (C == 32 || C == 64 || (C == 128 && c.num_ratios > 2 && rb128_ok(h, h->enc_rb[2]))) && c.residual_kernel_size == 3 && c.compress == 2;
     };
     if (thin_ok(c, c.kernel_size))
@@ -1472,6 +1513,7 @@ int decoder_fwd(ac_handle* h, hipStream_t st, const long long* toks, int B, int 
 
 #include "mimi_path.h"
 #include "dac_path.h"
+#include "wavtok_path.h"
 
 }  // namespace
 
@@ -1560,12 +1602,73 @@ int ac_dac_create(const ac_dac_config* cfg, ac_handle** out) {
     return AC_OK;
 }
 
+int ac_wavtok_create(const ac_wavtok_config* cfg, ac_handle** out) {
+    if (!cfg || !out) return AC_EINVAL;
+    *out = nullptr;
+    if (cfg->struct_size != (int32_t)sizeof(ac_wavtok_config)) return AC_EINVAL;
+    const ac_wavtok_config& c = *cfg;
+    if (c.num_ratios < 1 || c.num_ratios > AC_MAX_RATIOS || c.num_filters < 1 || c.dimension < 16 || c.dimension % 16 || c.dimension > 512 ||
+        c.compress < 1 || c.num_lstm_layers < 1 || c.num_lstm_layers > 2 || c.codebook_size % 32 || c.codebook_size < 32 ||
+        c.kernel_size < 1 || c.kernel_size > 8 || c.last_kernel_size < 1 || c.last_kernel_size > 8 || c.residual_kernel_size < 1 ||
+        c.residual_kernel_size > 8 || (c.backbone_dim != 256 && c.backbone_dim != 768) || c.intermediate_dim < 16 || c.intermediate_dim % 4 ||
+        c.num_layers < 0 || c.adanorm_num_embeddings < 1 || c.bandwidth_id < 0 || c.bandwidth_id >= c.adanorm_num_embeddings ||
+        c.num_groups < 1 || c.num_groups > 256 || c.backbone_dim % c.num_groups || c.n_fft < 4 || c.n_fft % 2)
+        return AC_EINVAL;
+    int hop = 1;
+    for (int i = 0; i < c.num_ratios; ++i) {
+        if (c.ratios[i] < 1) return AC_EINVAL;
+        hop *= c.ratios[i];
+    }
+    // the inverse STFT is a GEMM over n_fft / hop whole frames per output row; "same" padding trims (n_fft - hop) / 2
+    if (c.n_fft % hop || c.n_fft / hop < 1 || c.n_fft / hop > 8 || hop % 4 || ((c.n_fft - hop) / 2) % 4 || (c.n_fft - hop) % 2) return AC_EINVAL;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= c.device || c.device < 0) return AC_ENODEV;
+    ac_handle* h = new (std::nothrow) ac_handle();
+    if (!h) return AC_ENOMEM;
+    h->arch = ARCH_WAVTOK;
+    h->wcfg = c;
+    h->noncausal = true;
+    // the SEANet encoder is the EnCodec encoder plan with centred padding: describe it in h->cfg
+    ac_config& e = h->cfg;
+    e.struct_size = (int32_t)sizeof(ac_config);
+    e.sampling_rate = c.sampling_rate;
+    e.num_filters = c.num_filters;
+    e.hidden_size = c.dimension;
+    e.num_ratios = c.num_ratios;
+    for (int i = 0; i < c.num_ratios; ++i) e.upsampling_ratios[i] = c.ratios[i];
+    e.kernel_size = c.kernel_size;
+    e.last_kernel_size = c.last_kernel_size;
+    e.residual_kernel_size = c.residual_kernel_size;
+    e.compress = c.compress;
+    e.num_lstm_layers = c.num_lstm_layers;
+    e.codebook_size = c.codebook_size;
+    e.num_quantizers = 1;
+    e.device = c.device;
+    h->hop = hop;
+    h->D = c.num_filters << c.num_ratios;
+    *out = h;
+    return AC_OK;
+}
+
+// WavTokenizer checkpoints spell the encoder's modules the encodec-library way; the packer knows the HF spelling
+static std::string wavtok_key(const std::string& name) {
+    static const std::string pre = "feature_extractor.encodec.encoder.model.";
+    if (name.compare(0, pre.size(), pre) != 0) return name;
+    std::string k = "encoder.layers." + name.substr(pre.size());
+    const size_t cc = k.find(".conv.conv.");
+    if (cc != std::string::npos) k = k.substr(0, cc) + ".conv." + k.substr(cc + 11);
+    auto ends = [&](const char* sfx) { const size_t n = std::strlen(sfx); return k.size() >= n && k.compare(k.size() - n, n, sfx) == 0; };
+    if (ends(".weight_g")) k = k.substr(0, k.size() - 9) + ".parametrizations.weight.original0";
+    else if (ends(".weight_v")) k = k.substr(0, k.size() - 9) + ".parametrizations.weight.original1";
+    return k;
+}
+
 int ac_load_weights(ac_handle* h, const char* name, const void* host_ptr, size_t bytes) {
     if (!h || !name || !host_ptr) return h ? fail(h, AC_EINVAL, "null argument") : AC_EINVAL;
     if (h->finalized) return fail(h, AC_ESTATE, "handle already finalized");
     if (bytes % 4) return fail(h, AC_EINVAL, "tensor '%s': byte size %zu is not a multiple of 4", name, bytes);
     const float* f = static_cast<const float*>(host_ptr);
-    h->host[name].assign(f, f + bytes / 4);
+    h->host[h->arch == ARCH_WAVTOK ? wavtok_key(name) : std::string(name)].assign(f, f + bytes / 4);
     return AC_OK;
 }
 
@@ -1617,6 +1720,11 @@ int ac_finalize(ac_handle* h) {
         Packer pk{h};
         if (int rc = dac_finalize(h, pk)) return rc;
         return upload_blob(h, pk, h->dcfg.device);
+    }
+    if (h->arch == ARCH_WAVTOK) {
+        Packer pk{h};
+        if (int rc = wavtok_finalize(h, pk)) return rc;
+        return upload_blob(h, pk, h->wcfg.device);
     }
     const ac_config& c = h->cfg;
     Arch a = make_arch(c);
@@ -1705,6 +1813,7 @@ static int num_q(const ac_handle* h) {
 
 static Workspace any_plan_ws(const ac_handle* h, int B, int T, int N, bool enc) {
     if (h->arch == ARCH_DAC) return dac_plan_ws(h, B, T, N, enc);
+    if (h->arch == ARCH_WAVTOK) return wavtok_plan_ws(h, B, T, N, enc);
     return h->arch == ARCH_MIMI ? mimi_plan_ws(h, B, T, N, enc) : plan_ws(h, B, T, N, enc);
 }
 
@@ -1863,6 +1972,13 @@ int ac_decode(ac_handle* h, const int64_t* toks, int B, int N, int K, float* sig
     WsPtrs p;
     rc = carve(h, any_plan_ws(h, B, 0, N, false), ws, ws_bytes, &p);
     if (rc) return rc;
+    if (h->arch == ARCH_WAVTOK) {
+        hipStream_t st = (hipStream_t)stream;
+        float* zq = p.take();   // codes_to_features: the single codebook's vectors [B*N][dimension]
+        rc = rvq_decode_fwd(h, st, reinterpret_cast<const long long*>(toks), B * N, K, zq);
+        if (rc) return rc;
+        return wavtok_decoder_fwd(h, st, zq, B, N, sig, p);
+    }
     if (h->arch == ARCH_MIMI) {
         hipStream_t st = (hipStream_t)stream;
         float* qsum = p.take();
@@ -1875,6 +1991,19 @@ int ac_decode(ac_handle* h, const int64_t* toks, int B, int N, int K, float* sig
         return mimi_decoder_fwd(h, st, qf, B, N, sig, p);
     }
     return decoder_fwd(h, (hipStream_t)stream, reinterpret_cast<const long long*>(toks), B, N, K, sig, p);
+}
+
+int ac_decode_feats(ac_handle* h, const float* feats, int B, int N, float* sig, void* ws, size_t ws_bytes, void* stream) {
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (h->arch != ARCH_WAVTOK) return fail(h, AC_EINVAL, "ac_decode_feats: WavTokenizer handles only (the other wrappers do not implement _feats_to_sig)");
+    if (!feats || !sig || B < 1 || N < 1) return fail(h, AC_EINVAL, "ac_decode_feats: bad argument (B=%d, N=%d)", B, N);
+    if ((rc = check_len(h, ac_num_samples(h, N)))) return rc;
+    if (!h->has_dec) return fail(h, AC_ESTATE, "ac_decode_feats: the handle was loaded without decoder weights (mode=\"encode\")");
+    WsPtrs p;
+    rc = carve(h, wavtok_plan_ws(h, B, 0, N, false), ws, ws_bytes, &p);
+    if (rc) return rc;
+    return wavtok_decoder_fwd(h, (hipStream_t)stream, feats, B, N, sig, p);
 }
 
 int ac_embs(ac_handle* h, int K, float* embs, void* stream) {

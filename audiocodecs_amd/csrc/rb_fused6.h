@@ -31,6 +31,7 @@ struct RbFused6Params {
     int B, L, Lp;           // Lp: reflect base length (L, or 3 when L <= 2: [HF]:148-155)
     int ntiles;             // tiles per clip
     int pad;                // PAD_REFLECT (EnCodec) / PAD_ZERO (Mimi)
+    int lpad;               // rows of left padding of the k3 conv: 2 = causal (EnCodec, Mimi), 1 = centred (WavTokenizer's non-causal SEANet)
     int dbg;                // developer timing modes (AC_RB6_DBG): 1 no stage-A MFMAs, 2 no stage-B MFMAs, 4 no staging,
                             // 8 no output stores, 16 no loads -- results are wrong in every mode but 0
 };
@@ -146,7 +147,7 @@ __global__ __launch_bounds__(256, C == 64 ? 2 : 3) void rb_fused6_kernel(const R
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.xr + (long long)b * p.L * C), 0, clip_bytes, 0x00020000);
 #pragma unroll
         for (int i = 0; i < SLOTS; ++i) {
-            int j = t0 - 2 + s_row[i];                           // causal pad of 2: reflect ([HF]:157-176) or zeros
+            int j = t0 - p.lpad + s_row[i];                      // left pad 2 (causal) or 1 (non-causal k3): reflect ([HF]:157-176) or zeros
             if (p.pad == PAD_REFLECT) j = j < 0 ? -j : (j >= p.Lp ? 2 * (p.Lp - 1) - j : j);
             const bool ok = s_row[i] < Cfg::XE_ROWS && j >= 0 && j < p.L;
             rx[i] = bufload16(rs, ok ? j * (C * 4) + s_q4[i] : 0x7fff0000, 0);
@@ -158,8 +159,8 @@ __global__ __launch_bounds__(256, C == 64 ? 2 : 3) void rb_fused6_kernel(const R
             const int row = s_row[i], q = s_q4[i] / 16;
             if (row < Cfg::XE_ROWS) {
                 split_store4(elu4(rx[i]), Xe, Cfg::XE_PLANE, row * XP + 4 * q);
-                // rows 2.. of the slab are the tile's own rows (never reflected: their source index is t0 + row - 2 >= 0)
-                if (SC && row >= 2) split_store4(rx[i], Xr, Cfg::XR_PLANE, (row - 2) * XP + 4 * q);
+                // rows lpad .. lpad + BM - 1 of the slab are the tile's own rows (source index t0 + row - lpad >= 0)
+                if (SC && row >= p.lpad && row < p.lpad + BM) split_store4(rx[i], Xr, Cfg::XR_PLANE, (row - p.lpad) * XP + 4 * q);
             }
         }
     };

@@ -74,7 +74,7 @@ __global__ __launch_bounds__(512, 1) void rb128_fused6_kernel(const RbFused6Para
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.xr + (long long)b * p.L * C), 0, clip_bytes, 0x00020000);
 #pragma unroll
         for (int i = 0; i < SLOTS; ++i) {
-            int j = t0 - 2 + s_row[i];                           // causal pad of 2: reflect ([HF]:157-176) or zeros
+            int j = t0 - p.lpad + s_row[i];                      // left pad 2 (causal) or 1 (non-causal k3): reflect ([HF]:157-176) or zeros
             if (p.pad == PAD_REFLECT) j = j < 0 ? -j : (j >= p.Lp ? 2 * (p.Lp - 1) - j : j);
             const bool ok = s_row[i] < Cfg::XE_ROWS && j >= 0 && j < p.L;
             rx[i] = bufload16(rs, ok ? j * (C * 4) + s_q4[i] : 0x7fff0000, 0);
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(512, 1) void rb128_fused6_kernel(const RbFused6Para
             const int row = s_row[i], q = s_q4[i] / 16;
             if (row < Cfg::XE_ROWS) {
                 split_store4(elu4(rx[i]), Xe, Cfg::XE_PLANE, row * XP + 4 * q);
-                if (SC && row >= 2) split_store4(rx[i], Xr, Cfg::XR_PLANE, (row - 2) * XP + 4 * q);
+                if (SC && row >= p.lpad && row < p.lpad + BM) split_store4(rx[i], Xr, Cfg::XR_PLANE, (row - p.lpad) * XP + 4 * q);
             }
         }
     };

@@ -78,6 +78,7 @@ struct TapGemmParams {
     int alpha_n;
     int tanh_out;
     long long y_off, y_len;
+    int n_valid;        // > 0: only columns n < n_valid are stored (N is padded to the tile width with zero weight rows)
 };
 
 enum { PAD_ZERO = 0, PAD_REFLECT = 1, PAD_REPLICATE = 2 };
@@ -254,7 +255,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void tap_gemm_kernel(const TapGemmPa
 #pragma unroll
         for (int c = 0; c < WN; ++c) {
             const int n = n0 + (wn * WN + c) * 16 + li;
-            if (n < p.N) {
+            if (n < (p.n_valid ? p.n_valid : p.N)) {
                 const float bv = p.bias ? p.bias[n] : 0.f;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {

@@ -281,7 +281,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void tap_gemm4_kernel(const TapGemmP
         const int row = e / (BN / 4), q = e % (BN / 4);
         const int m = m0 + row, n = n0 + 4 * q;
         const long long fi = (long long)m * p.y_rs + n + p.y_off;      // flat index inside the item
-        if (m < p.M && n < p.N && (p.y_len == 0 || (fi >= 0 && fi < p.y_len))) {
+        if (m < p.M && n < (p.n_valid ? p.n_valid : p.N) && (p.y_len == 0 || (fi >= 0 && fi < p.y_len))) {
             f32x4 v = *reinterpret_cast<const f32x4*>(&Cs[row * CP + 4 * q]);
             if (post) {
                 if (p.gelu) { v.x = gelu1(v.x); v.y = gelu1(v.y); v.z = gelu1(v.z); v.w = gelu1(v.w); }

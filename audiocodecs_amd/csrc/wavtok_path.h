@@ -1,0 +1,336 @@
+// WavTokenizer (BASELINE.json configs[4]): model plan, weight packing and the launch sequence of
+// the decoder.  Included by ac_api.hip inside its anonymous namespace.  PARITY UNPINNED: the reference's backend package is
+// not on disk (oracle/wavtokenizer_oracle.py restates it and cites the wrapper's call sites).
+//
+//   encode (wavtokenizer.py:92-96):  SEANet encoder -- the EnCodec encoder of ac_api.hip with centred (non-causal) reflect
+//           padding, strides reversed(ratios), output width `dimension` -- then ONE Euclidean codebook: rvq_encode_kernel, K = 1.
+//   decode (wavtokenizer.py:113-119): codebook gather -> VocosBackbone -> ISTFTHead.
+// Decoder data layout: the [B*N][C] frame matrix, fp32.  Dense layers are tap-GEMMs:
+//   embed Conv1d(k7, pad 3) and the ResnetBlocks' k3 convs: zero-padded taps over each clip's frames;
+//   q | k | v: one [3C][C] GEMM;  pwconv1 (+GELU epilogue), pwconv2 (+gamma, +residual epilogue);
+//   head Linear packed with interleaved (log-magnitude, phase) columns so that polar_kernel works on adjacent pairs;
+//   inverse rFFT x window x overlap-add = ONE 4-tap GEMM: output row m = the `hop` samples [m*hop, (m+1)*hop) of the
+//   overlap-add buffer, tap j = frame m + j - 3, weight[n][j][2c | 2c+1] = (a_c / nfft) * (cos | -sin)(2 pi c pos / nfft) *
+//   window[pos], pos = (3 - j)*hop + n;  the "same" trim of (nfft - hop)/2 samples is the GEMM's output offset.
+#pragma once
+
+// one fp32 vector of the checkpoint -> blob
+bool wt_vec(Packer& pk, const std::string& name, size_t n, size_t& off, size_t row = 0) {
+    auto it = pk.h->host.find(name);
+    if (it == pk.h->host.end()) { pk.rc = fail(pk.h, AC_ESTATE, "missing tensor '%s'", name.c_str()); return false; }
+    if (it->second.size() < (row + 1) * n || it->second.size() % n) {
+        pk.rc = fail(pk.h, AC_EINVAL, "tensor '%s' has %zu elements, expected a multiple of %zu with at least %zu rows", name.c_str(), it->second.size(), n, row + 1);
+        return false;
+    }
+    off = pk.reserve(n);
+    std::copy(it->second.begin() + row * n, it->second.begin() + (row + 1) * n, pk.blob.begin() + off);
+    return true;
+}
+
+int wavtok_finalize(ac_handle* h, Packer& pk) {
+    const ac_wavtok_config& c = h->wcfg;
+    WavtokPlan& m = h->wt;
+    const int C = c.backbone_dim, I = c.intermediate_dim, D = c.dimension, hop = h->hop, nfft = c.n_fft;
+    h->has_enc = h->has_dec = false;
+    for (const auto& kv : h->host) {
+        if (kv.first.compare(0, 8, "encoder.") == 0) h->has_enc = true;
+        if (kv.first.compare(0, 9, "backbone.") == 0) h->has_dec = true;
+    }
+    if (!h->has_enc && !h->has_dec) return fail(h, AC_ESTATE, "no feature_extractor.encodec.encoder.* or backbone.* tensor was loaded");
+    // ---- encoder: the EnCodec plan over h->cfg (keys were mapped to the HF spelling by ac_load_weights)
+    if (h->has_enc) {
+        const ac_config& e = h->cfg;
+        Arch a = make_arch(e);
+        bool ok = pk.conv(a.enc_stem, h->enc_stem);
+        h->enc_rb.resize(e.num_ratios);
+        h->enc_down.resize(e.num_ratios);
+        for (int i = 0; ok && i < e.num_ratios; ++i) {
+            ok = ok && pk.resblock(a.enc_rb3[i], a.enc_rb1[i], a.enc_rbs[i], h->enc_rb[i]);
+            ok = ok && pk.conv(a.enc_down[i], h->enc_down[i]);
+        }
+        ok = ok && pk.lstm(a.enc_lstm, a.D, e.num_lstm_layers, h->enc_lstm);
+        ok = ok && pk.conv(a.enc_final, h->enc_final);
+        if (!ok) return pk.rc;
+    }
+    // ---- the codebook (both directions need it): plain, MFMA B-fragment order, squared norms
+    {
+        const int Cb = c.codebook_size;
+        const std::vector<float>* e = pk.get("feature_extractor.encodec.quantizer.vq.layers.0._codebook.embed", (size_t)Cb * D);
+        if (!e) return pk.rc;
+        h->cb_plain = pk.reserve((size_t)Cb * D);
+        h->cb_packed = pk.reserve((size_t)Cb * D);
+        h->cb_ee = pk.reserve((size_t)Cb);
+        std::copy(e->begin(), e->end(), pk.blob.begin() + h->cb_plain);
+        for (int code = 0; code < Cb; ++code) {
+            double ss = 0.0;
+            for (int d = 0; d < D; ++d) ss += (double)(*e)[(size_t)code * D + d] * (*e)[(size_t)code * D + d];
+            pk.blob[h->cb_ee + code] = (float)ss;
+        }
+        const int HV = D / 16;
+        for (int ct = 0; ct < Cb / 16; ++ct)
+            for (int v = 0; v < HV; ++v)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int u = 0; u < 4; ++u)
+                        pk.blob[h->cb_packed + (((size_t)ct * HV + v) * 64 + lane) * 4 + u] =
+                            (*e)[(size_t)(ct * 16 + (lane & 15)) * D + v * 16 + 4 * (lane >> 4) + u];
+    }
+    if (!h->has_dec) return AC_OK;
+    // ---- backbone
+    bool ok = pk.conv(ConvSpec{"backbone.embed", 0, D, C, 7, 1}, m.embed);
+    const int rn_idx[4] = {0, 1, 3, 4};
+    for (int i = 0; ok && i < 4; ++i) {
+        const std::string p = "backbone.pos_net." + std::to_string(rn_idx[i]);
+        ok = ok && wt_vec(pk, p + ".norm1.weight", C, m.rn[i].n1w) && wt_vec(pk, p + ".norm1.bias", C, m.rn[i].n1b);
+        ok = ok && pk.conv(ConvSpec{p + ".conv1", 0, C, C, 3, 1}, m.rn[i].c1);
+        ok = ok && wt_vec(pk, p + ".norm2.weight", C, m.rn[i].n2w) && wt_vec(pk, p + ".norm2.bias", C, m.rn[i].n2b);
+        ok = ok && pk.conv(ConvSpec{p + ".conv2", 0, C, C, 3, 1}, m.rn[i].c2);
+    }
+    if (!ok) return pk.rc;
+    {   // q | k | v as one [3C][C] matrix
+        const std::string p = "backbone.pos_net.2.";
+        std::vector<float> w, b;
+        for (const char* nm : {"q", "k", "v"}) {
+            const std::vector<float>* wi = pk.get(p + nm + ".weight", (size_t)C * C);
+            const std::vector<float>* bi = pk.get(p + nm + ".bias", (size_t)C);
+            if (!wi || !bi) return pk.rc;
+            w.insert(w.end(), wi->begin(), wi->end());
+            b.insert(b.end(), bi->begin(), bi->end());
+        }
+        h->host[p + "qkv.weight"] = std::move(w);
+        h->host[p + "qkv.bias"] = std::move(b);
+        ok = pk.conv(ConvSpec{p + "qkv", 0, C, 3 * C, 1, 1}, m.qkv);
+        ok = ok && pk.conv(ConvSpec{p + "proj_out", 0, C, C, 1, 1}, m.proj);
+        ok = ok && wt_vec(pk, p + "norm.weight", C, m.an_w) && wt_vec(pk, p + "norm.bias", C, m.an_b);
+    }
+    ok = ok && wt_vec(pk, "backbone.pos_net.5.weight", C, m.g5w) && wt_vec(pk, "backbone.pos_net.5.bias", C, m.g5b);
+    ok = ok && wt_vec(pk, "backbone.norm.scale.weight", C, m.nsc, c.bandwidth_id) && wt_vec(pk, "backbone.norm.shift.weight", C, m.nsh, c.bandwidth_id);
+    m.cnx.resize(c.num_layers);
+    for (int l = 0; ok && l < c.num_layers; ++l) {
+        const std::string p = "backbone.convnext." + std::to_string(l);
+        WtCnxPlan& L = m.cnx[l];
+        ok = ok && wt_vec(pk, p + ".dwconv.weight", (size_t)C * 7, L.dww) && wt_vec(pk, p + ".dwconv.bias", C, L.dwb);
+        ok = ok && wt_vec(pk, p + ".norm.scale.weight", C, L.sc, c.bandwidth_id) && wt_vec(pk, p + ".norm.shift.weight", C, L.sh, c.bandwidth_id);
+        ok = ok && pk.conv(ConvSpec{p + ".pwconv1", 0, C, I, 1, 1}, L.p1);
+        ok = ok && pk.conv(ConvSpec{p + ".pwconv2", 0, I, C, 1, 1}, L.p2);
+        ok = ok && wt_vec(pk, p + ".gamma", C, L.gamma);
+    }
+    ok = ok && wt_vec(pk, "backbone.final_layer_norm.weight", C, m.flw) && wt_vec(pk, "backbone.final_layer_norm.bias", C, m.flb);
+    if (!ok) return pk.rc;
+    // ---- head: Linear(C, nfft + 2) with columns interleaved (2c = log-magnitude of bin c, 2c + 1 = its phase), padded to 64
+    m.bins = nfft / 2 + 1;
+    m.npad = (int)align_up((size_t)2 * m.bins, 64);
+    m.taps = nfft / hop;
+    m.hop_pad = (int)align_up((size_t)hop, 64);   // tile width of the split-operand GEMM; the padding columns are never stored
+    {
+        const std::vector<float>* w = pk.get("head.out.weight", (size_t)(nfft + 2) * C);
+        const std::vector<float>* b = pk.get("head.out.bias", (size_t)(nfft + 2));
+        if (!w || !b) return pk.rc;
+        std::vector<float> wi((size_t)m.npad * C, 0.f), bi((size_t)m.npad, 0.f);
+        for (int cb = 0; cb < m.bins; ++cb)
+            for (int part = 0; part < 2; ++part) {
+                std::copy(w->begin() + (size_t)(part * m.bins + cb) * C, w->begin() + (size_t)(part * m.bins + cb + 1) * C, wi.begin() + (size_t)(2 * cb + part) * C);
+                bi[2 * cb + part] = (*b)[part * m.bins + cb];
+            }
+        h->host["head.out.il.weight"] = std::move(wi);
+        h->host["head.out.il.bias"] = std::move(bi);
+        if (!pk.conv(ConvSpec{"head.out.il", 0, C, m.npad, 1, 1}, m.head)) return pk.rc;
+    }
+    // ---- inverse rFFT x window x overlap-add as a `taps`-tap GEMM (see the header of this file)
+    {
+        std::vector<double> win(nfft);
+        auto it = h->host.find("head.istft.window");
+        if (it != h->host.end()) {
+            if ((int)it->second.size() != nfft) return fail(h, AC_EINVAL, "head.istft.window has %zu elements, expected %d", it->second.size(), nfft);
+            for (int i = 0; i < nfft; ++i) win[i] = it->second[i];
+        } else {
+            for (int i = 0; i < nfft; ++i) win[i] = (double)(float)(0.5 - 0.5 * std::cos(2.0 * M_PI * i / nfft));   // torch.hann_window (periodic)
+        }
+        m.w2 = pk.reserve(nfft);
+        for (int i = 0; i < nfft; ++i) pk.blob[m.w2 + i] = (float)win[i] * (float)win[i];
+        PackedGemm& g = m.istft;
+        g.N = m.hop_pad;
+        g.Ktot = m.taps * m.npad;
+        g.has_bias = false;
+        g.w_off = pk.reserve((size_t)g.N * g.Ktot);
+        std::vector<double> cs(nfft), sn(nfft);
+        for (int r = 0; r < nfft; ++r) { cs[r] = std::cos(2.0 * M_PI * r / nfft); sn[r] = std::sin(2.0 * M_PI * r / nfft); }
+        for (int n = 0; n < hop; ++n)
+            for (int j = 0; j < m.taps; ++j) {
+                const int pos = (m.taps - 1 - j) * hop + n;
+                float* row = &pk.blob[g.w_off + (size_t)n * g.Ktot + (size_t)j * m.npad];
+                for (int cb = 0; cb < m.bins; ++cb) {
+                    const bool edge = cb == 0 || cb == nfft / 2;
+                    const int r = (int)(((long long)cb * pos) % nfft);
+                    const double a = (edge ? 1.0 : 2.0) / nfft * win[pos];
+                    row[2 * cb] = (float)(a * cs[r]);
+                    row[2 * cb + 1] = edge ? 0.f : (float)(-a * sn[r]);
+                }
+            }
+        pk.pack6(g);
+    }
+    return AC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// launches
+// ---------------------------------------------------------------------------------------------
+// conv over each clip's frames with zero padding (left, right) -- nn.Conv1d(padding=p); out contiguous [B][N][g.N]
+int wt_conv(ac_handle* h, hipStream_t st, const PackedGemm& g, const Act& x, int k, int left, int right, float* y, int B, const Epi& epi = Epi{}) {
+    TapGemmParams p{};
+    p.nseg = 1;
+    p.seg[0] = make_seg(x, 1, k, PAD_ZERO, 0, 0, nullptr, left, right);
+    p.w = h->blob + g.w_off;
+    p.bias = g.has_bias ? h->blob + g.b_off : nullptr;
+    p.y = y;
+    p.y_bs = (long long)x.L * g.N;
+    p.y_rs = g.N;
+    p.B = B;
+    p.M = x.L;
+    p.N = g.N;
+    p.Ktot = g.Ktot;
+    p.scale = epi.scale;
+    p.res = epi.res;
+    p.res_bs = epi.res_bs;
+    p.res_rs = epi.res_rs;
+    p.gelu = epi.gelu;
+    return run_tap(h, st, p);
+}
+
+int wt_groupnorm(ac_handle* h, hipStream_t st, const float* x, size_t w_off, size_t b_off, float* stats, float* y, int B, int N, int swish) {
+    const ac_wavtok_config& c = h->wcfg;
+    const int C = c.backbone_dim, G = c.num_groups;
+    {
+        GnStatsParams p{x, stats, B, N, C, G, 1e-6f};
+        ProfScope ps(h, st, "gn_stats_kernel", 4.0 * B * N * C, 4.0 * B * N * C);
+        hipLaunchKernelGGL(gn_stats_kernel, dim3(B), dim3(256), 0, st, p);
+    }
+    {
+        GnApplyParams p{x, stats, h->blob + w_off, h->blob + b_off, y, B, N, C, G, swish};
+        const long long total = (long long)B * N * (C / 4);
+        ProfScope ps(h, st, "gn_apply_kernel", 4.0 * B * N * C, 8.0 * B * N * C);
+        hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p);
+    }
+    HIPCHK(h, hipGetLastError());
+    return AC_OK;
+}
+
+// feats [B][N][dimension] -> sig [B][N*hop]
+int wavtok_decoder_fwd(ac_handle* h, hipStream_t st, const float* feats, int B, int N, float* sig, WsPtrs& ws) {
+    const ac_wavtok_config& c = h->wcfg;
+    const WavtokPlan& m = h->wt;
+    const int C = c.backbone_dim, I = c.intermediate_dim, D = c.dimension, hop = h->hop;
+    const long long rows = (long long)B * N;
+    float* stats = ws.lstm.c;
+    float* x = ws.take();
+    float* t = ws.take();
+    float* u = ws.take();
+    float* v = ws.take();
+    int rc;
+    Act fa{feats, (long long)N * D, D, N, D};
+    if ((rc = wt_conv(h, st, m.embed, fa, 7, 3, 3, x, B))) return rc;
+    Act xa{x, (long long)N * C, C, N, C};
+    capture(h, st, xa, B);
+    auto resnet = [&](const WtResnetPlan& r) -> int {
+        int e;
+        if ((e = wt_groupnorm(h, st, x, r.n1w, r.n1b, stats, t, B, N, 1))) return e;
+        if ((e = wt_conv(h, st, r.c1, Act{t, (long long)N * C, C, N, C}, 3, 1, 1, u, B))) return e;
+        if ((e = wt_groupnorm(h, st, u, r.n2w, r.n2b, stats, t, B, N, 1))) return e;
+        Epi ep;
+        ep.res = x;
+        ep.res_bs = (long long)N * C;
+        ep.res_rs = C;
+        if ((e = wt_conv(h, st, r.c2, Act{t, (long long)N * C, C, N, C}, 3, 1, 1, x, B, ep))) return e;   // x += conv2(...)
+        capture(h, st, xa, B);
+        return AC_OK;
+    };
+    if ((rc = resnet(m.rn[0])) || (rc = resnet(m.rn[1]))) return rc;
+    {   // AttnBlock
+        if ((rc = wt_groupnorm(h, st, x, m.an_w, m.an_b, stats, t, B, N, 0))) return rc;
+        if ((rc = mimi_linear(h, st, m.qkv, t, rows, C, C, 0, u, 3 * C))) return rc;
+        Attn1Params ap{u, v, B, N, C, 1.0f / std::sqrt((float)C)};
+        {
+            ProfScope ps(h, st, "attn1_kernel", 4.0 * B * (double)N * N * C, 16.0 * B * N * C);
+            const dim3 grid(cdiv(N, 16), B);
+            if (C == 768) hipLaunchKernelGGL(attn1_kernel<192>, grid, dim3(256), 0, st, ap);
+            else if (C == 256) hipLaunchKernelGGL(attn1_kernel<64>, grid, dim3(256), 0, st, ap);
+            else return fail(h, AC_EINVAL, "backbone_dim %d unsupported by the attention kernel (256 or 768)", C);
+        }
+        HIPCHK(h, hipGetLastError());
+        Epi ep;
+        ep.res = x;
+        ep.res_rs = C;
+        if ((rc = mimi_linear(h, st, m.proj, v, rows, C, C, 0, x, C, ep))) return rc;
+        capture(h, st, xa, B);
+    }
+    if ((rc = resnet(m.rn[2])) || (rc = resnet(m.rn[3]))) return rc;
+    if ((rc = wt_groupnorm(h, st, x, m.g5w, m.g5b, stats, t, B, N, 0))) return rc;
+    capture(h, st, Act{t, (long long)N * C, C, N, C}, B);
+    if ((rc = layernorm_fwd(h, st, t, m.nsc, m.nsh, x, rows, C, 1e-6f))) return rc;   // AdaLayerNorm: LN * scale[cond] + shift[cond]
+    capture(h, st, xa, B);
+    for (const WtCnxPlan& L : m.cnx) {
+        {
+            DwLnParams p{x, h->blob + L.dww, h->blob + L.dwb, h->blob + L.sc, h->blob + L.sh, t, B, N, C, 1e-6f};
+            ProfScope ps(h, st, "dwconv_ln_kernel", 2.0 * rows * C * 7, 8.0 * rows * C);
+            hipLaunchKernelGGL(dwconv_ln_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, p);
+            HIPCHK(h, hipGetLastError());
+        }
+        Epi eg;
+        eg.gelu = 1;
+        if ((rc = mimi_linear(h, st, L.p1, t, rows, C, C, 0, u, I, eg))) return rc;
+        Epi em;
+        em.scale = h->blob + L.gamma;
+        em.res = x;
+        em.res_rs = C;
+        if ((rc = mimi_linear(h, st, L.p2, u, rows, I, I, 0, x, C, em))) return rc;
+        capture(h, st, xa, B);
+    }
+    if ((rc = layernorm_fwd(h, st, x, m.flw, m.flb, t, rows, C, 1e-6f))) return rc;
+    capture(h, st, Act{t, (long long)N * C, C, N, C}, B);
+    // ---- head
+    if ((rc = mimi_linear(h, st, m.head, t, rows, C, C, 0, u, m.npad))) return rc;
+    {
+        PolarParams p{u, rows, m.npad, m.bins};
+        const long long total = rows * (m.npad / 2);
+        ProfScope ps(h, st, "polar_kernel", 0.0, 8.0 * rows * m.npad);
+        hipLaunchKernelGGL(polar_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p);
+        HIPCHK(h, hipGetLastError());
+    }
+    {
+        TapGemmParams p{};
+        p.nseg = 1;
+        p.seg[0] = make_seg(Act{u, (long long)N * m.npad, m.npad, N, m.npad}, 1, m.taps, PAD_ZERO, 0, 0, nullptr);
+        p.w = h->blob + m.istft.w_off;
+        p.bias = nullptr;
+        p.y = sig;
+        p.y_bs = (long long)N * hop;
+        p.y_rs = hop;
+        p.B = B;
+        p.M = N + m.taps - 1;
+        p.N = m.istft.N;
+        p.n_valid = hop;
+        p.Ktot = m.istft.Ktot;
+        p.y_off = -(long long)(c.n_fft - hop) / 2;
+        p.y_len = (long long)N * hop;
+        if ((rc = run_tap(h, st, p))) return rc;
+    }
+    {
+        EnvParams p{sig, h->blob + m.w2, B, N, hop, c.n_fft};
+        const long long L = (long long)N * hop;
+        ProfScope ps(h, st, "istft_env_kernel", 0.0, 8.0 * B * L);
+        hipLaunchKernelGGL(istft_env_kernel, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, st, p);
+        HIPCHK(h, hipGetLastError());
+    }
+    ws.give(x); ws.give(t); ws.give(u); ws.give(v);
+    return AC_OK;
+}
+
+Workspace wavtok_plan_ws(const ac_handle* h, int B, int T_in, int N_frames, bool enc) {
+    if (enc) return plan_ws(h, B, T_in, N_frames, true);
+    const ac_wavtok_config& c = h->wcfg;
+    Workspace w;
+    const size_t widest = std::max<size_t>(std::max(3 * c.backbone_dim, c.intermediate_dim), std::max(h->wt.npad, c.dimension));
+    w.act_floats = align_up((size_t)B * N_frames * widest, 64);
+    w.c = align_up((size_t)B * c.num_groups * 2, 64);
+    w.total_bytes = (NACT * w.act_floats + 2 * w.gin + 2 * w.hseq + w.c) * sizeof(float) + 256;
+    return w;
+}

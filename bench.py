@@ -181,9 +181,9 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="clips per GPU")
-    ap.add_argument("--codec", choices=["encodec", "mimi", "dac"], default="encodec",
+    ap.add_argument("--codec", choices=["encodec", "mimi", "dac", "wavtokenizer"], default="encodec",
                     help="encodec = BASELINE.json configs[1] (the contract's default); mimi = configs[3] shape (SURVEY.md §8 f3); "
-                         "dac = configs[2] (DAC 44.1 kHz, 9 codebooks; use --batch 256)")
+                         "dac = configs[2] (DAC 44.1 kHz, 9 codebooks; use --batch 256); wavtokenizer = configs[4] (40 tok/s, 64 clips per GPU)")
     ap.add_argument("--seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -202,14 +202,14 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    from audiocodecs_amd import DAC, Encodec, Mimi, checkpoint, prng
-    from audiocodecs_amd.config import DAC_44KHZ, ENCODEC_24KHZ, MIMI_24KHZ
+    from audiocodecs_amd import DAC, Encodec, Mimi, WavTokenizer, checkpoint, prng
+    from audiocodecs_amd.config import DAC_44KHZ, ENCODEC_24KHZ, MIMI_24KHZ, WAVTOK_40
     from audiocodecs_amd.sharding import gather_tokens
 
     mimi = args.codec != "encodec"   # "not the headline codec": whole-path fractions from the kernels' own counts
-    cfg = {"mimi": MIMI_24KHZ, "dac": DAC_44KHZ, "encodec": ENCODEC_24KHZ}[args.codec]
-    label = {"mimi": "Mimi-24k", "dac": "DAC-44.1k", "encodec": "EnCodec-24k"}[args.codec]
-    ncb = 9 if args.codec == "dac" else 8
+    cfg = {"mimi": MIMI_24KHZ, "dac": DAC_44KHZ, "encodec": ENCODEC_24KHZ, "wavtokenizer": WAVTOK_40}[args.codec]
+    label = {"mimi": "Mimi-24k", "dac": "DAC-44.1k", "encodec": "EnCodec-24k", "wavtokenizer": "WavTokenizer-24k-40tok"}[args.codec]
+    ncb = {"dac": 9, "wavtokenizer": 1}.get(args.codec, 8)
     B, T = args.batch, int(round(args.seconds * cfg.sampling_rate))
     if args.codec == "mimi":
         sd = checkpoint.synthetic_mimi_state_dict(cfg, seed=0)
@@ -217,6 +217,9 @@ def main():
     elif args.codec == "dac":
         sd = checkpoint.synthetic_dac_state_dict(cfg, seed=0)
         codec = DAC(cfg.sampling_rate, cfg.sampling_rate, num_codebooks=9, state_dict=sd, config=cfg).eval()
+    elif args.codec == "wavtokenizer":
+        sd = checkpoint.synthetic_wavtok_state_dict(cfg, seed=0)
+        codec = WavTokenizer(cfg.sampling_rate, state_dict=sd, arch=cfg).eval()
     else:
         sd = checkpoint.synthetic_state_dict(cfg, seed=0)
         codec = Encodec(cfg.sampling_rate, num_codebooks=8, state_dict=sd).eval()

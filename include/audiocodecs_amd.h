@@ -126,6 +126,43 @@ typedef struct ac_dac_config {
     int32_t device;
 } ac_dac_config;
 
+/* WavTokenizer (BASELINE.json configs[4]).  The reference wrapper (audiocodecs/wavtokenizer.py:31-135)
+ * calls the package `wavtokenizer` (lucadellalib/WavTokenizer), which is NOT on disk: PARITY UNPINNED -- this path is
+ * pinned to oracle/wavtokenizer_oracle.py, a restatement of the published modules.  Replaces
+ *     wavtokenizer.py:94-95    self.model.encode(sig, bandwidth_id=0)                  -> ac_encode (K = 1) / ac_dequantize
+ *     wavtokenizer.py:101      self.model.feature_extractor.encodec.encoder(sig[:, None]) -> ac_encode_feats
+ *     wavtokenizer.py:115-118  codes_to_features(...) + self.model.decode(feats, bandwidth_id=0) -> ac_decode (ac_dequantize)
+ *     wavtokenizer.py:130-133  self.model.decode(feats.movedim(-1,-2), bandwidth_id=0)  -> ac_decode_feats
+ *     wavtokenizer.py:87       quantizer.vq.layers[0].codebook                          -> ac_embs
+ * Fields: the published YAML configs the wrapper names (:37-40).  Weight names are the checkpoint's own
+ * ("feature_extractor.encodec.encoder.model.{i}.conv.conv.{weight_g,weight_v,bias}", "...block.{1,3}...", "...shortcut...",
+ * "...model.{i}.lstm.weight_ih_l0", "feature_extractor.encodec.quantizer.vq.layers.0._codebook.embed",
+ * "backbone.embed.*", "backbone.pos_net.{0,1,3,4}.{norm1,conv1,norm2,conv2}.*", "backbone.pos_net.2.{norm,q,k,v,proj_out}.*",
+ * "backbone.pos_net.5.*", "backbone.norm.{scale,shift}.weight", "backbone.convnext.{l}.{dwconv,norm.scale,norm.shift,
+ * pwconv1,pwconv2}.*", "...gamma", "backbone.final_layer_norm.*", "head.out.*", optional "head.istft.window"). */
+typedef struct ac_wavtok_config {
+    int32_t struct_size;               /* = sizeof(ac_wavtok_config)                                          */
+    int32_t sampling_rate;             /* 24000                                                               */
+    int32_t num_filters;               /* 32                                                                  */
+    int32_t dimension;                 /* 512: encoder output width == codebook dim == backbone input width   */
+    int32_t num_ratios;                /* 4                                                                   */
+    int32_t ratios[AC_MAX_RATIOS];     /* 6,5,5,4 (`dowmsamples`; the encoder applies them reversed); 75 tok/s: 8,5,4,2 */
+    int32_t kernel_size;               /* 7                                                                   */
+    int32_t last_kernel_size;          /* 7                                                                   */
+    int32_t residual_kernel_size;      /* 3                                                                   */
+    int32_t compress;                  /* 2                                                                   */
+    int32_t num_lstm_layers;           /* 2                                                                   */
+    int32_t codebook_size;             /* 4096                                                                */
+    int32_t backbone_dim;              /* 768 (256 also supported)                                            */
+    int32_t intermediate_dim;          /* 2304                                                                */
+    int32_t num_layers;                /* 12 ConvNeXt blocks                                                  */
+    int32_t adanorm_num_embeddings;    /* 4                                                                   */
+    int32_t num_groups;                /* 32 (GroupNorm of pos_net)                                           */
+    int32_t n_fft;                     /* 2400 (hop 600); 1280 (hop 320); must be a multiple of the hop       */
+    int32_t bandwidth_id;              /* 0: the AdaLayerNorm row the wrapper always selects                  */
+    int32_t device;
+} ac_wavtok_config;
+
 /* Library/ABI version: major*10000 + minor*100 + patch. */
 int ac_version(void);
 
@@ -139,6 +176,9 @@ int ac_mimi_create(const ac_mimi_config* cfg, ac_handle** out);
  * res_unit{u}.{snake1.alpha,conv1.weight,...}", "decoder.block.{i}.conv_t1.weight", "quantizer.quantizers.{k}.
  * {in_proj,out_proj}.{weight,bias}", "...codebook.weight"; weights plain, i.e. weight-norm already folded). */
 int ac_dac_create(const ac_dac_config* cfg, ac_handle** out);
+
+/* Same, for a WavTokenizer handle. */
+int ac_wavtok_create(const ac_wavtok_config* cfg, ac_handle** out);
 
 /* Hand one fp32 tensor to the handle (copied).  `name` uses the HF state-dict keys of
  * EncodecModel with weight-norm either
@@ -200,6 +240,11 @@ int ac_encode_feats(ac_handle* h, const float* sig_dev, const float* rel_len_dev
 int ac_decode(ac_handle* h, const int64_t* toks_dev, int B, int N, int K, float* sig_dev,
               void* workspace_dev, size_t workspace_bytes, void* stream);
 
+/* WavTokenizer only (wavtokenizer.py:128-135 `_feats_to_sig`): feats_dev [B,N,dimension] (channels-last) -> sig_dev [B, N*hop]
+ * through backbone + iSTFT head.  Workspace: ac_decode_workspace_bytes(h, B, N). */
+int ac_decode_feats(ac_handle* h, const float* feats_dev, int B, int N, float* sig_dev, void* workspace_dev, size_t workspace_bytes,
+                    void* stream);
+
 /* DAC only.  ac_encode_quantized: ac_encode that also returns the quantised representation
  * qfeats_dev [B,N,H] `model.encode` yields (dac.py:117-119; not bit-identical to from_codes: the
  * straight-through form rounds).  ac_encode_feats_latent: quantizers[0].in_proj(encoder(sig)) -> [B,N,8]
@@ -257,9 +302,17 @@ int ac_profile_end(ac_handle* h, ac_kernel_stat* out, int cap);
 int ac_debug_capture(ac_handle* h, float* buf_dev, size_t cap_floats);
 size_t ac_debug_captured(const ac_handle* h);
 
-/* Which LSTM path the handle uses (synchronising; tests / diagnostics): 1 = the persistent single-launch kernel
+/* Which LSTM path the handle uses (SYNCHRONISES the device; tests / diagnostics): 1 = the persistent single-launch kernel
  * (D = 512, 2 layers, 256-CU device; opt out with the environment variable AC_LSTM=step), 0 = one launch per
- * time step, AC_EHIP = the persistent kernel's bounded waits timed out in the last call (results invalid). */
+ * time step, AC_EHIP = a persistent launch failed since the handle was created (a bounded wait expired, or the launch
+ * did not get 32 workgroups on every XCD -- e.g. a shared GPU).
+ *
+ * Failures only the device can see are STICKY and reported by the next entry point called on the handle (no entry point
+ * synchronises): the failed call's outputs were set to NaN on the device -- never left unwritten --, the next call
+ * returns AC_EHIP once and the handle switches to the per-step LSTM kernels; likewise a token id outside
+ * [0, codebook_size) in ac_decode / ac_dequantize sets that frame to NaN and the next call returns AC_EINVAL once
+ * (torch.nn.functional.embedding raises).  A clip whose samples contain NaN/Inf does not disturb the other clips of
+ * the batch: its LSTM outputs are NaN from that frame on, like the reference's. */
 int ac_lstm_status(ac_handle* h);
 
 const char* ac_last_error(const ac_handle* h);

@@ -101,3 +101,29 @@ def dac_checkpoints():
         return _DAC_CKPT[key]
 
     return get
+
+
+@pytest.fixture(scope="session")
+def wavtok_golden():
+    z = np.load(os.path.join(GOLDEN_DIR, "wavtokenizer_golden.npz"))
+    meta = json.loads(bytes(z["meta_json"]).decode())
+    return z, meta
+
+
+_WT_CKPT = {}
+
+
+@pytest.fixture(scope="session")
+def wavtok_checkpoints():
+    """(cfg_name, seed) -> (WavTokenizerConfig, synthetic checkpoint in the upstream key layout); cached for the session."""
+    from audiocodecs_amd import checkpoint
+    from audiocodecs_amd.config import WAVTOK_40, WAVTOK_75, WAVTOK_TINY
+
+    def get(cfg_name, seed):
+        key = (cfg_name, seed)
+        if key not in _WT_CKPT:
+            cfg = {"full": WAVTOK_40, "f75": WAVTOK_75, "tiny": WAVTOK_TINY}[cfg_name]
+            _WT_CKPT[key] = (cfg, checkpoint.synthetic_wavtok_state_dict(cfg, seed=seed))
+        return _WT_CKPT[key]
+
+    return get
