@@ -12,7 +12,7 @@ import os
 
 import torch  # noqa: F401  (loads libamdhip64 first)
 
-__all__ = ["lib", "lib_path", "AcConfig", "AcMimiConfig", "AcDacConfig", "AcWavtokConfig", "AcKernelStat", "NativeError", "check", "EXPORTS"]
+__all__ = ["lib", "lib_path", "AcConfig", "AcMimiConfig", "AcDacConfig", "AcWavtokConfig", "AcKernelStat", "NativeError", "check", "EXPORTS", "track"]
 
 AC_MAX_RATIOS = 8
 # AUDIOCODECS_AMD_LIB: developer override (timing variants built by hand); the product is the in-tree library
@@ -167,6 +167,31 @@ EXPORTS = {
 }
 
 _lib = None
+_live = None   # weak set of objects holding an ac_handle (attribute `h`): destroyed at interpreter exit, while the HIP
+               # runtime is still up (a handle owns device memory, pinned host memory and events)
+
+
+def track(obj) -> None:
+    """Register an object with attributes `lib` and `h` (an ac_handle) for destruction at exit."""
+    global _live
+    if _live is None:
+        import atexit
+        import weakref
+
+        _live = weakref.WeakSet()
+
+        def _destroy_all():
+            for o in list(_live):
+                try:
+                    if getattr(o, "h", None):
+                        o.lib.ac_destroy(o.h)
+                        o.h = None
+                except Exception:
+                    pass
+
+        atexit.register(_destroy_all)
+    _live.add(obj)
+
 
 
 def lib():

@@ -1612,7 +1612,8 @@ int ac_wavtok_create(const ac_wavtok_config* cfg, ac_handle** out) {
         c.kernel_size < 1 || c.kernel_size > 8 || c.last_kernel_size < 1 || c.last_kernel_size > 8 || c.residual_kernel_size < 1 ||
         c.residual_kernel_size > 8 || (c.backbone_dim != 256 && c.backbone_dim != 768) || c.intermediate_dim < 16 || c.intermediate_dim % 4 ||
         c.num_layers < 0 || c.adanorm_num_embeddings < 1 || c.bandwidth_id < 0 || c.bandwidth_id >= c.adanorm_num_embeddings ||
-        c.num_groups < 1 || c.num_groups > 256 || c.backbone_dim % c.num_groups || c.n_fft < 4 || c.n_fft % 2)
+        c.num_groups < GN_GPW || c.num_groups % GN_GPW || c.backbone_dim % c.num_groups || (c.backbone_dim / c.num_groups * GN_GPW) % 4 ||
+        c.backbone_dim / c.num_groups * GN_GPW > 1024 || c.n_fft < 4 || c.n_fft % 2)
         return AC_EINVAL;
     int hop = 1;
     for (int i = 0; i < c.num_ratios; ++i) {

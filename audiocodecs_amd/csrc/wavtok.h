@@ -14,9 +14,10 @@
 namespace ac {
 
 // ---------------------------------------------------------------------------------------------
-// GroupNorm statistics: one workgroup per clip reads its [N][C] slab once per pass (coalesced rows), every thread
-// owns C/256 channels; two passes (mean, then centred second moment) in fp32 -- biased variance like torch.
-// Algorithmic bytes: 4*N*C per clip (second pass hits L2).  stats[b][g] = (mean, rstd).
+// GroupNorm statistics: workgroup = (clip, GN_GPW consecutive groups) -- 512 workgroups at 64 clips x 32 groups.  It reads
+// its [N][GN_GPW * C/G] column block with 16-byte loads (thread = (row lane, 4 channels)), two passes (mean, then centred
+// second moment; the second pass hits L2) in fp32 -- biased variance like torch.  stats[b][g] = (mean, rstd).
+// Algorithmic bytes: 4*N*C per clip.
 // ---------------------------------------------------------------------------------------------
 struct GnStatsParams {
     const float* x;      // [B][N][C]
@@ -25,52 +26,49 @@ struct GnStatsParams {
     float eps;
 };
 
-constexpr int GN_MAXC = 4;   // C <= 1024
+constexpr int GN_GPW = 4;    // groups per workgroup; needs (C/G * GN_GPW) % 4 == 0 and C/G * GN_GPW <= 1024
 
 __global__ __launch_bounds__(256) void gn_stats_kernel(const GnStatsParams p) {
-    __shared__ float red[GN_MAXC * 256];
-    __shared__ float gmean[256];
-    const int b = blockIdx.x, tid = threadIdx.x;
-    const int cpg = p.C / p.G;
-    const float* xb = p.x + (long long)b * p.N * p.C;
+    __shared__ float red[256 * 4];
+    __shared__ float gmean[GN_GPW];
+    const int b = blockIdx.y, g0 = blockIdx.x * GN_GPW, tid = threadIdx.x;
+    const int cpg = p.C / p.G, width = cpg * GN_GPW, cols4 = width / 4;
+    const int rl = 256 / cols4, rlane = tid / cols4, c4 = (tid % cols4) * 4;
+    const bool active = rlane < rl;
+    const float* xb = p.x + (long long)b * p.N * p.C + (long long)g0 * cpg + c4;
     const float cnt = (float)p.N * (float)cpg;
-    float s[GN_MAXC];
-#pragma unroll
-    for (int i = 0; i < GN_MAXC; ++i) s[i] = 0.f;
-    for (int t = 0; t < p.N; ++t)
-#pragma unroll
-        for (int i = 0; i < GN_MAXC; ++i) {
-            const int c = tid + 256 * i;
-            if (c < p.C) s[i] += xb[(long long)t * p.C + c];
+    f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (active)
+        for (int t = rlane; t < p.N; t += rl) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(xb + (long long)t * p.C);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
-#pragma unroll
-    for (int i = 0; i < GN_MAXC; ++i) red[tid + 256 * i] = s[i];
+    *reinterpret_cast<f32x4*>(&red[tid * 4]) = s;
     __syncthreads();
-    if (tid < p.G) {
+    if (tid < GN_GPW) {          // fixed summation order: row lanes outer, the group's channels inner
         float m = 0.f;
-        for (int c = 0; c < cpg; ++c) m += red[tid * cpg + c];
+        for (int r = 0; r < rl; ++r)
+            for (int c = 0; c < cpg; ++c) m += red[(r * cols4) * 4 + tid * cpg + c];
         gmean[tid] = m / cnt;
     }
     __syncthreads();
-#pragma unroll
-    for (int i = 0; i < GN_MAXC; ++i) s[i] = 0.f;
-    for (int t = 0; t < p.N; ++t)
-#pragma unroll
-        for (int i = 0; i < GN_MAXC; ++i) {
-            const int c = tid + 256 * i;
-            if (c < p.C) {
-                const float d = xb[(long long)t * p.C + c] - gmean[c / cpg];
-                s[i] = fmaf(d, d, s[i]);
-            }
+    s = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (active) {
+        const f32x4 mu = f32x4{gmean[c4 / cpg], gmean[(c4 + 1) / cpg], gmean[(c4 + 2) / cpg], gmean[(c4 + 3) / cpg]};
+        for (int t = rlane; t < p.N; t += rl) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(xb + (long long)t * p.C);
+            const f32x4 d = f32x4{v.x - mu.x, v.y - mu.y, v.z - mu.z, v.w - mu.w};
+            s.x = fmaf(d.x, d.x, s.x); s.y = fmaf(d.y, d.y, s.y); s.z = fmaf(d.z, d.z, s.z); s.w = fmaf(d.w, d.w, s.w);
         }
+    }
     __syncthreads();
-#pragma unroll
-    for (int i = 0; i < GN_MAXC; ++i) red[tid + 256 * i] = s[i];
+    *reinterpret_cast<f32x4*>(&red[tid * 4]) = s;
     __syncthreads();
-    if (tid < p.G) {
+    if (tid < GN_GPW) {
         float v = 0.f;
-        for (int c = 0; c < cpg; ++c) v += red[tid * cpg + c];
-        float* o = p.stats + ((long long)b * p.G + tid) * 2;
+        for (int r = 0; r < rl; ++r)
+            for (int c = 0; c < cpg; ++c) v += red[(r * cols4) * 4 + tid * cpg + c];
+        float* o = p.stats + ((long long)b * p.G + g0 + tid) * 2;
         o[0] = gmean[tid];
         o[1] = 1.0f / sqrtf(v / cnt + p.eps);
     }

@@ -202,7 +202,7 @@ int wt_groupnorm(ac_handle* h, hipStream_t st, const float* x, size_t w_off, siz
     {
         GnStatsParams p{x, stats, B, N, C, G, 1e-6f};
         ProfScope ps(h, st, "gn_stats_kernel", 4.0 * B * N * C, 4.0 * B * N * C);
-        hipLaunchKernelGGL(gn_stats_kernel, dim3(B), dim3(256), 0, st, p);
+        hipLaunchKernelGGL(gn_stats_kernel, dim3(G / GN_GPW, B), dim3(256), 0, st, p);
     }
     {
         GnApplyParams p{x, stats, h->blob + w_off, h->blob + b_off, y, B, N, C, G, swish};

@@ -97,6 +97,7 @@ class _NativeDac:
         with torch.cuda.device(self.device):
             _native.check(self.lib.ac_finalize(self.h), self.h, "ac_finalize")
         self.ws: Optional[torch.Tensor] = None
+        _native.track(self)
 
     def workspace(self, nbytes: int) -> torch.Tensor:
         if self.ws is None or self.ws.numel() < nbytes:

@@ -56,6 +56,7 @@ class _NativeWavTok:
         with torch.cuda.device(self.device):
             _native.check(self.lib.ac_finalize(self.h), self.h, "ac_finalize")
         self.ws: Optional[torch.Tensor] = None
+        _native.track(self)
 
     def workspace(self, nbytes: int) -> torch.Tensor:
         if self.ws is None or self.ws.numel() < nbytes:
