@@ -12,7 +12,7 @@ import os
 
 import torch  # noqa: F401  (loads libamdhip64 first)
 
-__all__ = ["lib", "lib_path", "AcConfig", "AcMimiConfig", "AcDacConfig", "AcWavtokConfig", "AcKernelStat", "NativeError", "check", "EXPORTS", "track"]
+__all__ = ["lib", "lib_path", "AcConfig", "AcMimiConfig", "AcDacConfig", "AcWavtokConfig", "AcKernelStat", "NativeError", "check", "EXPORTS", "track", "set_precision", "check_precision", "PRECISIONS"]
 
 AC_MAX_RATIOS = 8
 # AUDIOCODECS_AMD_LIB: developer override (timing variants built by hand); the product is the in-tree library
@@ -136,6 +136,7 @@ EXPORTS = {
     "ac_wavtok_create": (_i, [C.POINTER(AcWavtokConfig), C.POINTER(_vp)]),
     "ac_decode_feats": (_i, [_vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
     "ac_load_weights": (_i, [_vp, C.c_char_p, _vp, _sz]),
+    "ac_set_precision": (_i, [_vp, _i]),
     "ac_finalize": (_i, [_vp]),
     "ac_num_frames": (_i, [_vp, _i]),
     "ac_num_samples": (C.c_longlong, [_vp, _i]),
@@ -165,6 +166,24 @@ EXPORTS = {
     "ac_last_error": (C.c_char_p, [_vp]),
     "ac_destroy": (None, [_vp]),
 }
+
+PRECISIONS = {"fp32": 0, "fp32_exact": 1, "bf16": 2}   # AC_PRECISION_*
+
+
+def check_precision(precision):
+    if precision is not None and precision not in PRECISIONS:
+        raise ValueError(f"`precision` ({precision}) must be one of {list(PRECISIONS)}")
+    return precision
+
+
+def set_precision(L, h, precision) -> None:
+    """precision: None (library default / AC_GEMM), "fp32" (split-operand, fp32 fidelity), "fp32_exact", "bf16" (opt-in)."""
+    if precision is None:
+        return
+    if precision not in PRECISIONS:
+        raise ValueError(f"`precision` ({precision}) must be one of {list(PRECISIONS)}")
+    check(L.ac_set_precision(h, PRECISIONS[precision]), h, "ac_set_precision")
+
 
 _lib = None
 _live = None   # weak set of objects holding an ac_handle (attribute `h`): destroyed at interpreter exit, while the HIP

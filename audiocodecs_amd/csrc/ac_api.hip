@@ -169,7 +169,9 @@ struct ac_handle {
     std::map<size_t, size_t> t6_of;   // thin_conv6.h fragment images of the [64][128] layers, keyed like w6_of
     bool noncausal = false;                // WavTokenizer's SEANet encoder: centred padding (right = total/2, left = total - right)
     bool has_enc = true, has_dec = true;   // a half the caller's mode never runs may be left out (encodec.py:67-71)
-    bool gemm_fp32 = false;         // AC_GEMM=fp32: exact-product kernels only
+    bool gemm_fp32 = false;         // AC_PRECISION_FP32_EXACT (or AC_GEMM=fp32): exact-product kernels only
+    bool gemm_bf16 = false;         // AC_PRECISION_BF16 (or AC_GEMM=bf16): opt-in, operands rounded to bf16 in the tap-GEMMs
+    int precision = -1;             // ac_set_precision; -1: take AC_GEMM from the environment
     // persistent LSTM (lstm_persist.h): control words, device shape, opt-out (AC_LSTM=step)
     unsigned* lp_ctl = nullptr;
     int num_cus = 0;
@@ -321,6 +323,12 @@ struct Packer {
     }
     // tap_gemm6.h weight operand: exact truncation split of every weight into three bf16 terms, packed in MFMA
     // B-fragment order  [n-tile of 32][k-step of 16][plane][lane 64][8]
+    static uint16_t bf16_rn(float v) {
+        uint32_t b;
+        std::memcpy(&b, &v, 4);
+        if ((b & 0x7f800000u) == 0x7f800000u) return (uint16_t)(b >> 16);   // inf / nan
+        return (uint16_t)((b + 0x7fffu + ((b >> 16) & 1u)) >> 16);
+    }
     void pack6(const PackedGemm& g) {
         if ((g.N % 64 && g.N % 96) || g.Ktot % 32 || h->w6_of.count(g.w_off)) return;
         const size_t n_el = (size_t)g.N * g.Ktot;
@@ -347,6 +355,10 @@ struct Packer {
                         uint32_t b2;
                         std::memcpy(&b2, &r2, 4);
                         const size_t base = (((size_t)nt * ksteps + s) * 3) * 512 + (size_t)l * 8 + e;
+                        if (h->gemm_bf16) {   // opt-in bf16 mode: plane 0 = round-to-nearest-even(w), the others unused
+                            planes[base] = bf16_rn(v);
+                            continue;
+                        }
                         planes[base] = (uint16_t)(bh >> 16);
                         planes[base + 512] = (uint16_t)(bm >> 16);
                         planes[base + 1024] = (uint16_t)(b2 >> 16);
@@ -735,6 +747,12 @@ int run_tap(ac_handle* h, hipStream_t st, TapGemmParams& p) {
         using Cfg6 = Tap6Cfg<WGM, WGN, WMT, WN>;                                                                        \
         p.ntiles = p.N / Cfg6::BN;                                                                                      \
         const long long blocks = (long long)p.B * p.mtiles * p.ntiles;                                                  \
+        if (h->gemm_bf16) {                                                                                             \
+            if ((rc = ensure_lds(h, reinterpret_cast<const void*>(tap_gemm6_kernel<WGM, WGN, WMT, WN, 1>), Cfg6::lds_bytes))) return rc; \
+            ProfScope ps(h, st, (std::string("tap_gemm6_kernel<" #WGM ", " #WGN ", " #WMT ", " #WN ", 1>") + shape).c_str(), flops, bytes); \
+            hipLaunchKernelGGL((tap_gemm6_kernel<WGM, WGN, WMT, WN, 1>), dim3((unsigned)blocks), dim3(256), Cfg6::lds_bytes, st, p, w6); \
+            break;                                                                                                      \
+        }                                                                                                               \
         if ((rc = ensure_lds(h, reinterpret_cast<const void*>(tap_gemm6_kernel<WGM, WGN, WMT, WN>), Cfg6::lds_bytes))) return rc; \
         ProfScope ps(h, st, (std::string("tap_gemm6_kernel<" #WGM ", " #WGN ", " #WMT ", " #WN ">") + shape).c_str(), flops, bytes); \
         hipLaunchKernelGGL((tap_gemm6_kernel<WGM, WGN, WMT, WN>), dim3((unsigned)blocks), dim3(256), Cfg6::lds_bytes, st, p, w6);   \
@@ -1680,8 +1698,6 @@ static int upload_blob(ac_handle* h, Packer& pk, int device) {
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(h, AC_ENODEV, "device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
     h->num_cus = prop.multiProcessorCount;
-    const char* gm = std::getenv("AC_GEMM");
-    h->gemm_fp32 = gm && std::strcmp(gm, "fp32") == 0;
     const char* lm = std::getenv("AC_LSTM");
     h->lstm_step_only = lm && std::strcmp(lm, "step") == 0;
     HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&h->lp_ctl), LP_CTL_WORDS * sizeof(unsigned)));
@@ -1709,9 +1725,26 @@ static int upload_blob(ac_handle* h, Packer& pk, int device) {
     return AC_OK;
 }
 
+int ac_set_precision(ac_handle* h, int precision) {
+    if (!h) return AC_EINVAL;
+    if (h->finalized) return fail(h, AC_ESTATE, "ac_set_precision must precede ac_finalize (weights are packed for one arithmetic)");
+    if (precision < AC_PRECISION_FP32 || precision > AC_PRECISION_BF16) return fail(h, AC_EINVAL, "unknown precision %d", precision);
+    h->precision = precision;
+    return AC_OK;
+}
+
 int ac_finalize(ac_handle* h) {
     if (!h) return AC_EINVAL;
     if (h->finalized) return fail(h, AC_ESTATE, "handle already finalized");
+    {   // arithmetic of the GEMM-shaped kernels: ac_set_precision, else the environment variable AC_GEMM (fp32 | bf16)
+        int pr = h->precision;
+        if (pr < 0) {
+            const char* gm = std::getenv("AC_GEMM");
+            pr = gm && std::strcmp(gm, "fp32") == 0 ? AC_PRECISION_FP32_EXACT : gm && std::strcmp(gm, "bf16") == 0 ? AC_PRECISION_BF16 : AC_PRECISION_FP32;
+        }
+        h->gemm_fp32 = pr == AC_PRECISION_FP32_EXACT;
+        h->gemm_bf16 = pr == AC_PRECISION_BF16;
+    }
     if (h->arch == ARCH_MIMI) {
         Packer pk{h};
         if (int rc = mimi_finalize(h, pk)) return rc;

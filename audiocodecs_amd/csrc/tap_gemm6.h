@@ -40,7 +40,10 @@ struct Tap6Cfg {
     static constexpr size_t lds_bytes = main_bytes > epi_bytes ? main_bytes : epi_bytes;
 };
 
-template <int WGM, int WGN, int WMT, int WN>
+// NP = 3: split-operand arithmetic (three bf16 planes per operand, 6 partial products): fp32 fidelity -- the default.
+// NP = 1: the opt-in bf16 mode (ac_set_precision(AC_PRECISION_BF16)): operands ROUNDED to bf16 (nearest-even), one product,
+//         fp32 accumulate; the weight image then holds round(w) in plane 0.  Never the parity path.
+template <int WGM, int WGN, int WMT, int WN, int NP = 3>
 __global__ __launch_bounds__(256, 2) void tap_gemm6_kernel(const TapGemmParams p, const __bf16* __restrict__ wp) {
     using Cfg = Tap6Cfg<WGM, WGN, WMT, WN>;
     constexpr int BM = Cfg::BM, BN = Cfg::BN, NT = Cfg::NT, A_SLOTS = Cfg::A_SLOTS, PLANE = Cfg::PLANE;
@@ -147,6 +150,11 @@ __global__ __launch_bounds__(256, 2) void tap_gemm6_kernel(const TapGemmParams p
         for (int i = 0; i < A_SLOTS; ++i)
             if (a_lds[i] >= 0) {
                 const f32x4 v = (a_zero & (1u << i)) ? f32x4{0.f, 0.f, 0.f, 0.f} : ra[i];
+                if (NP == 1) {   // bf16 mode: round to nearest even, one plane
+                    typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+                    *reinterpret_cast<bf16x4_t*>(dst + a_lds[i]) = __builtin_convertvector(v, bf16x4_t);
+                    continue;
+                }
                 unsigned h[4], m[4], l[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -174,7 +182,7 @@ __global__ __launch_bounds__(256, 2) void tap_gemm6_kernel(const TapGemmParams p
 #pragma unroll
         for (int c = 0; c < WN; ++c)
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl)
+            for (int pl = 0; pl < NP; ++pl)
                 bf[pl][c] = *reinterpret_cast<const bf16x8*>(wbase + (((long long)c * ksteps + s_) * 3 + pl) * (64 * 8));
     };
 
@@ -192,7 +200,7 @@ __global__ __launch_bounds__(256, 2) void tap_gemm6_kernel(const TapGemmParams p
     const int a_frag = (wm * WMT * 32 + i32) * T6_PITCH + 8 * kh;    // + (a*32 + j)*T6_PITCH + ks*16, + plane*PLANE
     auto read_a = [&](const __bf16* Ac, int ks, bf16x8 (&af)[3][WMT]) {
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
+        for (int pl = 0; pl < NP; ++pl)
 #pragma unroll
             for (int a = 0; a < WMT; ++a) af[pl][a] = *reinterpret_cast<const bf16x8*>(Ac + pl * PLANE + a * 32 * T6_PITCH + ks * 16);
     };
@@ -202,6 +210,10 @@ __global__ __launch_bounds__(256, 2) void tap_gemm6_kernel(const TapGemmParams p
 #pragma unroll
             for (int c = 0; c < WN; ++c) {
                 f32x16 v = acc[a][c];
+                if (NP == 1) {
+                    acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][a], bf[0][c], v, 0, 0, 0);
+                    continue;
+                }
                 // smallest partial products first: hl, lh, mm, hm, mh, hh
                 v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][a], bf[2][c], v, 0, 0, 0);
                 v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][a], bf[0][c], v, 0, 0, 0);

@@ -62,7 +62,7 @@ def state_dict_from_descript(sd: Dict[str, torch.Tensor], cfg: DacConfig) -> Dic
 class _NativeDac:
     """One DAC ac_handle: weights on one GPU + a grow-only workspace tensor."""
 
-    def __init__(self, cfg: DacConfig, sd: Dict[str, torch.Tensor], device: torch.device):
+    def __init__(self, cfg: DacConfig, sd: Dict[str, torch.Tensor], device: torch.device, precision=None):
         self.lib = _native.lib()
         c = _native.AcDacConfig()
         c.struct_size = C.sizeof(_native.AcDacConfig)
@@ -86,6 +86,7 @@ class _NativeDac:
         rc = self.lib.ac_dac_create(C.byref(c), C.byref(self.h))
         if rc < 0:
             raise _native.NativeError(f"ac_dac_create failed with code {rc} (unsupported configuration, or no gfx950 GPU visible)")
+        _native.set_precision(self.lib, self.h, precision)
         for name, t in sd.items():
             if not t.is_floating_point():
                 continue
@@ -131,6 +132,7 @@ class DAC(Codec):
         *,
         state_dict: Optional[Dict[str, torch.Tensor]] = None,
         config: Optional[DacConfig] = None,
+        precision: Optional[str] = None,
     ):
         """`state_dict`: HF `DacModel.state_dict()` names, or descript's own (`weights.pth["state_dict"]`, detected
         by its `weight_g` keys and converted by :func:`state_dict_from_descript`), or
@@ -140,6 +142,7 @@ class DAC(Codec):
         self.num_codebooks = num_codebooks
         self.vocab_size = 1024  # dac.py:52
         self.latent = latent
+        self.precision = _native.check_precision(precision)   # see Encodec: None / "fp32" (parity arithmetic), "fp32_exact", "bf16" (opt-in)
         tag = int(orig_sample_rate / 1000)  # dac.py:55
         if config is None:
             if tag not in _BY_TAG:
@@ -160,7 +163,7 @@ class DAC(Codec):
             )
         idx = t.device.index
         if idx not in self._natives:
-            self._natives[idx] = _NativeDac(self.config, self._sd, t.device)
+            self._natives[idx] = _NativeDac(self.config, self._sd, t.device, self.precision)
         return self._natives[idx]
 
     def _any_native(self) -> _NativeDac:

@@ -31,7 +31,7 @@ def _stream():
 class _Native:
     """One ac_handle: weights on one GPU + a grow-only workspace tensor."""
 
-    def __init__(self, cfg: EncodecConfig, folded: Dict[str, torch.Tensor], device: torch.device):
+    def __init__(self, cfg: EncodecConfig, folded: Dict[str, torch.Tensor], device: torch.device, precision=None):
         self.lib = _native.lib()
         c = _native.AcConfig()
         c.struct_size = C.sizeof(_native.AcConfig)
@@ -54,6 +54,7 @@ class _Native:
         rc = self.lib.ac_create(C.byref(c), C.byref(self.h))
         if rc < 0:
             raise _native.NativeError(f"ac_create failed with code {rc} (is a gfx950 GPU visible?)")
+        _native.set_precision(self.lib, self.h, precision)
         for name, t in folded.items():
             if not t.is_floating_point():
                 continue
@@ -99,12 +100,16 @@ class Encodec(Codec):
         *,
         state_dict: Optional[Dict[str, torch.Tensor]] = None,
         config: EncodecConfig = ENCODEC_24KHZ,
+        precision: Optional[str] = None,
     ):
         """`state_dict`: an HF-format EncodecModel state dict (keys of SURVEY.md Appendix A.3, e.g.
         `safetensors.torch.load_file(model.safetensors)` of facebook/encodec_24khz, or
         `checkpoint.synthetic_state_dict(cfg, seed)`).  When omitted the pretrained checkpoint is
-        fetched through huggingface_hub like the reference does (needs network or a warm cache)."""
+        fetched through huggingface_hub like the reference does (needs network or a warm cache).
+        `precision`: None / "fp32" = fp32 fidelity (the parity arithmetic, default); "fp32_exact" = exact fp32 products;
+        "bf16" = OPT-IN reduced precision for the tap-GEMMs (include/audiocodecs_amd.h ac_set_precision) -- not a parity mode."""
         super().__init__(sample_rate, orig_sample_rate, mode)
+        self.precision = _native.check_precision(precision)
         if use_vocos:
             raise NotImplementedError("the Vocos decoder variant (encodec.py:53-66) is outside the MI355X path")
         if config.sampling_rate != orig_sample_rate:
@@ -142,7 +147,7 @@ class Encodec(Codec):
             )
         idx = t.device.index
         if idx not in self._natives:
-            self._natives[idx] = _Native(self.config, self._folded, t.device)
+            self._natives[idx] = _Native(self.config, self._folded, t.device, self.precision)
         return self._natives[idx]
 
     def _num_quantizers(self) -> int:

@@ -24,7 +24,7 @@ __all__ = ["Mimi"]
 class _NativeMimi:
     """One Mimi ac_handle: weights on one GPU + a grow-only workspace tensor."""
 
-    def __init__(self, cfg: MimiConfig, sd: Dict[str, torch.Tensor], device: torch.device):
+    def __init__(self, cfg: MimiConfig, sd: Dict[str, torch.Tensor], device: torch.device, precision=None):
         self.lib = _native.lib()
         c = _native.AcMimiConfig()
         c.struct_size = C.sizeof(_native.AcMimiConfig)
@@ -43,6 +43,7 @@ class _NativeMimi:
         rc = self.lib.ac_mimi_create(C.byref(c), C.byref(self.h))
         if rc < 0:
             raise _native.NativeError(f"ac_mimi_create failed with code {rc} (is a gfx950 GPU visible?)")
+        _native.set_precision(self.lib, self.h, precision)
         for name, t in sd.items():
             if not t.is_floating_point() or name.endswith(".initialized"):
                 continue
@@ -87,6 +88,7 @@ class Mimi(Codec):
         *,
         state_dict: Optional[Dict[str, torch.Tensor]] = None,
         config: MimiConfig = MIMI_24KHZ,
+        precision: Optional[str] = None,
     ):
         """`state_dict`: an HF-format MimiModel state dict (`safetensors.torch.load_file` of kyutai/mimi's
         model.safetensors, or `checkpoint.synthetic_mimi_state_dict(cfg, seed)`); fetched through
@@ -96,6 +98,7 @@ class Mimi(Codec):
         self.vocab_size = config.codebook_size  # 2048 (mimi.py:40)
         self.latent = latent
         self.config = config
+        self.precision = _native.check_precision(precision)   # see Encodec: None / "fp32" (parity arithmetic), "fp32_exact", "bf16" (opt-in)
         if state_dict is None:
             state_dict = self._fetch_pretrained()
         self._sd = {k: v for k, v in state_dict.items()}
@@ -119,7 +122,7 @@ class Mimi(Codec):
             )
         idx = t.device.index
         if idx not in self._natives:
-            self._natives[idx] = _NativeMimi(self.config, self._sd, t.device)
+            self._natives[idx] = _NativeMimi(self.config, self._sd, t.device, self.precision)
         return self._natives[idx]
 
     def _any_native(self) -> _NativeMimi:

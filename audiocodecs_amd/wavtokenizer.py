@@ -28,7 +28,7 @@ __all__ = ["WavTokenizer"]
 class _NativeWavTok:
     """One WavTokenizer ac_handle: weights on one GPU + a grow-only workspace tensor."""
 
-    def __init__(self, cfg: WavTokenizerConfig, sd: Dict[str, torch.Tensor], device: torch.device):
+    def __init__(self, cfg: WavTokenizerConfig, sd: Dict[str, torch.Tensor], device: torch.device, precision=None):
         self.lib = _native.lib()
         c = _native.AcWavtokConfig()
         c.struct_size = C.sizeof(_native.AcWavtokConfig)
@@ -45,6 +45,7 @@ class _NativeWavTok:
         rc = self.lib.ac_wavtok_create(C.byref(c), C.byref(self.h))
         if rc < 0:
             raise _native.NativeError(f"ac_wavtok_create failed with code {rc} (unsupported configuration, or no gfx950 GPU visible)")
+        _native.set_precision(self.lib, self.h, precision)
         for name, t in sd.items():
             if not torch.is_tensor(t) or not t.is_floating_point():
                 continue
@@ -102,6 +103,7 @@ class WavTokenizer(Codec):
         *,
         state_dict: Optional[Dict[str, torch.Tensor]] = None,
         arch: Optional[WavTokenizerConfig] = None,
+        precision: Optional[str] = None,
     ):
         """`state_dict`: the `state_dict` of the upstream Lightning checkpoint (keys feature_extractor.* / backbone.* /
         head.*), or `checkpoint.synthetic_wavtok_state_dict(arch, seed)`; when omitted it is fetched through
@@ -113,6 +115,7 @@ class WavTokenizer(Codec):
         self.num_codebooks = 1
         self.vocab_size = arch.codebook_size  # 4096 (wavtokenizer.py:70)
         self.arch = arch
+        self.precision = _native.check_precision(precision)   # see Encodec: None / "fp32" (parity arithmetic), "fp32_exact", "bf16" (opt-in)
         if state_dict is None:
             state_dict = self._fetch_pretrained(source, checkpoint)
         sd = {k: v for k, v in state_dict.items() if not k.startswith("feature_extractor.encodec.decoder.")}  # never used for inference
@@ -143,7 +146,7 @@ class WavTokenizer(Codec):
             )
         idx = t.device.index
         if idx not in self._natives:
-            self._natives[idx] = _NativeWavTok(self.arch, self._sd, t.device)
+            self._natives[idx] = _NativeWavTok(self.arch, self._sd, t.device, self.precision)
         return self._natives[idx]
 
     def _any_native(self) -> _NativeWavTok:

@@ -185,6 +185,9 @@ def main():
                     help="encodec = BASELINE.json configs[1] (the contract's default); mimi = configs[3] shape (SURVEY.md §8 f3); "
                          "dac = configs[2] (DAC 44.1 kHz, 9 codebooks; use --batch 256); wavtokenizer = configs[4] (40 tok/s, 64 clips per GPU)")
     ap.add_argument("--seconds", type=float, default=10.0)
+    ap.add_argument("--precision", choices=["fp32", "fp32_exact", "bf16"], default=None,
+                    help="arithmetic of the GEMM-shaped kernels: default = fp32 fidelity (split-operand; the parity arithmetic, what `value` is "
+                         "quoted for); bf16 = OPT-IN reduced precision, a reported side mode with its own parity figures")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -213,16 +216,16 @@ def main():
     B, T = args.batch, int(round(args.seconds * cfg.sampling_rate))
     if args.codec == "mimi":
         sd = checkpoint.synthetic_mimi_state_dict(cfg, seed=0)
-        codec = Mimi(cfg.sampling_rate, num_codebooks=8, state_dict=sd).eval()
+        codec = Mimi(cfg.sampling_rate, num_codebooks=8, state_dict=sd, precision=args.precision).eval()
     elif args.codec == "dac":
         sd = checkpoint.synthetic_dac_state_dict(cfg, seed=0)
-        codec = DAC(cfg.sampling_rate, cfg.sampling_rate, num_codebooks=9, state_dict=sd, config=cfg).eval()
+        codec = DAC(cfg.sampling_rate, cfg.sampling_rate, num_codebooks=9, state_dict=sd, config=cfg, precision=args.precision).eval()
     elif args.codec == "wavtokenizer":
         sd = checkpoint.synthetic_wavtok_state_dict(cfg, seed=0)
-        codec = WavTokenizer(cfg.sampling_rate, state_dict=sd, arch=cfg).eval()
+        codec = WavTokenizer(cfg.sampling_rate, state_dict=sd, arch=cfg, precision=args.precision).eval()
     else:
         sd = checkpoint.synthetic_state_dict(cfg, seed=0)
-        codec = Encodec(cfg.sampling_rate, num_codebooks=8, state_dict=sd).eval()
+        codec = Encodec(cfg.sampling_rate, num_codebooks=8, state_dict=sd, precision=args.precision).eval()
     # sig = 0.1*N(0,1), repo PRNG seed 123; each rank draws its own shard
     sig_cpu = torch.from_numpy((prng.normal(123, f"bench.sig.rank{rank}", (B, T)) * 0.1).astype(np.float32))
     sig = sig_cpu.cuda()
@@ -260,13 +263,17 @@ def main():
         dt, dt_plain = tt.tolist()
 
     audio_s = world * B * T / cfg.sampling_rate * args.steps
+    mode_ = args.precision or {"fp32": "fp32_exact", "bf16": "bf16"}.get(os.environ.get("AC_GEMM", ""), "fp32")
     if rank == 0:
         ms = dt / args.steps * 1e3
         stats.sort(key=lambda s: -s[2])
         name, launches, tot_ms, flops, nbytes = stats[0]
         avg_us = tot_ms / launches * 1e3
         ai = flops / max(nbytes, 1.0)
-        if name.startswith("tap_gemm6"):
+        if name.startswith("tap_gemm6") and mode_ == "bf16":
+            tf = flops / (tot_ms * 1e-3) / 1e12
+            roof = {"bound": "mfma", "achieved": round(tf, 1), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "pipe": "bf16 MFMA, one product per operand pair"}
+        elif name.startswith("tap_gemm6"):
             # split-operand GEMM (tap_gemm6.h): every fp32 product is 6 bf16 MFMA partial products, so the kernel's
             # roofline is the dense bf16 MFMA peak; `achieved` counts the bf16 flops it actually executes
             eq = flops / (tot_ms * 1e-3) / 1e12
@@ -303,7 +310,8 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32" if os.environ.get("AC_GEMM") == "fp32" else "f32 (GEMMs and LSTM products: operands split exactly into 3 bf16 terms, 6 partial products, fp32 accumulate)",
+            "dtype": {"fp32_exact": "f32", "bf16": "bf16 operands / f32 accumulate in the tap-GEMMs (OPT-IN side mode, not the parity arithmetic); everything else f32-faithful"}.get(
+                mode_, "f32 (GEMMs and LSTM products: operands split exactly into 3 bf16 terms, 6 partial products, fp32 accumulate)"),
             "data": f"synthetic (0.1*N(0,1) clips, seeded synthetic weights of the {label} architecture)",
             "config": {"workload": f"{label} {ncb} codebooks, encode+decode, {B} clips x {args.seconds:g} s per GPU, resident in HBM",
                        "clips_per_gpu": B, "seconds_per_clip": args.seconds, "parallelism": f"clip-sharded x{world}"},

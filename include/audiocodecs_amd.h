@@ -199,6 +199,20 @@ int ac_wavtok_create(const ac_wavtok_config* cfg, ac_handle** out);
  * buffer; computed as 1/theta^(2i/d) in fp32 when absent). */
 int ac_load_weights(ac_handle* h, const char* name, const void* host_ptr, size_t bytes);
 
+/* Arithmetic of the GEMM-shaped kernels; call before ac_finalize (weights are packed for one arithmetic).
+ *   AC_PRECISION_FP32        default: fp32 fidelity on the bf16 matrix pipe (operands split exactly into three bf16 terms,
+ *                            6 partial products, fp32 accumulate) -- the arithmetic every parity claim is made for;
+ *   AC_PRECISION_FP32_EXACT  exact fp32 products (v_mfma_f32_16x16x4_f32) everywhere; same as AC_GEMM=fp32;
+ *   AC_PRECISION_BF16        OPT-IN, not a parity mode (BASELINE.json configs[1] says "bf16"): the
+ *                            tap-GEMMs round both operands to bf16 (nearest-even) and do ONE product per pair with fp32
+ *                            accumulate; LSTM, fused residual blocks, codebook search stay fp32-faithful.  Reported with its
+ *                            own token-mismatch rate and waveform error (bench.py --precision bf16); same as AC_GEMM=bf16.
+ * Without this call the environment variable AC_GEMM (fp32 | bf16) decides, default AC_PRECISION_FP32. */
+#define AC_PRECISION_FP32 0
+#define AC_PRECISION_FP32_EXACT 1
+#define AC_PRECISION_BF16 2
+int ac_set_precision(ac_handle* h, int precision);
+
 /* Check that every tensor of the configuration arrived, fold/pack them into the kernels' layouts
  * and upload them (one device allocation owned by the handle). */
 int ac_finalize(ac_handle* h);
