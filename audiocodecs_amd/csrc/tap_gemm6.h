@@ -28,8 +28,8 @@ constexpr int T6_PITCH = 40;        // bf16 per LDS row (32 + 8): 80-byte rows k
 
 template <int WGM, int WGN, int WMT, int WN>
 struct Tap6Cfg {
-    static_assert(WGM * WGN == 4 && WGM * WMT == 4, "4 waves, 128 rows");
-    static constexpr int BM = 128, BN = 32 * WGN * WN, NT = 256;
+    static_assert((WGM * WGN == 4 || WGM * WGN == 8) && WGM * WMT == 4, "4 or 8 waves, 128 rows");
+    static constexpr int BM = 128, BN = 32 * WGN * WN, NT = 64 * WGM * WGN;
     static constexpr int MAXJ = 8;
     static constexpr int A_ROWS = BM + MAXJ - 1;
     static constexpr int A_SLOTS = (A_ROWS * (KC / 4) + NT - 1) / NT;
@@ -44,7 +44,7 @@ struct Tap6Cfg {
 // NP = 1: the opt-in bf16 mode (ac_set_precision(AC_PRECISION_BF16)): operands ROUNDED to bf16 (nearest-even), one product,
 //         fp32 accumulate; the weight image then holds round(w) in plane 0.  Never the parity path.
 template <int WGM, int WGN, int WMT, int WN, int NP = 3>
-__global__ __launch_bounds__(256, 2) void tap_gemm6_kernel(const TapGemmParams p, const __bf16* __restrict__ wp) {
+__global__ __launch_bounds__(64 * WGM * WGN, WGM* WGN == 4 ? 2 : 1) void tap_gemm6_kernel(const TapGemmParams p, const __bf16* __restrict__ wp) {
     using Cfg = Tap6Cfg<WGM, WGN, WMT, WN>;
     constexpr int BM = Cfg::BM, BN = Cfg::BN, NT = Cfg::NT, A_SLOTS = Cfg::A_SLOTS, PLANE = Cfg::PLANE;
     extern __shared__ __attribute__((aligned(16))) float smem[];

@@ -189,6 +189,7 @@ def main():
                     help="arithmetic of the GEMM-shaped kernels: default = fp32 fidelity (split-operand; the parity arithmetic, what `value` is "
                          "quoted for); bf16 = OPT-IN reduced precision, a reported side mode with its own parity figures")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the parity gates (profiling passes: keeps the kernel trace to the timed workload)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -331,7 +332,7 @@ def main():
             ],
         }
         with torch.no_grad():
-            out["parity"] = parity_gate(args.codec, codec)
+            out["parity"] = None if args.no_parity else parity_gate(args.codec, codec)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.codec, cfg, sd, sig_cpu, ncb)
         print(json.dumps(out), flush=True)
