@@ -741,10 +741,10 @@ int run_tap(ac_handle* h, hipStream_t st, TapGemmParams& p) {
         }                                                                                                   \
     } while (0)
     if (w6) {
-        p.mtiles = cdiv(p.M, 128);
 #define TAP6_CASE(WGM, WGN, WMT, WN)                                                                                    \
     do {                                                                                                                \
         using Cfg6 = Tap6Cfg<WGM, WGN, WMT, WN>;                                                                        \
+        p.mtiles = cdiv(p.M, Cfg6::BM);                                                                                 \
         p.ntiles = p.N / Cfg6::BN;                                                                                      \
         const long long blocks = (long long)p.B * p.mtiles * p.ntiles;                                                  \
         if (h->gemm_bf16) {                                                                                             \
@@ -754,7 +754,7 @@ int run_tap(ac_handle* h, hipStream_t st, TapGemmParams& p) {
             break;                                                                                                      \
         }                                                                                                               \
         if ((rc = ensure_lds(h, reinterpret_cast<const void*>(tap_gemm6_kernel<WGM, WGN, WMT, WN>), Cfg6::lds_bytes))) return rc; \
-        ProfScope ps(h, st, (std::string("tap_gemm6_kernel<" #WGM ", " #WGN ", " #WMT ", " #WN ">") + shape).c_str(), flops, bytes); \
+        ProfScope ps(h, st, (std::string("tap_gemm6_kernel<" #WGM ", " #WGN ", " #WMT ", " #WN ", 3>") + shape).c_str(), flops, bytes); \
         hipLaunchKernelGGL((tap_gemm6_kernel<WGM, WGN, WMT, WN>), dim3((unsigned)blocks), dim3(Cfg6::NT), Cfg6::lds_bytes, st, p, w6);   \
     } while (0)
         // Wave arrangement (measured, profiles/r2_tapgemm_variants.md): the weight fragments come L2 -> registers, so the CU's
@@ -762,10 +762,7 @@ int run_tap(ac_handle* h, hipStream_t st, TapGemmParams& p) {
         // the A slab in LDS) beats 2 x 2 waves of 64 x 64 (each fragment loaded twice) by 5-7 %; 4 x 1 (each fragment loaded by
         // all four waves) saturates the path (-35 %).  Long contractions also gain from 1 x 8 waves over 256 columns (the A slab
         // is loaded and split once per 256 columns); short ones lose more to the 8-wave barrier than they gain.
-        static const int v6 = std::getenv("AC_T6_VARIANT") ? std::atoi(std::getenv("AC_T6_VARIANT")) : -1;   // developer A/B switch
-        if (p.N % 256 == 0 && (v6 == 3 || (v6 < 0 && kk >= 2048))) TAP6_CASE(1, 8, 4, 1);
-        else if (p.N % 128 == 0 && v6 == 2) TAP6_CASE(4, 1, 1, 4);
-        else if (p.N % 128 == 0 && v6 == 0) TAP6_CASE(2, 2, 2, 2);
+        if (p.N % 256 == 0 && kk >= 2048) TAP6_CASE(1, 8, 4, 1);
         else if (p.N % 128 == 0) TAP6_CASE(1, 4, 4, 1);
         else if (p.N % 96 == 0) TAP6_CASE(4, 1, 1, 3);
         else TAP6_CASE(2, 2, 2, 1);

@@ -28,8 +28,8 @@ constexpr int T6_PITCH = 40;        // bf16 per LDS row (32 + 8): 80-byte rows k
 
 template <int WGM, int WGN, int WMT, int WN>
 struct Tap6Cfg {
-    static_assert((WGM * WGN == 4 || WGM * WGN == 8) && WGM * WMT == 4, "4 or 8 waves, 128 rows");
-    static constexpr int BM = 128, BN = 32 * WGN * WN, NT = 64 * WGM * WGN;
+    static_assert((WGM * WGN == 4 || WGM * WGN == 8) && (WGM * WMT == 4 || WGM * WMT == 8), "4 or 8 waves, 128 or 256 rows");
+    static constexpr int BM = 32 * WGM * WMT, BN = 32 * WGN * WN, NT = 64 * WGM * WGN;
     static constexpr int MAXJ = 8;
     static constexpr int A_ROWS = BM + MAXJ - 1;
     static constexpr int A_SLOTS = (A_ROWS * (KC / 4) + NT - 1) / NT;
