@@ -239,12 +239,12 @@ __global__ __launch_bounds__(256) void attn1_kernel(const Attn1Params p) {
 // ---------------------------------------------------------------------------------------------
 // ConvNeXt front half: y[t][c] = LN_c( bias[c] + sum_j w[c][j] * x[t - 3 + j][c] ) * scale[c] + shift[c]   (zero padding,
 // layer_norm without affine, eps; scale/shift = row `cond` of the AdaLayerNorm embeddings).  One wavefront per frame, a
-// lane owns channels lane + 64 i; two-pass moments.  HBM-bound: 8*C bytes per frame (the 7 taps of neighbouring frames
+// lane owns the 16-byte channel vectors lane + 64 i (weights tap-major so that they vectorise too); two-pass moments.  HBM-bound: 8*C bytes per frame (the 7 taps of neighbouring frames
 // come from L2).  Taps accumulate in ascending order from the bias.
 // ---------------------------------------------------------------------------------------------
 struct DwLnParams {
     const float* x;      // [B][N][C]
-    const float* w;      // [C][7]
+    const float* w;      // [7][C]  (tap-major: re-packed from the checkpoint's [C][1][7])
     const float* bias;   // [C]
     const float* scale;  // [C]
     const float* shift;  // [C]
@@ -253,7 +253,7 @@ struct DwLnParams {
     float eps;
 };
 
-constexpr int DWLN_MAXV = 16;   // C <= 1024
+constexpr int DWLN_MAXV = 4;    // 16-byte vectors per lane: C <= 1024, C % 4 == 0
 
 __global__ __launch_bounds__(256) void dwconv_ln_kernel(const DwLnParams p) {
     const int lane = threadIdx.x & 63;
@@ -261,21 +261,27 @@ __global__ __launch_bounds__(256) void dwconv_ln_kernel(const DwLnParams p) {
     if (row >= (long long)p.B * p.N) return;
     const int t = (int)(row % p.N);
     const float* xc = p.x + (row - t) * p.C;     // the clip's first frame
-    float v[DWLN_MAXV];
+    const int cv = p.C / 4;                      // vectors per row; lane owns vectors lane + 64 i
+    f32x4 v[DWLN_MAXV];
     float sum = 0.f;
 #pragma unroll
     for (int i = 0; i < DWLN_MAXV; ++i) {
-        const int c = lane + 64 * i;
-        v[i] = 0.f;
-        if (c < p.C) {
-            float acc = p.bias[c];
+        const int q = lane + 64 * i;
+        v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (q < cv) {
+            f32x4 acc = *reinterpret_cast<const f32x4*>(p.bias + 4 * q);
 #pragma unroll
             for (int j = 0; j < 7; ++j) {
                 const int tj = t - 3 + j;
-                if (tj >= 0 && tj < p.N) acc = fmaf(p.w[c * 7 + j], xc[(long long)tj * p.C + c], acc);
+                if (tj >= 0 && tj < p.N) {
+                    const f32x4 xv = *reinterpret_cast<const f32x4*>(xc + (long long)tj * p.C + 4 * q);
+                    const f32x4 wv = *reinterpret_cast<const f32x4*>(p.w + (long long)j * p.C + 4 * q);
+                    acc.x = fmaf(wv.x, xv.x, acc.x); acc.y = fmaf(wv.y, xv.y, acc.y);
+                    acc.z = fmaf(wv.z, xv.z, acc.z); acc.w = fmaf(wv.w, xv.w, acc.w);
+                }
             }
             v[i] = acc;
-            sum += acc;
+            sum += (acc.x + acc.y) + (acc.z + acc.w);
         }
     }
 #pragma unroll
@@ -284,9 +290,10 @@ __global__ __launch_bounds__(256) void dwconv_ln_kernel(const DwLnParams p) {
     float sq = 0.f;
 #pragma unroll
     for (int i = 0; i < DWLN_MAXV; ++i) {
-        const int c = lane + 64 * i;
-        const float d = c < p.C ? v[i] - mean : 0.f;
-        sq = fmaf(d, d, sq);
+        if (lane + 64 * i < cv) {
+            const f32x4 d = f32x4{v[i].x - mean, v[i].y - mean, v[i].z - mean, v[i].w - mean};
+            sq = fmaf(d.x, d.x, sq); sq = fmaf(d.y, d.y, sq); sq = fmaf(d.z, d.z, sq); sq = fmaf(d.w, d.w, sq);
+        }
     }
 #pragma unroll
     for (int sh = 1; sh < 64; sh <<= 1) sq += __shfl_xor(sq, sh);
@@ -294,8 +301,12 @@ __global__ __launch_bounds__(256) void dwconv_ln_kernel(const DwLnParams p) {
     float* yr = p.y + row * p.C;
 #pragma unroll
     for (int i = 0; i < DWLN_MAXV; ++i) {
-        const int c = lane + 64 * i;
-        if (c < p.C) yr[c] = (v[i] - mean) * rstd * p.scale[c] + p.shift[c];
+        const int q = lane + 64 * i;
+        if (q < cv) {
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + 4 * q), sh = *reinterpret_cast<const f32x4*>(p.shift + 4 * q);
+            *reinterpret_cast<f32x4*>(yr + 4 * q) = f32x4{(v[i].x - mean) * rstd * sc.x + sh.x, (v[i].y - mean) * rstd * sc.y + sh.y,
+                                                           (v[i].z - mean) * rstd * sc.z + sh.z, (v[i].w - mean) * rstd * sc.w + sh.w};
+        }
     }
 }
 

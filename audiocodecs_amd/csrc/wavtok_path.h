@@ -109,6 +109,12 @@ int wavtok_finalize(ac_handle* h, Packer& pk) {
         const std::string p = "backbone.convnext." + std::to_string(l);
         WtCnxPlan& L = m.cnx[l];
         ok = ok && wt_vec(pk, p + ".dwconv.weight", (size_t)C * 7, L.dww) && wt_vec(pk, p + ".dwconv.bias", C, L.dwb);
+        if (ok) {   // [C][7] -> tap-major [7][C]
+            std::vector<float> wt((size_t)7 * C);
+            for (int ch = 0; ch < C; ++ch)
+                for (int j = 0; j < 7; ++j) wt[(size_t)j * C + ch] = pk.blob[L.dww + (size_t)ch * 7 + j];
+            std::copy(wt.begin(), wt.end(), pk.blob.begin() + L.dww);
+        }
         ok = ok && wt_vec(pk, p + ".norm.scale.weight", C, L.sc, c.bandwidth_id) && wt_vec(pk, p + ".norm.shift.weight", C, L.sh, c.bandwidth_id);
         ok = ok && pk.conv(ConvSpec{p + ".pwconv1", 0, C, I, 1, 1}, L.p1);
         ok = ok && pk.conv(ConvSpec{p + ".pwconv2", 0, I, C, 1, 1}, L.p2);

@@ -200,7 +200,9 @@ def main():
             raise SystemExit("launch with torch.distributed.run for --gpus > 1")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    # under torch.distributed.run (RANK in the environment) the collective path runs even at world size 1, so that a 1-GPU
+    # box can exercise exactly what the N > 1 launches do (RCCL init, barrier, token all_gather, MAX-reduce of the timings)
+    if world > 1 or (os.environ.get("RANK") is not None and os.environ.get("MASTER_PORT") is not None):
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -234,7 +236,7 @@ def main():
     def step():
         toks = codec.sig_to_toks(sig)
         if dist is not None:
-            gather_tokens(toks)
+            gather_tokens(toks, force=True)
         return codec.toks_to_sig(toks)
 
     def fence():
