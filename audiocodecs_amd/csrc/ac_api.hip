@@ -757,12 +757,24 @@ int run_tap(ac_handle* h, hipStream_t st, TapGemmParams& p) {
         ProfScope ps(h, st, (std::string("tap_gemm6_kernel<" #WGM ", " #WGN ", " #WMT ", " #WN ", 3>") + shape).c_str(), flops, bytes); \
         hipLaunchKernelGGL((tap_gemm6_kernel<WGM, WGN, WMT, WN>), dim3((unsigned)blocks), dim3(Cfg6::NT), Cfg6::lds_bytes, st, p, w6);   \
     } while (0)
-        // Wave arrangement (measured, profiles/r2_tapgemm_variants.md): the weight fragments come L2 -> registers, so the CU's
-        // load path is what the arrangement must spare: 1 x 4 waves of 128 x 32 (every wave loads DISTINCT fragments, all share
-        // the A slab in LDS) beats 2 x 2 waves of 64 x 64 (each fragment loaded twice) by 5-7 %; 4 x 1 (each fragment loaded by
-        // all four waves) saturates the path (-35 %).  Long contractions also gain from 1 x 8 waves over 256 columns (the A slab
-        // is loaded and split once per 256 columns); short ones lose more to the 8-wave barrier than they gain.
-        if (p.N % 256 == 0 && kk >= 2048) TAP6_CASE(1, 8, 4, 1);
+        // Tile / wave arrangement (measured, profiles/r2_tapgemm_variants.md).  The weight fragments come L2 -> registers and the
+        // activation slab is shared through LDS, so the CU's vector-memory path and the LDS pipe are what an arrangement must
+        // spare:  1 x 4 waves of 128 x 32 (distinct weight fragments per wave) beats 2 x 2 waves of 64 x 64 by 5-7 %;
+        // 1 x 4 waves of 128 x 64 over 256 columns (half the A-slab reads, loads and splits per MFMA; lean main loop) gains
+        // another 8-10 % where the launch still fills the chip evenly; 1 x 8 waves over 256 columns (one workgroup per CU)
+        // wins for long contractions.  Choice by a small cost model: rate of the arrangement x how evenly its workgroups
+        // fill the 256 CUs (waves of workgroups / ceil(waves)).
+        int pick = 0;   // 0: 128 columns, 1: 256 columns lean, 2: 256 columns 1 x 8
+        if (p.N % 256 == 0) {
+            const double wg256 = (double)p.B * cdiv(p.M, 128) * (p.N / 256);
+            auto fill = [](double wgs, double slots) { const double w = wgs / slots; return w / std::ceil(w); };
+            const double s128 = 1.00 * fill(2.0 * wg256, 512.0);
+            const double s256 = 1.10 * fill(wg256, 512.0);
+            const double s8 = (kk >= 2048 ? 1.12 : 0.95) * fill(wg256, 256.0);
+            pick = s256 >= s128 && s256 >= s8 ? 1 : (s8 > s128 ? 2 : 0);
+        }
+        if (pick == 1) TAP6_CASE(1, 4, 4, 2);
+        else if (pick == 2) TAP6_CASE(1, 8, 4, 1);
         else if (p.N % 128 == 0) TAP6_CASE(1, 4, 4, 1);
         else if (p.N % 96 == 0) TAP6_CASE(4, 1, 1, 3);
         else TAP6_CASE(2, 2, 2, 1);

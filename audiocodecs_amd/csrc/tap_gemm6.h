@@ -34,7 +34,7 @@ struct Tap6Cfg {
     static constexpr int A_ROWS = BM + MAXJ - 1;
     static constexpr int A_SLOTS = (A_ROWS * (KC / 4) + NT - 1) / NT;
     static constexpr int PLANE = A_ROWS * T6_PITCH;                 // bf16 elements per plane
-    static constexpr int CP = BN + 4;
+    static constexpr int CP = 32 * WGN + 4;      // epilogue staging: one wave column tile per pass
     static constexpr size_t main_bytes = (size_t)2 * 3 * PLANE * 2;
     static constexpr size_t epi_bytes = (size_t)BM * CP * 4;
     static constexpr size_t lds_bytes = main_bytes > epi_bytes ? main_bytes : epi_bytes;
@@ -224,6 +224,10 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM* WGN == 4 ? 2 : 1) void tap_gem
                 acc[a][c] = v;
             }
     };
+    // LEAN (wave tile of 8 accumulator tiles, 128 x 64): 128 accumulator registers leave room for ONE fragment set and TWO
+    // weight sets only -- a weight set is reloaded right after the k-step that used it (one k-step ahead of its next use), the
+    // A fragments of a k-step are read just before its MFMAs (the co-resident workgroup covers the LDS latency).
+    constexpr bool LEAN = WMT * WN >= 8;
     // one stage; returns true when it was the last one
     auto stage = [&](bf16x8 (&u0)[3][WN], bf16x8 (&u1)[3][WN], bf16x8 (&sp)[3][WN]) -> bool {
         int nsi = si, nc0 = c0, nj = j + 1;
@@ -241,16 +245,26 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM* WGN == 4 ? 2 : 1) void tap_gem
             if (nsi != si) enter_segment(nsi);
             new_chunk = new_chunk || seg_reload;
             s_next = (seg_kofs + nj * seg_Cw + nc0) >> 4;      // first k-step of the next stage in the packed weight rows
-            load_b(s_next, sp);
+            if (!LEAN) load_b(s_next, sp);
             if (new_chunk) load_a(nsi, nc0, nj);
         }
         const __bf16* Ac = As0 + abuf * 3 * PLANE + a_frag + cur_j * T6_PITCH;
-        bf16x8 af0[3][WMT], af1[3][WMT];
-        read_a(Ac, 0, af0);
-        read_a(Ac, 1, af1);                                    // the second k-step's fragments travel under the first one's MFMAs
-        mfma_step(af0, u0);
-        if (has_next) load_b(s_next + 1, u0);
-        mfma_step(af1, u1);
+        if constexpr (LEAN) {
+            bf16x8 af[3][WMT];
+            read_a(Ac, 0, af);
+            mfma_step(af, u0);
+            if (has_next) load_b(s_next, u0);
+            read_a(Ac, 1, af);
+            mfma_step(af, u1);
+            if (has_next) load_b(s_next + 1, u1);
+        } else {
+            bf16x8 af0[3][WMT], af1[3][WMT];
+            read_a(Ac, 0, af0);
+            read_a(Ac, 1, af1);                                // the second k-step's fragments travel under the first one's MFMAs
+            mfma_step(af0, u0);
+            if (has_next) load_b(s_next + 1, u0);
+            mfma_step(af1, u1);
+        }
         if (!has_next) return true;
         if (new_chunk) {                                       // the A loads had the whole stage to arrive
             abuf ^= 1;
@@ -260,58 +274,66 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM* WGN == 4 ? 2 : 1) void tap_gem
         si = nsi; c0 = nc0; j = nj;
         return false;
     };
-    for (;;) {
-        if (stage(bx, by, bz)) break;
-        if (stage(bz, bx, by)) break;
-        if (stage(by, bz, bx)) break;
+    if constexpr (LEAN) {
+        while (!stage(bx, by, bz)) {}
+    } else {
+        for (;;) {
+            if (stage(bx, by, bz)) break;
+            if (stage(bz, bx, by)) break;
+            if (stage(by, bz, bx)) break;
+        }
     }
 
-    // ---- epilogue through LDS (as tap_gemm4).  C layout of 32x32: column = lane & 31, row = 8*(r/4) + 4*kh + r%4
-    __syncthreads();
+    // ---- epilogue through LDS (as tap_gemm4), one chunk per wave column tile c: [BM][32 * WGN] staged at a time, so the
+    // staging tile never exceeds the main loop's LDS (a 128 x 256 tile keeps two workgroups per CU).  C layout of 32x32:
+    // column = lane & 31, row = 8*(r/4) + 4*kh + r%4.  Staging column q <-> global column n0 + (q/32)*32*WN + 32*c + q%32.
     float* Cs = smem;
-    constexpr int CP = Cfg::CP;
-#pragma unroll
-    for (int a = 0; a < WMT; ++a)
-#pragma unroll
-        for (int c = 0; c < WN; ++c) {
-            const int n = (wn * WN + c) * 32 + i32;
-            const float bv = (p.bias && n0 + n < p.N) ? p.bias[n0 + n] : 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) Cs[((wm * WMT + a) * 32 + 8 * (r / 4) + 4 * kh + (r % 4)) * CP + n] = acc[a][c][r] + bv;
-        }
-    __syncthreads();
+    constexpr int CP = Cfg::CP, CW = 32 * WGN;
     const long long yoff = (long long)b * p.y_bs;
     const bool post = p.gelu || p.scale || p.res || p.tanh_out;
-    for (int e = tid; e < BM * (BN / 4); e += NT) {
-        const int row = e / (BN / 4), q = e % (BN / 4);
-        const int m = m0 + row, n = n0 + 4 * q;
-        const long long fi = (long long)m * p.y_rs + n + p.y_off;
-        if (m < p.M && n < (p.n_valid ? p.n_valid : p.N) && (p.y_len == 0 || (fi >= 0 && fi < p.y_len))) {
-            f32x4 v = *reinterpret_cast<const f32x4*>(&Cs[row * CP + 4 * q]);
-            if (post) {
-                if (p.gelu) { v.x = gelu1(v.x); v.y = gelu1(v.y); v.z = gelu1(v.z); v.w = gelu1(v.w); }
-                if (p.scale) {
-                    const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + n);
-                    v.x = __fmul_rn(sc.x, v.x); v.y = __fmul_rn(sc.y, v.y); v.z = __fmul_rn(sc.z, v.z); v.w = __fmul_rn(sc.w, v.w);
+    const int nvalid = p.n_valid ? p.n_valid : p.N;
+#pragma unroll
+    for (int c = 0; c < WN; ++c) {
+        __syncthreads();
+#pragma unroll
+        for (int a = 0; a < WMT; ++a) {
+            const int ng = n0 + (wn * WN + c) * 32 + i32;
+            const float bv = (p.bias && ng < p.N) ? p.bias[ng] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Cs[((wm * WMT + a) * 32 + 8 * (r / 4) + 4 * kh + (r % 4)) * CP + wn * 32 + i32] = acc[a][c][r] + bv;
+        }
+        __syncthreads();
+        for (int e = tid; e < BM * (CW / 4); e += NT) {
+            const int row = e / (CW / 4), q = e % (CW / 4);
+            const int m = m0 + row, n = n0 + (q / 8) * (32 * WN) + 32 * c + 4 * (q % 8);
+            const long long fi = (long long)m * p.y_rs + n + p.y_off;
+            if (m < p.M && n < nvalid && (p.y_len == 0 || (fi >= 0 && fi < p.y_len))) {
+                f32x4 v = *reinterpret_cast<const f32x4*>(&Cs[row * CP + 4 * q]);
+                if (post) {
+                    if (p.gelu) { v.x = gelu1(v.x); v.y = gelu1(v.y); v.z = gelu1(v.z); v.w = gelu1(v.w); }
+                    if (p.scale) {
+                        const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + n);
+                        v.x = __fmul_rn(sc.x, v.x); v.y = __fmul_rn(sc.y, v.y); v.z = __fmul_rn(sc.z, v.z); v.w = __fmul_rn(sc.w, v.w);
+                    }
+                    if (p.res) {
+                        const f32x4 rv = *reinterpret_cast<const f32x4*>(p.res + (long long)b * p.res_bs + (long long)m * p.res_rs + n);
+                        v.x = __fadd_rn(rv.x, v.x); v.y = __fadd_rn(rv.y, v.y); v.z = __fadd_rn(rv.z, v.z); v.w = __fadd_rn(rv.w, v.w);
+                    }
+                    if (p.tanh_out) { v.x = tanhf(v.x); v.y = tanhf(v.y); v.z = tanhf(v.z); v.w = tanhf(v.w); }
                 }
-                if (p.res) {
-                    const f32x4 rv = *reinterpret_cast<const f32x4*>(p.res + (long long)b * p.res_bs + (long long)m * p.res_rs + n);
-                    v.x = __fadd_rn(rv.x, v.x); v.y = __fadd_rn(rv.y, v.y); v.z = __fadd_rn(rv.z, v.z); v.w = __fadd_rn(rv.w, v.w);
+                const long long o = yoff + fi;
+                if (p.y) *reinterpret_cast<f32x4*>(p.y + o) = v;
+                if (p.y_elu) {
+                    f32x4 w;
+                    if (p.alpha) {
+                        const int ca = n % p.alpha_n;
+                        const f32x4 al = *reinterpret_cast<const f32x4*>(p.alpha + ca), ai = *reinterpret_cast<const f32x4*>(p.alpha_inv + ca);
+                        w.x = snake1(v.x, al.x, ai.x); w.y = snake1(v.y, al.y, ai.y); w.z = snake1(v.z, al.z, ai.z); w.w = snake1(v.w, al.w, ai.w);
+                    } else {
+                        w = elu4(v);
+                    }
+                    *reinterpret_cast<f32x4*>(p.y_elu + o) = w;
                 }
-                if (p.tanh_out) { v.x = tanhf(v.x); v.y = tanhf(v.y); v.z = tanhf(v.z); v.w = tanhf(v.w); }
-            }
-            const long long o = yoff + fi;
-            if (p.y) *reinterpret_cast<f32x4*>(p.y + o) = v;
-            if (p.y_elu) {
-                f32x4 w;
-                if (p.alpha) {
-                    const int c = n % p.alpha_n;
-                    const f32x4 al = *reinterpret_cast<const f32x4*>(p.alpha + c), ai = *reinterpret_cast<const f32x4*>(p.alpha_inv + c);
-                    w.x = snake1(v.x, al.x, ai.x); w.y = snake1(v.y, al.y, ai.y); w.z = snake1(v.z, al.z, ai.z); w.w = snake1(v.w, al.w, ai.w);
-                } else {
-                    w = elu4(v);
-                }
-                *reinterpret_cast<f32x4*>(p.y_elu + o) = w;
             }
         }
     }

@@ -270,14 +270,27 @@ def main():
     if rank == 0:
         ms = dt / args.steps * 1e3
         stats.sort(key=lambda s: -s[2])
-        name, launches, tot_ms, flops, nbytes = stats[0]
+        # The dominant kernel.  tap_gemm6_kernel is ONE kernel template launched in several tile arrangements (1 x 4 waves
+        # over 128 or 256 columns, 1 x 8 waves, ...; rocprof lists each instantiation on its own row): the arrangements are
+        # taken together when ranking, and listed one by one (with their own average launch time, the figure to compare
+        # with rocprofv3's rows) under roofline.arrangements.
+        fam = {}
+        for s_ in stats:
+            f_ = s_[0].split("<")[0] if s_[0].startswith("tap_gemm6") else s_[0]
+            a_ = fam.setdefault(f_, [f_, 0, 0.0, 0.0, 0.0, []])
+            a_[1] += s_[1]; a_[2] += s_[2]; a_[3] += s_[3]; a_[4] += s_[4]; a_[5].append(s_)
+        top = max(fam.values(), key=lambda a_: a_[2])
+        name, launches, tot_ms, flops, nbytes, members = top
+        if len(members) == 1:
+            name = members[0][0]
         avg_us = tot_ms / launches * 1e3
         ai = flops / max(nbytes, 1.0)
+        split_kernel = name.startswith(("tap_gemm6", "lstm_persist6", "rb_fused6", "rb128_fused6", "thin_conv6"))
         if name.startswith("tap_gemm6") and mode_ == "bf16":
             tf = flops / (tot_ms * 1e-3) / 1e12
             roof = {"bound": "mfma", "achieved": round(tf, 1), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "pipe": "bf16 MFMA, one product per operand pair"}
-        elif name.startswith("tap_gemm6"):
-            # split-operand GEMM (tap_gemm6.h): every fp32 product is 6 bf16 MFMA partial products, so the kernel's
+        elif split_kernel:
+            # split-operand kernels (tap_gemm6.h arithmetic): every fp32 product is 6 bf16 MFMA partial products, so the kernel's
             # roofline is the dense bf16 MFMA peak; `achieved` counts the bf16 flops it actually executes
             eq = flops / (tot_ms * 1e-3) / 1e12
             roof = {"bound": "mfma", "achieved": round(SPLIT_TERMS * eq, 1), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
@@ -288,7 +301,17 @@ def main():
         else:
             roof = {"bound": "hbm", "achieved": round(nbytes / (tot_ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s"}
         roof["frac"] = round(roof["achieved"] / roof["peak"], 4)
-        tr = measured_traffic(name, roof["unit"], args.codec, B)
+        if len(members) > 1:
+            trs = [(m_[1], measured_traffic(m_[0], roof["unit"], args.codec, B)) for m_ in members]
+            tr = None
+            if all(t_ for _, t_ in trs):
+                tr = (round(sum(n_ * t_[0] for n_, t_ in trs) / sum(n_ for n_, _ in trs)), trs[0][1][1])
+            roof["arrangements"] = [{"kernel": m_[0], "launches_per_step": m_[1] / args.steps, "avg_launch_us": round(m_[2] / m_[1] * 1e3, 2),
+                                     "fp32_equivalent_tflops": round(m_[3] / (m_[2] * 1e-3) / 1e12, 2)} for m_ in members]
+        else:
+            tr = measured_traffic(name, roof["unit"], args.codec, B)
+        if name.startswith("lstm_persist"):
+            roof["note"] = "sequential recurrence: latency-bound (one exchange of h per time step), not a throughput kernel"
         roof["traffic"] = tr[0] if tr else None
         # PMC counters cannot be collected from inside this process: the figure is the one of the committed rocprofv3
         # --pmc passes over this same command (a different run / box); null when no such summary knows the kernel
@@ -298,7 +321,7 @@ def main():
         roof["algorithmic_bytes_per_launch"] = round(nbytes / launches)
         roof["hbm_gbs"] = round(nbytes / (tot_ms * 1e-3) / 1e9, 1)
         roof["hbm_frac"] = round(nbytes / (tot_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)
-        roof["kernel"] = name
+        roof["kernel"] = name if len(members) == 1 else f"{name}<...> ({len(members)} tile arrangements of one kernel)"
         roof["launches_per_step"] = launches / args.steps
         roof["avg_launch_us"] = round(avg_us, 2)
         roof["share_of_step"] = round(tot_ms / (dt * 1e3), 4)
