@@ -776,6 +776,7 @@ int run_tap(ac_handle* h, hipStream_t st, TapGemmParams& p) {
         if (pick == 1) TAP6_CASE(1, 4, 4, 2);
         else if (pick == 2) TAP6_CASE(1, 8, 4, 1);
         else if (p.N % 128 == 0) TAP6_CASE(1, 4, 4, 1);
+        else if (p.N % 192 == 0) TAP6_CASE(2, 2, 2, 3);   // DAC's 192-wide layers: a weight fragment is loaded by two waves, not four
         else if (p.N % 96 == 0) TAP6_CASE(4, 1, 1, 3);
         else TAP6_CASE(2, 2, 2, 1);
 #undef TAP6_CASE

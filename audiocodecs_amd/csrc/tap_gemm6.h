@@ -224,10 +224,10 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM* WGN == 4 ? 2 : 1) void tap_gem
                 acc[a][c] = v;
             }
     };
-    // LEAN (wave tile of 8 accumulator tiles, 128 x 64): 128 accumulator registers leave room for ONE fragment set and TWO
+    // LEAN (wave tile of 6-8 accumulator tiles: 128 x 64, 64 x 96): 96-128 accumulator registers leave room for ONE fragment set and TWO
     // weight sets only -- a weight set is reloaded right after the k-step that used it (one k-step ahead of its next use), the
     // A fragments of a k-step are read just before its MFMAs (the co-resident workgroup covers the LDS latency).
-    constexpr bool LEAN = WMT * WN >= 8;
+    constexpr bool LEAN = WMT * WN >= 6;
     // one stage; returns true when it was the last one
     auto stage = [&](bf16x8 (&u0)[3][WN], bf16x8 (&u1)[3][WN], bf16x8 (&sp)[3][WN]) -> bool {
         int nsi = si, nc0 = c0, nj = j + 1;
