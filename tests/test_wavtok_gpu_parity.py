@@ -227,3 +227,23 @@ def test_modes_and_errors(wavtok_checkpoints):
     c16 = WavTokenizer(16000, state_dict=sd, arch=cfg).eval()
     rec = c16(noise(78, 1, 3200).cuda())
     assert rec.shape == (1, 3200)
+
+
+def test_batches_beyond_one_lstm_launch_and_nan_clip(codecs):
+    """More than 64 clips: the persistent LSTM runs once per 64-clip chunk; clips are independent units, so any split of the
+    batch gives the same ids and samples.  A clip with a NaN sample does not disturb the others (lstm_tail_kernel)."""
+    codec = codecs("full", 0)
+    sig = noise(4400, 70, 9000).cuda()
+    toks = codec.sig_to_toks(sig)
+    parts = torch.cat([codec.sig_to_toks(sig[i : i + 16]) for i in range(0, 70, 16)])
+    assert torch.equal(toks, parts)
+    rec = codec.toks_to_sig(toks)
+    recp = torch.cat([codec.toks_to_sig(toks[i : i + 16]) for i in range(0, 70, 16)])
+    assert torch.equal(rec, recp)
+    bad = sig[:4].clone()
+    bad[1, 4000] = float("nan")
+    tb = codec.sig_to_toks(bad)
+    for b in (0, 2, 3):
+        assert torch.equal(tb[b], toks[b])
+    nat = next(iter(codec._natives.values()))
+    assert nat.lib.ac_lstm_status(nat.h) == 1
