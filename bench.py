@@ -32,6 +32,9 @@ PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # same guide: dense bf16 MFMA peak (the 5 PF headline includes 2:1 sparsity)
 SPLIT_TERMS = 6                 # tap_gemm6.h: bf16 partial products executed per fp32 product
 PEAK_HBM_GBS = 8000.0          # same guide, "HBM3E peak BW" (spec; 6.29 TB/s achievable)
+# What the bf16 matrix pipe SUSTAINS on random operands: the bare v_mfma_f32_32x32x16_bf16 stream keeps the pipe 100 % busy and
+# power management drops the shader clock to 1.66-1.8 GHz (measured in-kernel, profiles/r2_tapgemm_variants.md): 1.69-1.83 PF
+SUSTAINED_BF16_MFMA_TFLOPS = 1760.0
 # algorithmic work per audio-second of encode+decode (EnCodec-24k, K=8)
 FLOP_PER_AUDIO_S = 6.12e9
 LAYER_BYTES_PER_AUDIO_S = 117.6e6
@@ -294,7 +297,8 @@ def main():
             # roofline is the dense bf16 MFMA peak; `achieved` counts the bf16 flops it actually executes
             eq = flops / (tot_ms * 1e-3) / 1e12
             roof = {"bound": "mfma", "achieved": round(SPLIT_TERMS * eq, 1), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "pipe": f"bf16 MFMA, {SPLIT_TERMS} partial products per fp32 product", "fp32_equivalent_tflops": round(eq, 2)}
+                    "pipe": f"bf16 MFMA, {SPLIT_TERMS} partial products per fp32 product", "fp32_equivalent_tflops": round(eq, 2),
+                    "power_capped_peak": SUSTAINED_BF16_MFMA_TFLOPS, "frac_of_power_capped_peak": round(SPLIT_TERMS * eq / SUSTAINED_BF16_MFMA_TFLOPS, 4)}
         elif ai > PEAK_FP32_MFMA_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9):
             roof = {"bound": "mfma", "achieved": round(flops / (tot_ms * 1e-3) / 1e12, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
                     "unit": "TFLOP/s"}

@@ -18,11 +18,14 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+__device__ unsigned long long* g_clk = nullptr;   // [blocks][2]: shader-clock ticks, 100 MHz real-time ticks per workgroup
+
 // WMT x WNT 32x32 tiles per wave; waves arranged WGM x WGN; BK = k per stage
 template <int WGM, int WGN, int WMT, int WNT, int BK, int OCC>
 __global__ __launch_bounds__(WGM* WGN * 64, OCC) void gemm7(const __bf16* __restrict__ Ap, const __bf16* __restrict__ Bf, float* __restrict__ C,
                                                                int M, int N, int K) {
 #if defined(__HIP_DEVICE_COMPILE__)
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     constexpr int NW = WGM * WGN, NT = NW * 64, BM = WGM * WMT * 32, BN = WGN * WNT * 32;
     constexpr int CH = BK / 8;                      // 16-byte chunks per row
     constexpr int ROWB = BK * 2;                    // bytes per LDS row
@@ -134,6 +137,11 @@ __global__ __launch_bounds__(WGM* WGN * 64, OCC) void gemm7(const __bf16* __rest
                 const int col = n0 + (wn * WNT + b) * 32 + i32;
                 C[(long long)row * N + col] = acc[a][b][r];
             }
+    if (g_clk && threadIdx.x == 0) {
+        const unsigned long long bid = (unsigned long long)blockIdx.y * gridDim.x + blockIdx.x;
+        g_clk[2 * bid] = __builtin_amdgcn_s_memtime() - t0;
+        g_clk[2 * bid + 1] = __builtin_amdgcn_s_memrealtime() - r0;
+    }
 #endif
 }
 
@@ -153,6 +161,17 @@ void run(const char* name, const __bf16* Ap, const __bf16* Bf, float* C, int M, 
         CK(hipEventElapsedTime(&ms, e0, e1));
     }
     CK(hipGetLastError());
+    {   // average shader clock while this kernel runs: s_memtime ticks per 100 MHz real-time tick
+        const size_t nb = (size_t)grid.x * grid.y;
+        unsigned long long* dclk; CK(hipMalloc(&dclk, nb * 16)); CK(hipMemset(dclk, 0, nb * 16));
+        CK(hipMemcpyToSymbol(HIP_SYMBOL(g_clk), &dclk, sizeof dclk));
+        hipLaunchKernelGGL((gemm7<WGM, WGN, WMT, WNT, BK, OCC>), grid, dim3(WGM * WGN * 64), lds, 0, Ap, Bf, C, M, N, K);
+        CK(hipDeviceSynchronize());
+        std::vector<unsigned long long> hc(nb * 2); CK(hipMemcpy(hc.data(), dclk, nb * 16, hipMemcpyDeviceToHost));
+        double st = 0, rt = 0; for (size_t i = 0; i < nb; ++i) { st += hc[2 * i]; rt += hc[2 * i + 1]; }
+        unsigned long long* z = nullptr; CK(hipMemcpyToSymbol(HIP_SYMBOL(g_clk), &z, sizeof z)); CK(hipFree(dclk));
+        printf("  [s_memtime / s_memrealtime = %.3f -> counter runs at %.0f MHz if real-time is 100 MHz] ", st / rt, 100.0 * st / rt);
+    }
     CK(hipMemcpy(hC.data(), C, hC.size() * 4, hipMemcpyDeviceToHost));
     double sumsq = 0, refsq = 0;
     for (int t = 0; t < 3000; ++t) {
