@@ -42,7 +42,7 @@ struct LstmPersistParams {
     int group0;            // first 16-clip group of this launch inside hseq (clip0 / 16)
     int clip0;             // first clip (for gin / skip / y rows)
     int dbg;               // developer timing modes (AC_LSTM_DBG; results invalid): 1 = layer 0 only, 2 = skip the MFMAs,
-                           // 4 = do not wait for flags
+                           // 4 = do not wait for flags; 16 = test hook: every workgroup reports a timeout and leaves
 };
 
 // control block layout (32-bit words)

@@ -396,3 +396,30 @@ def test_mode_drops_the_unused_half(checkpoints):
         enc.toks_to_sig(toks)
     with pytest.raises(NativeError, match="without encoder weights"):
         dec.sig_to_toks(sig)
+
+
+def test_failed_persistent_launch_is_reported_and_healed(checkpoints, monkeypatch):
+    """A persistent LSTM launch that fails (bounded wait expired / XCD placement broken; forced here by the kernel's test
+    hook AC_LSTM_DBG=16) must never hand back unwritten memory: the tail kernel sets the launch's outputs to NaN and raises
+    a sticky word; the NEXT call on the handle returns AC_EHIP once and the handle switches to the per-step kernels, after
+    which it produces the same tokens as a healthy handle."""
+    from audiocodecs_amd import Encodec
+    from audiocodecs_amd._native import NativeError
+
+    cfg, sd = checkpoints("full", 0)
+    good = Encodec(24000, num_codebooks=8, state_dict=sd, config=cfg).eval()
+    codec = Encodec(24000, num_codebooks=8, state_dict=sd, config=cfg).eval()
+    sig = noise(8282, 3, 16000).cuda()
+    want = good.sig_to_toks(sig)
+    monkeypatch.setenv("AC_LSTM_DBG", "16")
+    feats = codec.sig_to_feats(sig)          # the call itself cannot know: nothing synchronises
+    torch.cuda.synchronize()
+    monkeypatch.delenv("AC_LSTM_DBG")
+    assert bool(torch.isnan(feats).all())    # ... but its outputs are NaN, not garbage
+    nat = next(iter(codec._natives.values()))
+    assert nat.lib.ac_lstm_status(nat.h) < 0
+    with pytest.raises(NativeError, match="persistent LSTM launch failed"):
+        codec.sig_to_toks(sig)
+    toks = codec.sig_to_toks(sig)            # healed: per-step kernels from now on
+    assert nat.lib.ac_lstm_status(nat.h) == 0
+    assert float((toks == want).float().mean()) > 0.999   # per-step vs persistent: same function up to fp32 rounding
