@@ -2115,7 +2115,7 @@ int ac_lstm_status(ac_handle* h) {
     if (!h) return AC_EINVAL;
     if (!h->lp_ctl) return 0;
     if (hipDeviceSynchronize() != hipSuccess) return AC_EHIP;
-    const bool usable = (h->arch == ARCH_ENCODEC || h->arch == ARCH_WAVTOK) && h->enc_lstm.has_persist && h->num_cus == 256 && !h->lstm_step_only;
+    const bool usable = (h->arch == ARCH_ENCODEC || h->arch == ARCH_WAVTOK) && (h->enc_lstm.has_persist || h->dec_lstm.has_persist) && h->num_cus == 256 && !h->lstm_step_only;
     volatile unsigned* s = h->sticky;
     if (s && (s[ST_LSTM_TIMEOUT] || s[ST_LSTM_PLACEMENT]))
         return fail(h, AC_EHIP, "persistent LSTM: %u bounded waits expired, %u misplaced launches (outputs of those calls are NaN)", s[ST_LSTM_TIMEOUT], s[ST_LSTM_PLACEMENT]);
