@@ -1559,7 +1559,7 @@ int decoder_fwd(ac_handle* h, hipStream_t st, const long long* toks, int B, int 
 // ---------------------------------------------------------------------------------------------
 extern "C" {
 
-int ac_version(void) { return 200; }
+int ac_version(void) { return 300; }
 
 int ac_create(const ac_config* cfg, ac_handle** out) {
     if (!cfg || !out) return AC_EINVAL;
