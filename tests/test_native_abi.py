@@ -37,6 +37,7 @@ def test_struct_layout_matches_header():
     assert C.sizeof(native.AcKernelStat) == 96 + 4 + 4 + 8 + 8
     assert C.sizeof(native.AcMimiConfig) == 4 * (5 + 8 + 4 + 4 + 7 + 2)
     assert C.sizeof(native.AcDacConfig) == 4 * (5 + 8 + 8 + 4 + 4 + 1)
+    assert C.sizeof(native.AcWavtokConfig) == 4 * (5 + 8 + 15)
 
 
 def test_create_rejects_bad_config_without_gpu():
@@ -48,4 +49,6 @@ def test_create_rejects_bad_config_without_gpu():
     assert L.ac_create(None, C.byref(h)) == -1
     assert L.ac_mimi_create(C.byref(native.AcMimiConfig()), C.byref(h)) == -1
     assert L.ac_dac_create(C.byref(native.AcDacConfig()), C.byref(h)) == -1
+    assert L.ac_wavtok_create(C.byref(native.AcWavtokConfig()), C.byref(h)) == -1
+    assert L.ac_set_precision(None, 0) == -1
     assert L.ac_last_error(None) == b"null handle"
