@@ -37,7 +37,7 @@ def test_struct_layout_matches_header():
     assert C.sizeof(native.AcKernelStat) == 96 + 4 + 4 + 8 + 8
     assert C.sizeof(native.AcMimiConfig) == 4 * (5 + 8 + 4 + 4 + 7 + 2)
     assert C.sizeof(native.AcDacConfig) == 4 * (5 + 8 + 8 + 4 + 4 + 1)
-    assert C.sizeof(native.AcWavtokConfig) == 4 * (5 + 8 + 15)
+    assert C.sizeof(native.AcWavtokConfig) == 4 * (5 + 8 + 14)
 
 
 def test_create_rejects_bad_config_without_gpu():
