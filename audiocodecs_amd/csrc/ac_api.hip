@@ -177,6 +177,7 @@ struct ac_handle {
     int num_cus = 0;
     bool lstm_step_only = false;
     // sticky status words (lstm_persist.h ST_*): host-pinned, device-mapped -- read on the host without synchronising
+    unsigned long long* clk_dev = nullptr;   // ac_debug_clock: shader / real-time tick sums of the tap_gemm6 workgroups
     unsigned* sticky = nullptr;       // host view
     unsigned* sticky_dev = nullptr;   // device view of the same words
     // profiling
@@ -741,6 +742,7 @@ int run_tap(ac_handle* h, hipStream_t st, TapGemmParams& p) {
         }                                                                                                   \
     } while (0)
     if (w6) {
+        p.clk = h->clk_dev;
 #define TAP6_CASE(WGM, WGN, WMT, WN)                                                                                    \
     do {                                                                                                                \
         using Cfg6 = Tap6Cfg<WGM, WGN, WMT, WN>;                                                                        \
@@ -2122,6 +2124,26 @@ int ac_lstm_status(ac_handle* h) {
     return usable ? 1 : 0;
 }
 
+int ac_debug_clock(ac_handle* h, int enable, double* shader_mhz) {
+    if (!h || !h->finalized) return AC_EINVAL;
+    if (shader_mhz) *shader_mhz = 0.0;
+    if (h->clk_dev) {
+        unsigned long long v[2] = {0, 0};
+        HIPCHK(h, hipDeviceSynchronize());
+        HIPCHK(h, hipMemcpy(v, h->clk_dev, sizeof v, hipMemcpyDeviceToHost));
+        if (shader_mhz && v[1]) *shader_mhz = 100.0 * (double)v[0] / (double)v[1];
+        HIPCHK(h, hipMemset(h->clk_dev, 0, sizeof v));
+    }
+    if (enable && !h->clk_dev) {
+        HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&h->clk_dev), 16));
+        HIPCHK(h, hipMemset(h->clk_dev, 0, 16));
+    } else if (!enable && h->clk_dev) {
+        (void)hipFree(h->clk_dev);
+        h->clk_dev = nullptr;
+    }
+    return AC_OK;
+}
+
 int ac_debug_capture(ac_handle* h, float* buf_dev, size_t cap_floats) {
     if (!h) return AC_EINVAL;
     h->dbg = buf_dev;
@@ -2181,6 +2203,7 @@ void ac_destroy(ac_handle* h) {
     if (h->blob) (void)hipFree(h->blob);
     if (h->lp_ctl) (void)hipFree(h->lp_ctl);
     if (h->sticky) (void)hipHostFree(h->sticky);
+    if (h->clk_dev) (void)hipFree(h->clk_dev);
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
     delete h;
 }

@@ -79,6 +79,8 @@ struct TapGemmParams {
     int tanh_out;
     long long y_off, y_len;
     int n_valid;        // > 0: only columns n < n_valid are stored (N is padded to the tile width with zero weight rows)
+    unsigned long long* clk;   // diagnostics (ac_debug_clock): [0] += shader-clock ticks, [1] += 100 MHz real-time ticks of
+                               // every workgroup of a tap_gemm6 launch; null = off
 };
 
 enum { PAD_ZERO = 0, PAD_REFLECT = 1, PAD_REPLICATE = 2 };

@@ -47,6 +47,8 @@ template <int WGM, int WGN, int WMT, int WN, int NP = 3>
 __global__ __launch_bounds__(64 * WGM * WGN, WGM* WGN == 4 ? 2 : 1) void tap_gemm6_kernel(const TapGemmParams p, const __bf16* __restrict__ wp) {
     using Cfg = Tap6Cfg<WGM, WGN, WMT, WN>;
     constexpr int BM = Cfg::BM, BN = Cfg::BN, NT = Cfg::NT, A_SLOTS = Cfg::A_SLOTS, PLANE = Cfg::PLANE;
+    unsigned long long clk_t0 = 0, clk_r0 = 0;
+    if (p.clk) { clk_t0 = __builtin_amdgcn_s_memtime(); clk_r0 = __builtin_amdgcn_s_memrealtime(); }
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __bf16* As0 = reinterpret_cast<__bf16*>(smem);            // [2 buffers][3 planes][A_ROWS][T6_PITCH]
 
@@ -336,6 +338,10 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM* WGN == 4 ? 2 : 1) void tap_gem
                 }
             }
         }
+    }
+    if (p.clk && tid == 0) {   // shader clock while this workgroup lived: sum of ticks / sum of 100 MHz real-time ticks
+        atomicAdd(&p.clk[0], (unsigned long long)(__builtin_amdgcn_s_memtime() - clk_t0));
+        atomicAdd(&p.clk[1], (unsigned long long)(__builtin_amdgcn_s_memrealtime() - clk_r0));
     }
 }
 

@@ -361,6 +361,16 @@ def main():
             ],
         }
         with torch.no_grad():
+            try:   # shader clock under the tap-GEMMs (power cap), sampled in 2 extra steps outside the timed region
+                import ctypes as _C
+                nat = next(iter(codec._natives.values()))
+                mhz = _C.c_double(0.0)
+                nat.lib.ac_debug_clock(nat.h, 1, _C.byref(mhz))
+                step(); step()
+                nat.lib.ac_debug_clock(nat.h, 0, _C.byref(mhz))
+                out["roofline"]["tap_gemm6_shader_clock_mhz"] = round(mhz.value, 0)
+            except Exception as e:  # diagnostics only
+                out["roofline"]["tap_gemm6_shader_clock_mhz"] = None
             out["parity"] = None if args.no_parity else parity_gate(args.codec, codec)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.codec, cfg, sd, sig_cpu, ncb)

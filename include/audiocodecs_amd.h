@@ -316,6 +316,12 @@ int ac_profile_end(ac_handle* h, ac_kernel_stat* out, int cap);
 int ac_debug_capture(ac_handle* h, float* buf_dev, size_t cap_floats);
 size_t ac_debug_captured(const ac_handle* h);
 
+/* Diagnostics (SYNCHRONISES): shader clock the tap_gemm6 workgroups ran at since the last call -- every workgroup reads
+ * s_memtime (shader clock) and s_memrealtime (100 MHz) at its start and end; *shader_mhz = 100 * sum / sum (0 when nothing ran).
+ * enable != 0 arms the sampling for the following calls, 0 disarms it.  The matrix pipe on this chip is power-capped: the
+ * clock under a GEMM is the missing half of its roofline. */
+int ac_debug_clock(ac_handle* h, int enable, double* shader_mhz);
+
 /* Which LSTM path the handle uses (SYNCHRONISES the device; tests / diagnostics): 1 = the persistent single-launch kernel
  * (D = 512, 2 layers, 256-CU device; opt out with the environment variable AC_LSTM=step), 0 = one launch per
  * time step, AC_EHIP = a persistent launch failed since the handle was created (a bounded wait expired, or the launch
