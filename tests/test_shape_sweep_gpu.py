@@ -64,3 +64,45 @@ def _cached(key, make):
     if key not in _CACHE:
         _CACHE[key] = make()
     return _CACHE[key]
+
+
+MIMI_SHAPES = [(1, 1), (3, 1921), (2, 5000), (7, 3841), (17, 2000)]
+DAC_SHAPES = [(1, 512), (3, 777), (2, 2049), (5, 1300)]
+
+
+@pytest.mark.parametrize("B,T", MIMI_SHAPES)
+def test_mimi(B, T, mimi_checkpoints):
+    from audiocodecs_amd import Mimi
+    from oracle import mimi_oracle as O
+
+    cfg, sd = mimi_checkpoints("full", 0)
+    codec = _cached("mimi", lambda: Mimi(24000, num_codebooks=8, state_dict=sd, config=cfg).eval())
+    W, W64 = O.cast_weights(sd), O.cast_weights(sd, torch.float64)
+    sig = noise(30000 + 7 * B + T, B, T)
+    with torch.no_grad():
+        otoks = O.sig_to_toks(cfg, W, sig)
+        _, m64 = O.sig_to_toks(cfg, W64, sig.double(), None, 8, True)
+        orec = O.toks_to_sig(cfg, W, otoks)
+    toks = codec.sig_to_toks(sig.cuda())
+    mism, bad, excused = parity_record.tokens("mimi", f"sweep_B{B}_T{T}", toks.cpu().numpy(), otoks.numpy(), m64.numpy(), TAU)
+    assert bad == 0 and mism <= excused
+    assert rms((codec.toks_to_sig(otoks.cuda()).cpu() - orec).numpy()) < 2e-5
+
+
+@pytest.mark.parametrize("B,T", DAC_SHAPES)
+def test_dac(B, T, dac_checkpoints):
+    from audiocodecs_amd import DAC
+    from oracle import dac_oracle as O
+
+    cfg, sd = dac_checkpoints("full", 0)
+    codec = _cached("dac", lambda: DAC(44100, 44100, num_codebooks=9, state_dict=sd, config=cfg).eval())
+    W, W64 = O.cast_weights(sd), O.cast_weights(sd, torch.float64)
+    sig = noise(40000 + 7 * B + T, B, T)
+    with torch.no_grad():
+        otoks = O.sig_to_toks(cfg, W, sig, None, 9)
+        _, m64 = O.sig_to_toks(cfg, W64, sig.double(), None, 9, return_margin=True)
+        orec = O.toks_to_sig(cfg, W, otoks)
+    toks = codec.sig_to_toks(sig.cuda())
+    mism, bad, excused = parity_record.tokens("dac", f"sweep_B{B}_T{T}", toks.cpu().numpy(), otoks.numpy(), m64.numpy(), TAU)
+    assert bad == 0 and mism <= excused
+    assert rms((codec.toks_to_sig(otoks.cuda()).cpu() - orec).numpy()) < 3e-5
