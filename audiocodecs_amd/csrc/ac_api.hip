@@ -401,7 +401,10 @@ struct Packer {
                     for (int e = 0; e < 8; ++e) {
                         const int k = kmap[s * 32 + 8 * (l >> 4) + e];
                         uint16_t t[3] = {0, 0, 0};
-                        if (k >= 0) split3h(blob[src_off + (size_t)(nt * 16 + (l & 15)) * Ksrc + k], t);
+                        if (k >= 0) {
+                            if (h->gemm_bf16) t[0] = bf16_rn(blob[src_off + (size_t)(nt * 16 + (l & 15)) * Ksrc + k]);   // opt-in bf16 mode: one rounded plane
+                            else split3h(blob[src_off + (size_t)(nt * 16 + (l & 15)) * Ksrc + k], t);
+                        }
                         const size_t base = (((size_t)nt * ksteps + s) * 3) * 512 + (size_t)l * 8 + e;
                         planes[base] = t[0];
                         planes[base + 512] = t[1];
@@ -828,7 +831,8 @@ int try_thin6(ac_handle* h, hipStream_t st, const PackedGemm& g, const Act& x, i
     const int grid = (int)std::min<long long>(total, 4 * 256);   // persistent, four workgroups per CU
     ProfScope ps(h, st, "thin_conv6_kernel", 2.0 * B * p.M * 64.0 * 128.0,
                  (double)B * p.M * 256.0 * (1 + (out.raw ? 1 : 0) + (out.elu ? 1 : 0)));
-    hipLaunchKernelGGL(thin_conv6_kernel, dim3(grid), dim3(256), T6_LDS, st, p);
+    if (h->gemm_bf16) hipLaunchKernelGGL(thin_conv6_kernel<1>, dim3(grid), dim3(256), T6_LDS, st, p);
+    else hipLaunchKernelGGL(thin_conv6_kernel<3>, dim3(grid), dim3(256), T6_LDS, st, p);
     return AC_OK;
 }
 
@@ -953,7 +957,7 @@ int launch_rb_fused6(ac_handle* h, hipStream_t st, const ResBlockPlan& rb, const
     p.ntiles = cdiv(x.raw.L, Cfg::BM);
     p.pad = pad;
     if (const char* d = std::getenv("AC_RB6_DBG")) p.dbg = std::atoi(d);
-    if (int rc = ensure_lds(h, reinterpret_cast<const void*>(rb_fused6_kernel<C, SC>), Cfg::lds_bytes)) return rc;
+    if (int rc = ensure_lds(h, h->gemm_bf16 ? reinterpret_cast<const void*>(rb_fused6_kernel<C, SC, 1>) : reinterpret_cast<const void*>(rb_fused6_kernel<C, SC, 3>), Cfg::lds_bytes)) return rc;
     const long long total = (long long)B * p.ntiles;
     const int per_cu = C == 64 ? 2 : 3;
     const int grid = (int)std::min<long long>(total, (long long)per_cu * 256);   // persistent
@@ -961,7 +965,8 @@ int launch_rb_fused6(ac_handle* h, hipStream_t st, const ResBlockPlan& rb, const
     ProfScope ps(h, st, !SC ? "rb_fused6_kernel<64, false>" : C == 32 ? "rb_fused6_kernel<32, true>" : "rb_fused6_kernel<64, true>",
                  2.0 * B * L * ((double)(C / 2) * 3 * C + (double)C * (C / 2 + (SC ? C : 0))),
                  (double)B * L * C * 4.0 * (1 + (out.raw ? 1 : 0) + (out.elu ? 1 : 0)));
-    hipLaunchKernelGGL((rb_fused6_kernel<C, SC>), dim3(grid), dim3(256), Cfg::lds_bytes, st, p);
+    if (h->gemm_bf16) hipLaunchKernelGGL((rb_fused6_kernel<C, SC, 1>), dim3(grid), dim3(256), Cfg::lds_bytes, st, p);
+    else hipLaunchKernelGGL((rb_fused6_kernel<C, SC, 3>), dim3(grid), dim3(256), Cfg::lds_bytes, st, p);
     return AC_OK;
 }
 
@@ -983,14 +988,15 @@ int launch_rb128_fused6(ac_handle* h, hipStream_t st, const ResBlockPlan& rb, co
     p.Lp = x.raw.L > p.lpad ? x.raw.L : p.lpad + 1;
     p.ntiles = cdiv(x.raw.L, Cfg::BM);
     p.pad = pad;
-    if (int rc = ensure_lds(h, reinterpret_cast<const void*>(rb128_fused6_kernel<SC>), Cfg::lds_bytes)) return rc;
+    if (int rc = ensure_lds(h, h->gemm_bf16 ? reinterpret_cast<const void*>(rb128_fused6_kernel<SC, 1>) : reinterpret_cast<const void*>(rb128_fused6_kernel<SC, 3>), Cfg::lds_bytes)) return rc;
     const long long total = (long long)B * p.ntiles;
     const int grid = (int)std::min<long long>(total, 256);   // persistent, one workgroup per CU
     const double L = x.raw.L;
     ProfScope ps(h, st, SC ? "rb128_fused6_kernel<true>" : "rb128_fused6_kernel<false>",
                  2.0 * B * L * (64.0 * 384 + 128.0 * (64 + (SC ? 128 : 0))),
                  (double)B * L * 128 * 4.0 * (1 + (out.raw ? 1 : 0) + (out.elu ? 1 : 0)));
-    hipLaunchKernelGGL((rb128_fused6_kernel<SC>), dim3(grid), dim3(512), Cfg::lds_bytes, st, p);
+    if (h->gemm_bf16) hipLaunchKernelGGL((rb128_fused6_kernel<SC, 1>), dim3(grid), dim3(512), Cfg::lds_bytes, st, p);
+    else hipLaunchKernelGGL((rb128_fused6_kernel<SC, 3>), dim3(grid), dim3(512), Cfg::lds_bytes, st, p);
     return AC_OK;
 }
 // can the 128-channel block run fused?  (the producer then writes the raw flavour only)

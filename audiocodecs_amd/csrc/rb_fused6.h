@@ -63,8 +63,15 @@ __device__ __forceinline__ void split3(float v, unsigned& h, unsigned& m, unsign
     l = __float_as_uint(r1 - __uint_as_float(m));
 }
 
-// 4 fp32 -> 4 bf16 per plane, stored as 8 bytes at element offset `o` of each plane
+// 4 fp32 -> 4 bf16 per plane, stored as 8 bytes at element offset `o` of each plane.  NP = 1 (the opt-in bf16 mode,
+// ac_set_precision): ONE plane, rounded to nearest-even -- no split.
+template <int NP = 3>
 __device__ __forceinline__ void split_store4(const f32x4 v, __bf16* p0, int plane, int o) {
+    if (NP == 1) {
+        typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+        *reinterpret_cast<bf16x4_t*>(p0 + o) = __builtin_convertvector(v, bf16x4_t);
+        return;
+    }
     unsigned h[4], m[4], l[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) split3(v[i], h[i], m[i], l[i]);
@@ -74,8 +81,10 @@ __device__ __forceinline__ void split_store4(const f32x4 v, __bf16* p0, int plan
     *reinterpret_cast<u32x2*>(p0 + 2 * plane + o) = u32x2{(l[0] >> 16) | (l[1] & 0xffff0000u), (l[2] >> 16) | (l[3] & 0xffff0000u)};
 }
 
-// acc (+)= W x^T over one k-step: 6 partial products, small terms first.  w / x: [plane]
+// acc (+)= W x^T over one k-step: 6 partial products, small terms first (NP = 1: the single bf16 product).  w / x: [plane]
+template <int NP = 3>
 __device__ __forceinline__ f32x4 mma6(const bf16x8 (&w)[3], const bf16x8 (&x)[3], f32x4 v) {
+    if (NP == 1) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[0], x[0], v, 0, 0, 0);
     v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[2], x[0], v, 0, 0, 0);   // l h
     v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[0], x[2], v, 0, 0, 0);   // h l
     v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[1], x[1], v, 0, 0, 0);   // m m
@@ -85,7 +94,7 @@ __device__ __forceinline__ f32x4 mma6(const bf16x8 (&w)[3], const bf16x8 (&x)[3]
     return v;
 }
 
-template <int C, bool SC>
+template <int C, bool SC, int NP = 3>
 __global__ __launch_bounds__(256, C == 64 ? 2 : 3) void rb_fused6_kernel(const RbFused6Params p) {
     using Cfg = Rb6Cfg<C, SC>;
     constexpr int BM = Cfg::BM, HC = Cfg::HC, XP = Cfg::XP, HP = Cfg::HP;
@@ -113,7 +122,7 @@ __global__ __launch_bounds__(256, C == 64 ? 2 : 3) void rb_fused6_kernel(const R
 #pragma unroll
         for (int ks = 0; ks < KSA; ++ks)
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl)
+            for (int pl = 0; pl < NP; ++pl)
                 w3r[ks][c][pl] = *reinterpret_cast<const bf16x8*>(p.w3f + ((((long long)(na0 / 16 + c) * KSA + ks) * 3 + pl) * 64 + lane) * 8);
     }
 #pragma unroll
@@ -122,7 +131,7 @@ __global__ __launch_bounds__(256, C == 64 ? 2 : 3) void rb_fused6_kernel(const R
 #pragma unroll
         for (int ks = 0; ks < KSB; ++ks)
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl)
+            for (int pl = 0; pl < NP; ++pl)
                 wfr[ks][c][pl] = *reinterpret_cast<const bf16x8*>(p.wff + ((((long long)(nb0 / 16 + c) * KSB + ks) * 3 + pl) * 64 + lane) * 8);
     }
     // hidden columns HC .. HCP-1 (C = 32) are K padding: zero once, the matching weight fragments are zero too
@@ -158,9 +167,9 @@ __global__ __launch_bounds__(256, C == 64 ? 2 : 3) void rb_fused6_kernel(const R
         for (int i = 0; i < SLOTS; ++i) {
             const int row = s_row[i], q = s_q4[i] / 16;
             if (row < Cfg::XE_ROWS) {
-                split_store4(elu4(rx[i]), Xe, Cfg::XE_PLANE, row * XP + 4 * q);
+                split_store4<NP>(elu4(rx[i]), Xe, Cfg::XE_PLANE, row * XP + 4 * q);
                 // rows lpad .. lpad + BM - 1 of the slab are the tile's own rows (source index t0 + row - lpad >= 0)
-                if (SC && row >= p.lpad && row < p.lpad + BM) split_store4(rx[i], Xr, Cfg::XR_PLANE, (row - p.lpad) * XP + 4 * q);
+                if (SC && row >= p.lpad && row < p.lpad + BM) split_store4<NP>(rx[i], Xr, Cfg::XR_PLANE, (row - p.lpad) * XP + 4 * q);
             }
         }
     };
@@ -188,18 +197,18 @@ __global__ __launch_bounds__(256, C == 64 ? 2 : 3) void rb_fused6_kernel(const R
 #pragma unroll
                 for (int a = 0; a < MS; ++a)
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl)
+                    for (int pl = 0; pl < NP; ++pl)
                         xf[a][pl] = *reinterpret_cast<const bf16x8*>(Xe + pl * Cfg::XE_PLANE + (r0 + a * 16 + li + j) * XP + kc * 32 + 8 * kq);
 #pragma unroll
                 for (int a = 0; a < MS; ++a)
 #pragma unroll
-                    for (int c = 0; c < NA; ++c) acc[a][c] = mma6(w3r[ks][c], xf[a], acc[a][c]);
+                    for (int c = 0; c < NA; ++c) acc[a][c] = mma6<NP>(w3r[ks][c], xf[a], acc[a][c]);
             }
 #pragma unroll
             for (int a = 0; a < MS; ++a)
 #pragma unroll
                 for (int c = 0; c < NA; ++c)
-                    split_store4(elu4(acc[a][c]), Hs, Cfg::H_PLANE, (r0 + a * 16 + li) * HP + na0 + c * 16 + 4 * kq);
+                    split_store4<NP>(elu4(acc[a][c]), Hs, Cfg::H_PLANE, (r0 + a * 16 + li) * HP + na0 + c * 16 + 4 * kq);
         }
         if (NSPLIT > 1) __syncthreads();                        // C = 32: a wave reads back only its own rows
         // ---- stage B: y = [W1 | Ws] * [hidden | x]^T + bf
@@ -215,13 +224,13 @@ __global__ __launch_bounds__(256, C == 64 ? 2 : 3) void rb_fused6_kernel(const R
 #pragma unroll
             for (int a = 0; a < MS; ++a)
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
+                for (int pl = 0; pl < NP; ++pl)
                     xf[a][pl] = ks < KSH ? *reinterpret_cast<const bf16x8*>(Hs + pl * Cfg::H_PLANE + (r0 + a * 16 + li) * HP + ks * 32 + 8 * kq)
                                          : *reinterpret_cast<const bf16x8*>(Xr + pl * Cfg::XR_PLANE + (r0 + a * 16 + li) * XP + (ks - KSH) * 32 + 8 * kq);
 #pragma unroll
             for (int a = 0; a < MS; ++a)
 #pragma unroll
-                for (int c = 0; c < NB; ++c) acc[a][c] = mma6(wfr[ks][c], xf[a], acc[a][c]);
+                for (int c = 0; c < NB; ++c) acc[a][c] = mma6<NP>(wfr[ks][c], xf[a], acc[a][c]);
         }
         __syncthreads();                                        // every wave is done reading the slabs
         // the next tile is staged BEFORE this tile's output stores are issued: the wait for its loads must not

@@ -28,7 +28,7 @@ struct Rb128Cfg {
     static constexpr size_t lds_bytes = (size_t)3 * (XE_PLANE + XR_PLANE + H_PLANE) * 2 + (size_t)BM * PSP * 4;
 };
 
-template <bool SC>
+template <bool SC, int NP = 3>
 __global__ __launch_bounds__(512, 1) void rb128_fused6_kernel(const RbFused6Params p) {
     using Cfg = Rb128Cfg<SC>;
     constexpr int C = Cfg::C, BM = Cfg::BM, NT = Cfg::NT, XP = Cfg::XP, HP = Cfg::HP, TT = Cfg::TT;
@@ -50,12 +50,12 @@ __global__ __launch_bounds__(512, 1) void rb128_fused6_kernel(const RbFused6Para
 #pragma unroll
     for (int i = 0; i < KSA_W; ++i)
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
+        for (int pl = 0; pl < NP; ++pl)
             w3r[i][pl] = *reinterpret_cast<const bf16x8*>(p.w3f + ((((long long)ng * Cfg::KSA + kg * KSA_W + i) * 3 + pl) * 64 + lane) * 8);
 #pragma unroll
     for (int ks = 0; ks < KSB; ++ks)
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
+        for (int pl = 0; pl < NP; ++pl)
             wfr[ks][pl] = *reinterpret_cast<const bf16x8*>(p.wff + ((((long long)wave * KSB + ks) * 3 + pl) * 64 + lane) * 8);
     const f32x4 b3v = *reinterpret_cast<const f32x4*>(p.b3 + ng * 16 + 4 * kq);
     const f32x4 bfv = *reinterpret_cast<const f32x4*>(p.bf + wave * 16 + 4 * kq);
@@ -85,8 +85,8 @@ __global__ __launch_bounds__(512, 1) void rb128_fused6_kernel(const RbFused6Para
         for (int i = 0; i < SLOTS; ++i) {
             const int row = s_row[i], q = s_q4[i] / 16;
             if (row < Cfg::XE_ROWS) {
-                split_store4(elu4(rx[i]), Xe, Cfg::XE_PLANE, row * XP + 4 * q);
-                if (SC && row >= p.lpad && row < p.lpad + BM) split_store4(rx[i], Xr, Cfg::XR_PLANE, (row - p.lpad) * XP + 4 * q);
+                split_store4<NP>(elu4(rx[i]), Xe, Cfg::XE_PLANE, row * XP + 4 * q);
+                if (SC && row >= p.lpad && row < p.lpad + BM) split_store4<NP>(rx[i], Xr, Cfg::XR_PLANE, (row - p.lpad) * XP + 4 * q);
             }
         }
     };
@@ -114,10 +114,10 @@ __global__ __launch_bounds__(512, 1) void rb128_fused6_kernel(const RbFused6Para
 #pragma unroll
                     for (int a = 0; a < 2; ++a)
 #pragma unroll
-                        for (int pl = 0; pl < 3; ++pl)
+                        for (int pl = 0; pl < NP; ++pl)
                             xf[a][pl] = *reinterpret_cast<const bf16x8*>(Xe + pl * Cfg::XE_PLANE + ((a0 + a) * 16 + li + j) * XP + kc * 32 + 8 * kq);
 #pragma unroll
-                    for (int a = 0; a < 2; ++a) acc[a0 + a] = mma6(w3r[i], xf[a], acc[a0 + a]);
+                    for (int a = 0; a < 2; ++a) acc[a0 + a] = mma6<NP>(w3r[i], xf[a], acc[a0 + a]);
                 }
             }
             if (kg == 1) {
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(512, 1) void rb128_fused6_kernel(const RbFused6Para
                 for (int a = 0; a < TT; ++a) {
                     const f32x4 u = *reinterpret_cast<const f32x4*>(&Ps[(a * 16 + li) * PSP + ng * 16 + 4 * kq]);
                     const f32x4 v = f32x4{acc[a].x + u.x, acc[a].y + u.y, acc[a].z + u.z, acc[a].w + u.w};
-                    split_store4(elu4(v), Hs, Cfg::H_PLANE, (a * 16 + li) * HP + ng * 16 + 4 * kq);
+                    split_store4<NP>(elu4(v), Hs, Cfg::H_PLANE, (a * 16 + li) * HP + ng * 16 + 4 * kq);
                 }
             }
         }
@@ -147,11 +147,11 @@ __global__ __launch_bounds__(512, 1) void rb128_fused6_kernel(const RbFused6Para
 #pragma unroll
                 for (int a = 0; a < 2; ++a)
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl)
+                    for (int pl = 0; pl < NP; ++pl)
                         xf[a][pl] = ks < KSH ? *reinterpret_cast<const bf16x8*>(Hs + pl * Cfg::H_PLANE + ((a0 + a) * 16 + li) * HP + ks * 32 + 8 * kq)
                                              : *reinterpret_cast<const bf16x8*>(Xr + pl * Cfg::XR_PLANE + ((a0 + a) * 16 + li) * XP + (ks - KSH) * 32 + 8 * kq);
 #pragma unroll
-                for (int a = 0; a < 2; ++a) acc[a0 + a] = mma6(wfr[ks], xf[a], acc[a0 + a]);
+                for (int a = 0; a < 2; ++a) acc[a0 + a] = mma6<NP>(wfr[ks], xf[a], acc[a0 + a]);
             }
         }
         __syncthreads();                                        // every wave is done reading the slabs

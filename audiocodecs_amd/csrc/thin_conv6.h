@@ -35,6 +35,7 @@ constexpr int T6_PLANE = T6_ROWS * T6_XP;
 constexpr int T6_SLOTS = (T6_ROWS * 16 + 255) / 256;        // float4 slots per thread
 constexpr size_t T6_LDS = (size_t)3 * T6_PLANE * 2;
 
+template <int NP = 3>
 __global__ __launch_bounds__(256, 4) void thin_conv6_kernel(const ThinConv6Params p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __bf16* Xs = reinterpret_cast<__bf16*>(smem);           // [3][T6_ROWS][T6_XP]: slab row r = super-row m0 - 1 + r
@@ -47,7 +48,7 @@ __global__ __launch_bounds__(256, 4) void thin_conv6_kernel(const ThinConv6Param
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
+        for (int pl = 0; pl < NP; ++pl)
             wr[ks][pl] = *reinterpret_cast<const bf16x8*>(p.wf + ((((long long)wave * 4 + ks) * 3 + pl) * 64 + lane) * 8);
     const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + wave * 16 + 4 * kq);
 
@@ -75,7 +76,7 @@ __global__ __launch_bounds__(256, 4) void thin_conv6_kernel(const ThinConv6Param
     auto store_tile = [&]() {
 #pragma unroll
         for (int i = 0; i < T6_SLOTS; ++i)
-            if (s_row[i] < T6_ROWS) split_store4(rx[i], Xs, T6_PLANE, s_row[i] * T6_XP + 4 * s_q[i]);
+            if (s_row[i] < T6_ROWS) split_store4<NP>(rx[i], Xs, T6_PLANE, s_row[i] * T6_XP + 4 * s_q[i]);
     };
 
     int tile = blockIdx.x;
@@ -96,10 +97,10 @@ __global__ __launch_bounds__(256, 4) void thin_conv6_kernel(const ThinConv6Param
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
+                for (int pl = 0; pl < NP; ++pl)
                     xf[a][pl] = *reinterpret_cast<const bf16x8*>(Xs + pl * T6_PLANE + (a * 16 + li + (ks >> 1)) * T6_XP + (ks & 1) * 32 + 8 * kq);
 #pragma unroll
-            for (int a = 0; a < 4; ++a) acc[a] = mma6(wr[ks], xf[a], acc[a]);
+            for (int a = 0; a < 4; ++a) acc[a] = mma6<NP>(wr[ks], xf[a], acc[a]);
         }
         __syncthreads();                                    // every wave is done reading the slab
         if (next < total) store_tile();                     // staged before the output stores are issued (rb_fused6.h)

@@ -204,9 +204,11 @@ int ac_load_weights(ac_handle* h, const char* name, const void* host_ptr, size_t
  *                            6 partial products, fp32 accumulate) -- the arithmetic every parity claim is made for;
  *   AC_PRECISION_FP32_EXACT  exact fp32 products (v_mfma_f32_16x16x4_f32) everywhere; same as AC_GEMM=fp32;
  *   AC_PRECISION_BF16        OPT-IN, not a parity mode (BASELINE.json configs[1] says "bf16"): the
- *                            tap-GEMMs round both operands to bf16 (nearest-even) and do ONE product per pair with fp32
- *                            accumulate; LSTM, fused residual blocks, codebook search stay fp32-faithful.  Reported with its
- *                            own token-mismatch rate and waveform error (bench.py --precision bf16); same as AC_GEMM=bf16.
+ *                            tap-GEMMs, the fused residual blocks and the [64][128] layers -- i.e. every conv of the SEANet
+ *                            stacks incl. the T >= 120 000 stages, and the dense layers of the transformers / backbone --
+ *                            round both operands to bf16 (nearest-even) and do ONE product per pair with fp32 accumulate;
+ *                            activations stay fp32 in HBM; LSTM, stem / head, codebook search stay fp32-faithful.  Reported
+ *                            with its own token-mismatch rate and waveform error (bench.py --precision bf16); = AC_GEMM=bf16.
  * Without this call the environment variable AC_GEMM (fp32 | bf16) decides, default AC_PRECISION_FP32. */
 #define AC_PRECISION_FP32 0
 #define AC_PRECISION_FP32_EXACT 1
