@@ -1,4 +1,5 @@
-"""The OPT-IN bf16 mode (ac_set_precision(AC_PRECISION_BF16)): the tap-GEMMs round their operands to
+"""The OPT-IN bf16 mode (ac_set_precision(AC_PRECISION_BF16)): the GEMM-shaped kernels
+(tap-GEMMs, fused residual blocks, [64][128] layers) round their operands to
 bf16 and do one product per pair.  It is NOT a parity mode -- token ids differ from the reference wherever the codebook
 margin is below the bf16 noise -- so this test only checks that the mode runs, stays close to the fp32-faithful default in
 the signal domain, and RECORDS its own mismatch rate and errors (parity_report.json), as the survey asks."""
