@@ -168,7 +168,7 @@ EXPORTS = {
     "ac_destroy": (None, [_vp]),
 }
 
-PRECISIONS = {"fp32": 0, "fp32_exact": 1, "bf16": 2}   # AC_PRECISION_*
+PRECISIONS = {"fp32": 0, "fp32_exact": 1, "bf16": 2, "fp32_bf16x3": 3}   # AC_PRECISION_*
 
 
 def check_precision(precision):

@@ -49,6 +49,8 @@ struct ResBlockPlan {
     PackedGemm c3;     // k3 conv C -> C/2
     PackedGemm fused;  // [ELU(h) | x] * [W1; Ws] + (b1 + bs)
     size_t w3f_off = 0, wff_off = 0;   // rb_fused6.h fragment images of the two matrices (float offsets into the blob)
+    size_t winv3_off = 0, winvf_off = 0;   // split16.h: per-row 2^-s of the two images
+    float hb0 = 0.f, hb1 = 0.f;            // split16.h: |hidden| <= hb0 + hb1 * amax(x)
     bool has6 = false;
 };
 
@@ -167,10 +169,17 @@ struct ac_handle {
     // split-operand weights (tap_gemm6.h): float offset of a packed fp32 matrix -> float offset of its bf16 planes
     std::map<size_t, size_t> w6_of;
     std::map<size_t, size_t> t6_of;   // thin_conv6.h fragment images of the [64][128] layers, keyed like w6_of
+    std::map<size_t, size_t> t6inv_of;   // split16.h: their per-row 2^-s
     bool noncausal = false;                // WavTokenizer's SEANet encoder: centred padding (right = total/2, left = total - right)
     bool has_enc = true, has_dec = true;   // a half the caller's mode never runs may be left out (encodec.py:67-71)
     bool gemm_fp32 = false;         // AC_PRECISION_FP32_EXACT (or AC_GEMM=fp32): exact-product kernels only
     bool gemm_bf16 = false;         // AC_PRECISION_BF16 (or AC_GEMM=bf16): opt-in, operands rounded to bf16 in the tap-GEMMs
+    bool split16 = true;            // fp32-fidelity arithmetic of the matrix kernels: two fp16 planes, 3 products (split16.h);
+                                    // false (AC_PRECISION_FP32_BF16X3 / AC_SPLIT=bf16x3): three bf16 planes, 6 products
+    std::map<size_t, size_t> winv_of;   // split16 images: float offset of a packed fp32 matrix -> offset of its per-row 2^-s
+    // amax slots (split16.h): [slot][amax_B] words, handed out in launch order, cleared at the start of every pass
+    unsigned* amax_buf = nullptr;
+    int amax_B = 0, amax_next = 0;
     int precision = -1;             // ac_set_precision; -1: take AC_GEMM from the environment
     // persistent LSTM (lstm_persist.h): control words, device shape, opt-out (AC_LSTM=step)
     unsigned* lp_ctl = nullptr;
@@ -330,8 +339,81 @@ struct Packer {
         if ((b & 0x7f800000u) == 0x7f800000u) return (uint16_t)(b >> 16);   // inf / nan
         return (uint16_t)((b + 0x7fffu + ((b >> 16) & 1u)) >> 16);
     }
+    // fp16 round-to-nearest-even (denormals kept, overflow -> inf) and back: split16.h on the host
+    static uint16_t f16_rn(float f) {
+        uint32_t x;
+        std::memcpy(&x, &f, 4);
+        const uint16_t sign = (uint16_t)((x >> 16) & 0x8000u);
+        x &= 0x7fffffffu;
+        if (x >= 0x7f800000u) return (uint16_t)(sign | 0x7c00u | (x > 0x7f800000u ? 0x200u : 0u));
+        if (x >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);      // >= 65520 rounds to inf
+        if (x <= 0x33000000u) return sign;                           // <= 2^-25: half the smallest denormal ties to even = 0
+        const int e = (int)(x >> 23) - 127;
+        const uint32_t m = (x & 0x7fffffu) | 0x800000u;
+        const int shift = e >= -14 ? 13 : 13 + (-14 - e);
+        uint32_t q = m >> shift;
+        const uint32_t rem = m & ((1u << shift) - 1u), half = 1u << (shift - 1);
+        if (rem > half || (rem == half && (q & 1u))) ++q;
+        if (e >= -14) return (uint16_t)(sign | (uint16_t)(((uint32_t)(e + 15) << 10) + (q - 0x400u)));
+        return (uint16_t)(sign | (uint16_t)q);
+    }
+    static float f16_f32(uint16_t hbits) {
+        const int e = (hbits >> 10) & 31, m = hbits & 0x3ff;
+        float v;
+        if (e == 0) v = std::ldexp((float)m, -24);
+        else if (e == 31) v = m ? NAN : INFINITY;
+        else v = std::ldexp((float)(m | 0x400), e - 25);
+        return (hbits & 0x8000) ? -v : v;
+    }
+    // split16.h scale of one weight row: 2^s with |w| 2^s < 2^15; returns s
+    static int row_scale(const float* w, size_t n, const std::vector<int>* kmap = nullptr) {
+        uint32_t mx = 0;
+        for (size_t k = 0; k < (kmap ? kmap->size() : n); ++k) {
+            if (kmap && (*kmap)[k] < 0) continue;
+            uint32_t b;
+            std::memcpy(&b, &w[kmap ? (size_t)(*kmap)[k] : k], 4);
+            b &= 0x7fffffffu;
+            mx = std::max(mx, b);
+        }
+        return s16_exponent(mx, 40);
+    }
+    static void split16h(float v, int s, uint16_t (&o)[3]) {
+        const float vs = std::ldexp(v, s);
+        o[0] = f16_rn(vs);
+        o[1] = f16_rn(vs - f16_f32(o[0]));
+        o[2] = 0;
+    }
+    bool use16() const { return h->split16 && !h->gemm_bf16 && !h->gemm_fp32; }
+    // tap_gemm6 NP = 2 image: [n-tile of 32][k-step of 16][plane 2][lane 64][8 fp16] of the scaled rows + winv[N]
+    void pack16(const PackedGemm& g) {
+        const size_t n_el = (size_t)g.N * g.Ktot;
+        const size_t off = reserve(n_el);
+        const size_t ioff = reserve(g.N);
+        std::vector<uint16_t> planes(2 * n_el);
+        const int ksteps = g.Ktot / 16;
+        std::vector<int> sc(g.N);
+        for (int n = 0; n < g.N; ++n) {
+            sc[n] = row_scale(&blob[g.w_off + (size_t)n * g.Ktot], g.Ktot);
+            blob[ioff + n] = s16_pow2(-sc[n]);
+        }
+        for (int nt = 0; nt < g.N / 32; ++nt)
+            for (int s = 0; s < ksteps; ++s)
+                for (int l = 0; l < 64; ++l)
+                    for (int e = 0; e < 8; ++e) {
+                        const int n = nt * 32 + (l & 31);
+                        uint16_t t[3];
+                        split16h(blob[g.w_off + (size_t)n * g.Ktot + s * 16 + 8 * (l >> 5) + e], sc[n], t);
+                        const size_t base = (((size_t)nt * ksteps + s) * 2) * 512 + (size_t)l * 8 + e;
+                        planes[base] = t[0];
+                        planes[base + 512] = t[1];
+                    }
+        std::memcpy(&blob[off], planes.data(), planes.size() * 2);
+        h->w6_of[g.w_off] = off;
+        h->winv_of[g.w_off] = ioff;
+    }
     void pack6(const PackedGemm& g) {
         if ((g.N % 64 && g.N % 96) || g.Ktot % 32 || h->w6_of.count(g.w_off)) return;
+        if (use16()) return pack16(g);
         const size_t n_el = (size_t)g.N * g.Ktot;
         const size_t off = reserve((3 * n_el + 1) / 2);
         std::vector<uint16_t> planes(3 * n_el);
@@ -390,9 +472,33 @@ struct Packer {
     // v_mfma_f32_16x16x32_bf16 operand fragments of a row-major [N][Ksrc] matrix in the blob:
     //   [n-tile of 16][k-step of 32][plane 3][lane 64][8 bf16],  lane (n = lane & 15, k = 8 * (lane >> 4) + e);
     // kmap[k'] = source column of padded column k', or -1 for a zero column
-    size_t frag16(size_t src_off, int N, int Ksrc, const std::vector<int>& kmap) {
+    size_t frag16(size_t src_off, int N, int Ksrc, const std::vector<int>& kmap, size_t* winv_off = nullptr) {
         const int ksteps = (int)kmap.size() / 32;
         const size_t n_el = (size_t)N * kmap.size();
+        if (use16()) {   // split16.h: two fp16 planes of the scaled rows, [n-tile of 16][k-step of 32][plane 2][lane 64][8], + winv[N]
+            const size_t off = reserve(n_el);
+            const size_t ioff = reserve(N);
+            std::vector<uint16_t> planes(2 * n_el);
+            std::vector<int> sc(N);
+            for (int n = 0; n < N; ++n) {
+                sc[n] = row_scale(&blob[src_off + (size_t)n * Ksrc], Ksrc, &kmap);
+                blob[ioff + n] = s16_pow2(-sc[n]);
+            }
+            for (int nt = 0; nt < N / 16; ++nt)
+                for (int s = 0; s < ksteps; ++s)
+                    for (int l = 0; l < 64; ++l)
+                        for (int e = 0; e < 8; ++e) {
+                            const int k = kmap[s * 32 + 8 * (l >> 4) + e], n = nt * 16 + (l & 15);
+                            uint16_t t[3] = {0, 0, 0};
+                            if (k >= 0) split16h(blob[src_off + (size_t)n * Ksrc + k], sc[n], t);
+                            const size_t base = (((size_t)nt * ksteps + s) * 2) * 512 + (size_t)l * 8 + e;
+                            planes[base] = t[0];
+                            planes[base + 512] = t[1];
+                        }
+            std::memcpy(&blob[off], planes.data(), planes.size() * 2);
+            if (winv_off) *winv_off = ioff;
+            return off;
+        }
         const size_t off = reserve((3 * n_el + 1) / 2);
         std::vector<uint16_t> planes(3 * n_el);
         for (int nt = 0; nt < N / 16; ++nt)
@@ -418,7 +524,9 @@ struct Packer {
         if (g.N != 64 || g.Ktot != 128 || !g.has_bias || h->t6_of.count(g.w_off)) return;
         std::vector<int> km(128);
         for (int k = 0; k < 128; ++k) km[k] = k;
-        h->t6_of[g.w_off] = frag16(g.w_off, 64, 128, km);
+        size_t ioff = 0;
+        h->t6_of[g.w_off] = frag16(g.w_off, 64, 128, km, &ioff);
+        if (use16()) h->t6inv_of[g.w_off] = ioff;
     }
     // rb_fused6.h images of a residual block (k3 conv C -> C/2, then [1x1 over the hidden | optional shortcut over x])
     void rb6(ResBlockPlan& rb, bool sc) {
@@ -429,8 +537,15 @@ struct Packer {
         const int hcp = hid < 32 ? 32 : hid;
         for (int k = 0; k < hcp; ++k) kf.push_back(k < hid ? k : -1);
         for (int k = 0; sc && k < C; ++k) kf.push_back(hid + k);
-        rb.w3f_off = frag16(rb.c3.w_off, hid, rb.c3.Ktot, k3);
-        rb.wff_off = frag16(rb.fused.w_off, C, rb.fused.Ktot, kf);
+        rb.w3f_off = frag16(rb.c3.w_off, hid, rb.c3.Ktot, k3, &rb.winv3_off);
+        rb.wff_off = frag16(rb.fused.w_off, C, rb.fused.Ktot, kf, &rb.winvf_off);
+        rb.hb0 = rb.hb1 = 0.f;
+        for (int n = 0; n < hid; ++n) {
+            double l1 = 0.0;
+            for (int k = 0; k < rb.c3.Ktot; ++k) l1 += std::fabs((double)blob[rb.c3.w_off + (size_t)n * rb.c3.Ktot + k]);
+            rb.hb1 = std::max(rb.hb1, (float)(l1 * 1.000001));
+            rb.hb0 = std::max(rb.hb0, std::fabs(blob[rb.c3.b_off + n]));
+        }
         rb.has6 = true;
     }
     // plain conv (stride 1 or k = 2*stride): packed[n][tap*cin + ci] = w[n][ci][tap]
@@ -604,6 +719,8 @@ struct Act {          // a channels-last activation view
     const float* p;
     long long bs, ts;
     int L, C;
+    const unsigned* amax = nullptr;   // split16.h: [B] largest-magnitude bits left by the producer (null: not reported)
+    int amax_n = 0;                   //   number of clips the slot was written for (a view of another batch shape must not use it)
 };
 
 int prof_name(ac_handle* h, const char* nm) {
@@ -645,6 +762,47 @@ struct ProfScope {
     }
 };
 
+constexpr int AMAX_SLOTS = 4096;
+
+// start of a pass over B clips: all slots back to zero
+int amax_begin(ac_handle* h, hipStream_t st, int B) {
+    if (!h->split16 || h->gemm_fp32 || h->gemm_bf16) return AC_OK;
+    if (B > h->amax_B) {
+        if (h->amax_buf) { HIPCHK(h, hipStreamSynchronize(st)); HIPCHK(h, hipFree(h->amax_buf)); h->amax_buf = nullptr; }
+        h->amax_B = std::max(B, 64);
+        HIPCHK(h, hipMalloc(&h->amax_buf, (size_t)AMAX_SLOTS * h->amax_B * 4));
+        h->amax_next = AMAX_SLOTS;
+    }
+    if (h->amax_next) HIPCHK(h, hipMemsetAsync(h->amax_buf, 0, (size_t)std::min(h->amax_next, AMAX_SLOTS) * h->amax_B * 4, st));
+    h->amax_next = 0;
+    return AC_OK;
+}
+// a fresh slot for a producer's output (null when the arithmetic does not use them)
+unsigned* amax_new(ac_handle* h) {
+    if (!h->split16 || h->gemm_fp32 || h->gemm_bf16 || !h->amax_buf || h->amax_next >= AMAX_SLOTS) return nullptr;
+    return h->amax_buf + (size_t)(h->amax_next++) * h->amax_B;
+}
+// the amax of a tensor a consumer is about to split: the producer's, or one more read of the tensor
+const unsigned* amax_of(ac_handle* h, hipStream_t st, const float* x, long long bs, long long ts, int L, int C, int B, const unsigned* known) {
+    if (known) return known;
+    unsigned* slot = amax_new(h);
+    if (!slot || B > h->amax_B) return nullptr;
+    const long long n = (long long)L * C;
+    const int gx = (int)std::max<long long>(1, std::min<long long>(cdiv((int)std::min<long long>(n / 4 + 1, 1 << 30), 256 * 8), 2048 / std::max(1, std::min(B, 64))));
+    ProfScope ps(h, st, "amax_kernel", 0.0, (double)B * n * 4.0);
+    hipLaunchKernelGGL(amax_kernel, dim3(gx, B), dim3(256), 0, st, x, bs, ts, L, C, slot);
+    return slot;
+}
+
+// slot holding the bound amax(x) + add of a tensor y with |y| <= |x| + add (LSTM with skip: |h| < 1); null when x has no amax
+const unsigned* amax_plus(ac_handle* h, hipStream_t st, const Act& x, float add, int B) {
+    if (!x.amax || x.amax_n != B) return nullptr;
+    unsigned* slot = amax_new(h);
+    if (!slot) return nullptr;
+    hipLaunchKernelGGL(amax_add_kernel, dim3(cdiv(B, 64)), dim3(64), 0, st, x.amax, add, slot, B);
+    return slot;
+}
+
 template <int WGM, int WGN, int WM, int WN, bool VEC>
 void launch_tap(const TapGemmParams& p0, hipStream_t st) {
     TapGemmParams p = p0;
@@ -676,6 +834,8 @@ int launch_tap4(ac_handle* h, const TapGemmParams& p0, hipStream_t st) {
 TapSeg make_seg(const Act& x, int s, int J, int pad /*PAD_**/, int extra, int kofs, const float* rel_len, int left = -1, int right = 0) {
     TapSeg g{};
     g.x = x.p;
+    g.amax = x.amax;
+    g.amax_n = x.amax_n;
     g.bs = x.bs;
     g.ts = x.ts;
     g.rel_len = rel_len;
@@ -746,21 +906,31 @@ int run_tap(ac_handle* h, hipStream_t st, TapGemmParams& p) {
     } while (0)
     if (w6) {
         p.clk = h->clk_dev;
+        auto iv = h->winv_of.find((size_t)(p.w - h->blob));
+        if (iv != h->winv_of.end()) {     // split16.h: every operand tensor needs its amax; the output reports its own
+            for (int i = 0; i < p.nseg; ++i) {
+                TapSeg& sg = p.seg[i];
+                sg.amax = amax_of(h, st, sg.x, sg.bs, sg.ts, sg.L, sg.cin, p.B, sg.amax_n == p.B ? sg.amax : nullptr);
+                if (!sg.amax) return fail(h, AC_ESTATE, "out of amax slots (split16.h)");
+            }
+            p.winv = h->blob + iv->second;
+            p.amax_out = amax_new(h);
+        }
+#define TAP6_LAUNCH(WGM, WGN, WMT, WN, NP)                                                                              \
+    do {                                                                                                                \
+        if ((rc = ensure_lds(h, reinterpret_cast<const void*>(tap_gemm6_kernel<WGM, WGN, WMT, WN, NP>), Cfg6::lds_bytes))) return rc; \
+        ProfScope ps(h, st, (std::string("tap_gemm6_kernel<" #WGM ", " #WGN ", " #WMT ", " #WN ", " #NP ">") + shape).c_str(), flops, bytes); \
+        hipLaunchKernelGGL((tap_gemm6_kernel<WGM, WGN, WMT, WN, NP>), dim3((unsigned)blocks), dim3(Cfg6::NT), Cfg6::lds_bytes, st, p, w6); \
+    } while (0)
 #define TAP6_CASE(WGM, WGN, WMT, WN)                                                                                    \
     do {                                                                                                                \
         using Cfg6 = Tap6Cfg<WGM, WGN, WMT, WN>;                                                                        \
         p.mtiles = cdiv(p.M, Cfg6::BM);                                                                                 \
         p.ntiles = p.N / Cfg6::BN;                                                                                      \
         const long long blocks = (long long)p.B * p.mtiles * p.ntiles;                                                  \
-        if (h->gemm_bf16) {                                                                                             \
-            if ((rc = ensure_lds(h, reinterpret_cast<const void*>(tap_gemm6_kernel<WGM, WGN, WMT, WN, 1>), Cfg6::lds_bytes))) return rc; \
-            ProfScope ps(h, st, (std::string("tap_gemm6_kernel<" #WGM ", " #WGN ", " #WMT ", " #WN ", 1>") + shape).c_str(), flops, bytes); \
-            hipLaunchKernelGGL((tap_gemm6_kernel<WGM, WGN, WMT, WN, 1>), dim3((unsigned)blocks), dim3(Cfg6::NT), Cfg6::lds_bytes, st, p, w6); \
-            break;                                                                                                      \
-        }                                                                                                               \
-        if ((rc = ensure_lds(h, reinterpret_cast<const void*>(tap_gemm6_kernel<WGM, WGN, WMT, WN>), Cfg6::lds_bytes))) return rc; \
-        ProfScope ps(h, st, (std::string("tap_gemm6_kernel<" #WGM ", " #WGN ", " #WMT ", " #WN ", 3>") + shape).c_str(), flops, bytes); \
-        hipLaunchKernelGGL((tap_gemm6_kernel<WGM, WGN, WMT, WN>), dim3((unsigned)blocks), dim3(Cfg6::NT), Cfg6::lds_bytes, st, p, w6);   \
+        if (h->gemm_bf16) TAP6_LAUNCH(WGM, WGN, WMT, WN, 1);                                                            \
+        else if (p.winv) TAP6_LAUNCH(WGM, WGN, WMT, WN, 2);                                                             \
+        else TAP6_LAUNCH(WGM, WGN, WMT, WN, 3);                                                                         \
     } while (0)
         // Tile / wave arrangement (measured, profiles/r2_tapgemm_variants.md).  The weight fragments come L2 -> registers and the
         // activation slab is shared through LDS, so the CU's vector-memory path and the LDS pipe are what an arrangement must
@@ -785,6 +955,7 @@ int run_tap(ac_handle* h, hipStream_t st, TapGemmParams& p) {
         else if (p.N % 96 == 0) TAP6_CASE(4, 1, 1, 3);
         else TAP6_CASE(2, 2, 2, 1);
 #undef TAP6_CASE
+#undef TAP6_LAUNCH
         HIPCHK(h, hipGetLastError());
         return AC_OK;
     }
@@ -810,7 +981,7 @@ struct Act2 {       // a layer output in up to two flavours (same shape/strides)
 };
 
 // the [64][128] layers on 64-float super-rows (thin_conv6.h); returns 1 when the shape does not qualify
-int try_thin6(ac_handle* h, hipStream_t st, const PackedGemm& g, const Act& x, int width, int edge, Out out, int B) {
+int try_thin6(ac_handle* h, hipStream_t st, const PackedGemm& g, const Act& x, int width, int edge, Out out, int B, const unsigned** amax_out = nullptr) {
     if (h->gemm_fp32 || g.N != 64 || g.Ktot != 128 || x.C != width || x.ts != width || x.bs != (long long)x.L * width ||
         (x.L * width) % 64 || x.L * width < 256 || !aligned16(x.p) || (long long)x.L * width * 4 > 0x70000000LL)
         return 1;
@@ -827,11 +998,20 @@ int try_thin6(ac_handle* h, hipStream_t st, const PackedGemm& g, const Act& x, i
     p.M = p.Ls;
     p.ntiles = cdiv(p.M, T6_BM);
     p.edge = edge;
+    const bool s16 = h->t6inv_of.count(g.w_off) != 0;
+    if (s16) {
+        p.amax_in = amax_of(h, st, x.p, x.bs, x.ts, x.L, x.C, B, x.amax_n == B ? x.amax : nullptr);
+        if (!p.amax_in) return fail(h, AC_ESTATE, "out of amax slots (split16.h)");
+        p.winv = h->blob + h->t6inv_of[g.w_off];
+        p.amax_out = amax_new(h);
+        if (amax_out) *amax_out = p.amax_out;
+    }
     const long long total = (long long)B * p.ntiles;
     const int grid = (int)std::min<long long>(total, 4 * 256);   // persistent, four workgroups per CU
     ProfScope ps(h, st, "thin_conv6_kernel", 2.0 * B * p.M * 64.0 * 128.0,
                  (double)B * p.M * 256.0 * (1 + (out.raw ? 1 : 0) + (out.elu ? 1 : 0)));
     if (h->gemm_bf16) hipLaunchKernelGGL(thin_conv6_kernel<1>, dim3(grid), dim3(256), T6_LDS, st, p);
+    else if (s16) hipLaunchKernelGGL(thin_conv6_kernel<2>, dim3(grid), dim3(256), T6_LDS, st, p);
     else hipLaunchKernelGGL(thin_conv6_kernel<3>, dim3(grid), dim3(256), T6_LDS, st, p);
     return AC_OK;
 }
@@ -842,11 +1022,12 @@ int conv_fwd(ac_handle* h, hipStream_t st, const PackedGemm& g, const Act& x, in
     const int M = cdiv(x.L, s);
     const int extra = M * s - x.L;
     if (s == 2 && k == 4 && !rel_len && extra == 0 && x.L >= 4 && out_rs == 64 && out_bs == (long long)M * 64 && !h->noncausal) {
-        const int rc = try_thin6(h, st, g, x, 32, 1, out, B);
+        const unsigned* am = nullptr;
+        const int rc = try_thin6(h, st, g, x, 32, 1, out, B, &am);
         if (rc <= 0) {
             if (y && !rc) {
-                y->raw = Act{out.raw, out_bs, out_rs, M, g.N};
-                y->elu = Act{out.elu, out_bs, out_rs, M, g.N};
+                y->raw = Act{out.raw, out_bs, out_rs, M, g.N, am, B};
+                y->elu = Act{out.elu, out_bs, out_rs, M, g.N, am, B};
             }
             if (!rc) HIPCHK(h, hipGetLastError());
             return rc;
@@ -871,21 +1052,23 @@ int conv_fwd(ac_handle* h, hipStream_t st, const PackedGemm& g, const Act& x, in
     p.M = M;
     p.N = g.N;
     p.Ktot = g.Ktot;
+    const int rc = run_tap(h, st, p);
     if (y) {
-        y->raw = Act{out.raw, out_bs, out_rs, M, g.N};
-        y->elu = Act{out.elu, out_bs, out_rs, M, g.N};
+        y->raw = Act{out.raw, out_bs, out_rs, M, g.N, p.amax_out, p.B};
+        y->elu = Act{out.elu, out_bs, out_rs, M, g.N, p.amax_out, p.B};
     }
-    return run_tap(h, st, p);
+    return rc;
 }
 
 int convtr_fwd(ac_handle* h, hipStream_t st, const PackedGemm& g, const Act& x, int s, Out out, int B, Act2* y) {
     const int cout = g.N / s;
     if (s == 2) {
-        const int rc = try_thin6(h, st, g, x, 64, 0, out, B);
+        const unsigned* am = nullptr;
+        const int rc = try_thin6(h, st, g, x, 64, 0, out, B, &am);
         if (rc <= 0) {
             if (!rc) {
-                y->raw = Act{out.raw, (long long)x.L * s * cout, cout, x.L * s, cout};
-                y->elu = Act{out.elu, (long long)x.L * s * cout, cout, x.L * s, cout};
+                y->raw = Act{out.raw, (long long)x.L * s * cout, cout, x.L * s, cout, am, B};
+                y->elu = Act{out.elu, (long long)x.L * s * cout, cout, x.L * s, cout, am, B};
                 HIPCHK(h, hipGetLastError());
             }
             return rc;
@@ -904,9 +1087,10 @@ int convtr_fwd(ac_handle* h, hipStream_t st, const PackedGemm& g, const Act& x, 
     p.M = x.L;
     p.N = g.N;
     p.Ktot = g.Ktot;
-    y->raw = Act{out.raw, (long long)x.L * s * cout, cout, x.L * s, cout};
-    y->elu = Act{out.elu, (long long)x.L * s * cout, cout, x.L * s, cout};
-    return run_tap(h, st, p);
+    const int rc = run_tap(h, st, p);
+    y->raw = Act{out.raw, (long long)x.L * s * cout, cout, x.L * s, cout, p.amax_out, p.B};
+    y->elu = Act{out.elu, (long long)x.L * s * cout, cout, x.L * s, cout, p.amax_out, p.B};
+    return rc;
 }
 
 template <int C, int BM, int NSPLIT, bool SC = true>
@@ -939,8 +1123,21 @@ int launch_rb_fused(ac_handle* h, hipStream_t st, const ResBlockPlan& rb, const 
 }
 
 // split-operand version of the fused block (rb_fused6.h); reads the raw rows only and activates them itself
+// split16.h operands of a fused block launch; false when the block's images are bf16 planes
+bool rb_split16(ac_handle* h, hipStream_t st, const ResBlockPlan& rb, const Act2& x, int B, RbFused6Params& p, const unsigned** amax_out) {
+    if (!h->split16 || h->gemm_bf16 || h->gemm_fp32 || !rb.winv3_off) return false;
+    p.amax_in = amax_of(h, st, x.raw.p, x.raw.bs, x.raw.ts, x.raw.L, x.raw.C, B, x.raw.amax_n == B ? x.raw.amax : nullptr);
+    p.winv3 = h->blob + rb.winv3_off;
+    p.winvf = h->blob + rb.winvf_off;
+    p.hb0 = rb.hb0;
+    p.hb1 = rb.hb1;
+    p.amax_out = amax_new(h);
+    if (amax_out) *amax_out = p.amax_out;
+    return true;
+}
+
 template <int C, bool SC>
-int launch_rb_fused6(ac_handle* h, hipStream_t st, const ResBlockPlan& rb, const Act2& x, Out out, int B, int pad = PAD_REFLECT) {
+int launch_rb_fused6(ac_handle* h, hipStream_t st, const ResBlockPlan& rb, const Act2& x, Out out, int B, int pad = PAD_REFLECT, const unsigned** amax_out = nullptr) {
     using Cfg = Rb6Cfg<C, SC>;
     RbFused6Params p{};
     p.xr = x.raw.p;
@@ -957,7 +1154,9 @@ int launch_rb_fused6(ac_handle* h, hipStream_t st, const ResBlockPlan& rb, const
     p.ntiles = cdiv(x.raw.L, Cfg::BM);
     p.pad = pad;
     if (const char* d = std::getenv("AC_RB6_DBG")) p.dbg = std::atoi(d);
-    if (int rc = ensure_lds(h, h->gemm_bf16 ? reinterpret_cast<const void*>(rb_fused6_kernel<C, SC, 1>) : reinterpret_cast<const void*>(rb_fused6_kernel<C, SC, 3>), Cfg::lds_bytes)) return rc;
+    const bool s16 = rb_split16(h, st, rb, x, B, p, amax_out);
+    if (s16 && !p.amax_in) return fail(h, AC_ESTATE, "out of amax slots (split16.h)");
+    if (int rc = ensure_lds(h, h->gemm_bf16 ? reinterpret_cast<const void*>(rb_fused6_kernel<C, SC, 1>) : s16 ? reinterpret_cast<const void*>(rb_fused6_kernel<C, SC, 2>) : reinterpret_cast<const void*>(rb_fused6_kernel<C, SC, 3>), Cfg::lds_bytes)) return rc;
     const long long total = (long long)B * p.ntiles;
     const int per_cu = C == 64 ? 2 : 3;
     const int grid = (int)std::min<long long>(total, (long long)per_cu * 256);   // persistent
@@ -966,13 +1165,14 @@ int launch_rb_fused6(ac_handle* h, hipStream_t st, const ResBlockPlan& rb, const
                  2.0 * B * L * ((double)(C / 2) * 3 * C + (double)C * (C / 2 + (SC ? C : 0))),
                  (double)B * L * C * 4.0 * (1 + (out.raw ? 1 : 0) + (out.elu ? 1 : 0)));
     if (h->gemm_bf16) hipLaunchKernelGGL((rb_fused6_kernel<C, SC, 1>), dim3(grid), dim3(256), Cfg::lds_bytes, st, p);
+    else if (s16) hipLaunchKernelGGL((rb_fused6_kernel<C, SC, 2>), dim3(grid), dim3(256), Cfg::lds_bytes, st, p);
     else hipLaunchKernelGGL((rb_fused6_kernel<C, SC, 3>), dim3(grid), dim3(256), Cfg::lds_bytes, st, p);
     return AC_OK;
 }
 
 // the 128-channel block as one 8-wave workgroup per CU (rb_fused6_128.h)
 template <bool SC>
-int launch_rb128_fused6(ac_handle* h, hipStream_t st, const ResBlockPlan& rb, const Act2& x, Out out, int B, int pad = PAD_REFLECT) {
+int launch_rb128_fused6(ac_handle* h, hipStream_t st, const ResBlockPlan& rb, const Act2& x, Out out, int B, int pad = PAD_REFLECT, const unsigned** amax_out = nullptr) {
     using Cfg = Rb128Cfg<SC>;
     RbFused6Params p{};
     p.xr = x.raw.p;
@@ -988,7 +1188,9 @@ int launch_rb128_fused6(ac_handle* h, hipStream_t st, const ResBlockPlan& rb, co
     p.Lp = x.raw.L > p.lpad ? x.raw.L : p.lpad + 1;
     p.ntiles = cdiv(x.raw.L, Cfg::BM);
     p.pad = pad;
-    if (int rc = ensure_lds(h, h->gemm_bf16 ? reinterpret_cast<const void*>(rb128_fused6_kernel<SC, 1>) : reinterpret_cast<const void*>(rb128_fused6_kernel<SC, 3>), Cfg::lds_bytes)) return rc;
+    const bool s16 = rb_split16(h, st, rb, x, B, p, amax_out);
+    if (s16 && !p.amax_in) return fail(h, AC_ESTATE, "out of amax slots (split16.h)");
+    if (int rc = ensure_lds(h, h->gemm_bf16 ? reinterpret_cast<const void*>(rb128_fused6_kernel<SC, 1>) : s16 ? reinterpret_cast<const void*>(rb128_fused6_kernel<SC, 2>) : reinterpret_cast<const void*>(rb128_fused6_kernel<SC, 3>), Cfg::lds_bytes)) return rc;
     const long long total = (long long)B * p.ntiles;
     const int grid = (int)std::min<long long>(total, 256);   // persistent, one workgroup per CU
     const double L = x.raw.L;
@@ -996,6 +1198,7 @@ int launch_rb128_fused6(ac_handle* h, hipStream_t st, const ResBlockPlan& rb, co
                  2.0 * B * L * (64.0 * 384 + 128.0 * (64 + (SC ? 128 : 0))),
                  (double)B * L * 128 * 4.0 * (1 + (out.raw ? 1 : 0) + (out.elu ? 1 : 0)));
     if (h->gemm_bf16) hipLaunchKernelGGL((rb128_fused6_kernel<SC, 1>), dim3(grid), dim3(512), Cfg::lds_bytes, st, p);
+    else if (s16) hipLaunchKernelGGL((rb128_fused6_kernel<SC, 2>), dim3(grid), dim3(512), Cfg::lds_bytes, st, p);
     else hipLaunchKernelGGL((rb128_fused6_kernel<SC, 3>), dim3(grid), dim3(512), Cfg::lds_bytes, st, p);
     return AC_OK;
 }
@@ -1006,12 +1209,13 @@ bool rb128_ok(const ac_handle* h, const ResBlockPlan& rb) { return rb.C == 128 &
 int resblock_fwd(ac_handle* h, hipStream_t st, const ResBlockPlan& rb, const Act2& x, float* hbuf, Out out, int B, Act2* y) {
     if (rb128_ok(h, rb) && h->cfg.residual_kernel_size == 3 && h->cfg.compress == 2 && x.raw.ts == 128 &&
         x.raw.bs == (long long)x.raw.L * 128 && aligned16(x.raw.p) && (long long)x.raw.L * 512 < 0x70000000LL) {
-        int rc = launch_rb128_fused6<true>(h, st, rb, x, out, B);
+        const unsigned* am = nullptr;
+        int rc = launch_rb128_fused6<true>(h, st, rb, x, out, B, PAD_REFLECT, &am);
         if (rc) return rc;
         HIPCHK(h, hipGetLastError());
         const long long bs = (long long)x.raw.L * 128;
-        y->raw = Act{out.raw, bs, 128, x.raw.L, 128};
-        y->elu = Act{out.elu, bs, 128, x.raw.L, 128};
+        y->raw = Act{out.raw, bs, 128, x.raw.L, 128, am, B};
+        y->elu = Act{out.elu, bs, 128, x.raw.L, 128, am, B};
         return AC_OK;
     }
     // thin stages: one fused kernel, hidden activation never leaves the CU
@@ -1020,13 +1224,14 @@ int resblock_fwd(ac_handle* h, hipStream_t st, const ResBlockPlan& rb, const Act
         x.raw.bs == (long long)x.raw.L * rb.C && aligned16(x.raw.p) &&
         (!x.elu.p || (x.elu.ts == rb.C && x.elu.bs == x.raw.bs && aligned16(x.elu.p)))) {
         int rc;
-        if (rb.has6 && !h->gemm_fp32) rc = rb.C == 32 ? launch_rb_fused6<32, true>(h, st, rb, x, out, B) : launch_rb_fused6<64, true>(h, st, rb, x, out, B);
+        const unsigned* am = nullptr;
+        if (rb.has6 && !h->gemm_fp32) rc = rb.C == 32 ? launch_rb_fused6<32, true>(h, st, rb, x, out, B, PAD_REFLECT, &am) : launch_rb_fused6<64, true>(h, st, rb, x, out, B, PAD_REFLECT, &am);
         else rc = rb.C == 32 ? launch_rb_fused<32, 128, 1>(h, st, rb, x, out, B) : launch_rb_fused<64, 64, 2>(h, st, rb, x, out, B);   // <C, rows per tile, column split>
         if (rc) return rc;
         HIPCHK(h, hipGetLastError());
         const long long bs = (long long)x.raw.L * rb.C;
-        y->raw = Act{out.raw, bs, rb.C, x.raw.L, rb.C};
-        y->elu = Act{out.elu, bs, rb.C, x.raw.L, rb.C};
+        y->raw = Act{out.raw, bs, rb.C, x.raw.L, rb.C, am, B};
+        y->elu = Act{out.elu, bs, rb.C, x.raw.L, rb.C, am, B};
         return AC_OK;
     }
     Act2 hv;
@@ -1047,9 +1252,10 @@ int resblock_fwd(ac_handle* h, hipStream_t st, const ResBlockPlan& rb, const Act
     p.M = x.raw.L;
     p.N = rb.C;
     p.Ktot = rb.fused.Ktot;
-    y->raw = Act{out.raw, p.y_bs, p.y_rs, x.raw.L, rb.C};
-    y->elu = Act{out.elu, p.y_bs, p.y_rs, x.raw.L, rb.C};
-    return run_tap(h, st, p);
+    rc = run_tap(h, st, p);
+    y->raw = Act{out.raw, p.y_bs, p.y_rs, x.raw.L, rb.C, p.amax_out, p.B};
+    y->elu = Act{out.elu, p.y_bs, p.y_rs, x.raw.L, rb.C, p.amax_out, p.B};
+    return rc;
 }
 
 // stem / head: dedicated HBM-bound kernels when the shape allows, tap-GEMM otherwise
@@ -1073,14 +1279,15 @@ int thin_stem(ac_handle* h, hipStream_t st, const PackedGemm& g, int F, int k, i
     p.k = k;
     p.Lp = Lp > 0 ? Lp : (T > k - 1 ? T : k);
     p.pad = pad;
+    p.amax_out = amax_new(h);
     {
         ProfScope ps(h, st, "stem_kernel", 2.0 * B * (double)T * F * k,
                      (double)B * T * 4.0 * (1 + F * ((out.raw ? 1 : 0) + (out.elu ? 1 : 0))));
         hipLaunchKernelGGL(stem_kernel, dim3(cdiv(T, STEM_TT), B), dim3(256), 0, st, p);
     }
     HIPCHK(h, hipGetLastError());
-    y->raw = Act{out.raw, (long long)T * F, F, T, F};
-    y->elu = Act{out.elu, (long long)T * F, F, T, F};
+    y->raw = Act{out.raw, (long long)T * F, F, T, F, p.amax_out, B};
+    y->elu = Act{out.elu, (long long)T * F, F, T, F, p.amax_out, B};
     return AC_OK;
 }
 
@@ -1228,8 +1435,9 @@ int lstm_fwd(ac_handle* h, hipStream_t st, const LstmPlan& lp, const Act& x, con
             tail(c0, q.B, nullptr);
         }
         HIPCHK(h, hipGetLastError());
-        y->raw = Act{out.raw, (long long)T * D, D, T, D};
-        y->elu = Act{out.elu, (long long)T * D, D, T, D};
+        const unsigned* am = amax_plus(h, st, x, 1.0f, B);   // |lstm(x) + x| <= 1 + amax(x)
+        y->raw = Act{out.raw, (long long)T * D, D, T, D, am, B};
+        y->elu = Act{out.elu, (long long)T * D, D, T, D, am, B};
         return AC_OK;
     }
     {
@@ -1288,8 +1496,9 @@ int lstm_fwd(ac_handle* h, hipStream_t st, const LstmPlan& lp, const Act& x, con
         }
     }
     HIPCHK(h, hipGetLastError());
-    y->raw = Act{out.raw, (long long)T * D, D, T, D};
-    y->elu = Act{out.elu, (long long)T * D, D, T, D};
+    const unsigned* am = amax_plus(h, st, x, 1.0f, B);
+    y->raw = Act{out.raw, (long long)T * D, D, T, D, am, B};
+    y->elu = Act{out.elu, (long long)T * D, D, T, D, am, B};
     return AC_OK;
 }
 
@@ -1755,7 +1964,7 @@ static int upload_blob(ac_handle* h, Packer& pk, int device) {
 int ac_set_precision(ac_handle* h, int precision) {
     if (!h) return AC_EINVAL;
     if (h->finalized) return fail(h, AC_ESTATE, "ac_set_precision must precede ac_finalize (weights are packed for one arithmetic)");
-    if (precision < AC_PRECISION_FP32 || precision > AC_PRECISION_BF16) return fail(h, AC_EINVAL, "unknown precision %d", precision);
+    if (precision < AC_PRECISION_FP32 || precision > AC_PRECISION_FP32_BF16X3) return fail(h, AC_EINVAL, "unknown precision %d", precision);
     h->precision = precision;
     return AC_OK;
 }
@@ -1767,10 +1976,12 @@ int ac_finalize(ac_handle* h) {
         int pr = h->precision;
         if (pr < 0) {
             const char* gm = std::getenv("AC_GEMM");
-            pr = gm && std::strcmp(gm, "fp32") == 0 ? AC_PRECISION_FP32_EXACT : gm && std::strcmp(gm, "bf16") == 0 ? AC_PRECISION_BF16 : AC_PRECISION_FP32;
+            pr = gm && std::strcmp(gm, "fp32") == 0 ? AC_PRECISION_FP32_EXACT : gm && std::strcmp(gm, "bf16") == 0 ? AC_PRECISION_BF16 :
+                 gm && std::strcmp(gm, "bf16x3") == 0 ? AC_PRECISION_FP32_BF16X3 : AC_PRECISION_FP32;
         }
         h->gemm_fp32 = pr == AC_PRECISION_FP32_EXACT;
         h->gemm_bf16 = pr == AC_PRECISION_BF16;
+        h->split16 = pr == AC_PRECISION_FP32;
     }
     if (h->arch == ARCH_MIMI) {
         Packer pk{h};
@@ -1922,6 +2133,7 @@ size_t ac_quantizer_workspace_bytes(const ac_handle* h, int B, int N) {
 int ac_encode_feats(ac_handle* h, const float* sig, const float* rel_len, int B, int T, float* feats, void* ws, size_t ws_bytes, void* stream) {
     int rc = check_ready(h);
     if (rc) return rc;
+    if ((rc = amax_begin(h, (hipStream_t)stream, B))) return rc;
     if (!sig || !feats || B < 1 || T < 1) return fail(h, AC_EINVAL, "ac_encode_feats: bad argument (B=%d, T=%d)", B, T);
     if ((rc = check_len(h, T))) return rc;
     if (!h->has_enc) return fail(h, AC_ESTATE, "ac_encode_feats: the handle was loaded without encoder weights (mode=\"decode\")");
@@ -1936,6 +2148,7 @@ int ac_encode_feats(ac_handle* h, const float* sig, const float* rel_len, int B,
 int ac_encode(ac_handle* h, const float* sig, const float* rel_len, int B, int T, int K, int64_t* toks, void* ws, size_t ws_bytes, void* stream) {
     int rc = check_ready(h);
     if (rc) return rc;
+    if ((rc = amax_begin(h, (hipStream_t)stream, B))) return rc;
     if (!sig || !toks || B < 1 || T < 1) return fail(h, AC_EINVAL, "ac_encode: bad argument (B=%d, T=%d)", B, T);
     if (K < 1 || K > num_q(h)) return fail(h, AC_EINVAL, "ac_encode: K=%d outside [1, %d]", K, num_q(h));
     if ((rc = check_len(h, T))) return rc;
@@ -1968,6 +2181,7 @@ int ac_encode(ac_handle* h, const float* sig, const float* rel_len, int B, int T
 int ac_quantize_ws(ac_handle* h, const float* feats, int B, int N, int K, int64_t* toks, void* ws, size_t ws_bytes, void* stream) {
     int rc = check_ready(h);
     if (rc) return rc;
+    if ((rc = amax_begin(h, (hipStream_t)stream, B))) return rc;
     if (!feats || !toks || B < 1 || N < 1 || K < 1 || K > num_q(h)) return fail(h, AC_EINVAL, "ac_quantize: bad argument");
     if (h->arch == ARCH_DAC) return dac_vq_encode(h, (hipStream_t)stream, feats, B * N, K, reinterpret_cast<long long*>(toks), nullptr);
     if (h->arch == ARCH_MIMI) {
@@ -1989,6 +2203,7 @@ int ac_quantize(ac_handle* h, const float* feats, int B, int N, int K, int64_t* 
 int ac_dequantize_ws(ac_handle* h, const int64_t* toks, int B, int N, int K, float* qfeats, void* ws, size_t ws_bytes, void* stream) {
     int rc = check_ready(h);
     if (rc) return rc;
+    if ((rc = amax_begin(h, (hipStream_t)stream, B))) return rc;
     if (!qfeats || !toks || B < 1 || N < 1 || K < 1 || K > num_q(h)) return fail(h, AC_EINVAL, "ac_dequantize: bad argument");
     if (h->arch == ARCH_DAC) return dac_from_codes(h, (hipStream_t)stream, reinterpret_cast<const long long*>(toks), B * N, K, qfeats);
     if (h->arch == ARCH_MIMI) {
@@ -2007,6 +2222,7 @@ int ac_dequantize(ac_handle* h, const int64_t* toks, int B, int N, int K, float*
 int ac_decode(ac_handle* h, const int64_t* toks, int B, int N, int K, float* sig, void* ws, size_t ws_bytes, void* stream) {
     int rc = check_ready(h);
     if (rc) return rc;
+    if ((rc = amax_begin(h, (hipStream_t)stream, B))) return rc;
     if (!sig || !toks || B < 1 || N < 1) return fail(h, AC_EINVAL, "ac_decode: bad argument (B=%d, N=%d)", B, N);
     if (K < 1 || K > num_q(h)) return fail(h, AC_EINVAL, "ac_decode: K=%d outside [1, %d]", K, num_q(h));
     if ((rc = check_len(h, ac_num_samples(h, N)))) return rc;
@@ -2057,6 +2273,7 @@ int ac_decode(ac_handle* h, const int64_t* toks, int B, int N, int K, float* sig
 int ac_decode_feats(ac_handle* h, const float* feats, int B, int N, float* sig, void* ws, size_t ws_bytes, void* stream) {
     int rc = check_ready(h);
     if (rc) return rc;
+    if ((rc = amax_begin(h, (hipStream_t)stream, B))) return rc;
     if (h->arch != ARCH_WAVTOK) return fail(h, AC_EINVAL, "ac_decode_feats: WavTokenizer handles only (the other wrappers do not implement _feats_to_sig)");
     if (!feats || !sig || B < 1 || N < 1) return fail(h, AC_EINVAL, "ac_decode_feats: bad argument (B=%d, N=%d)", B, N);
     if ((rc = check_len(h, ac_num_samples(h, N)))) return rc;
@@ -2070,6 +2287,7 @@ int ac_decode_feats(ac_handle* h, const float* feats, int B, int N, float* sig, 
 int ac_embs(ac_handle* h, int K, float* embs, void* stream) {
     int rc = check_ready(h);
     if (rc) return rc;
+    if ((rc = amax_begin(h, (hipStream_t)stream, 1))) return rc;
     if (!embs || K < 1 || K > num_q(h)) return fail(h, AC_EINVAL, "ac_embs: bad argument");
     size_t n, off;
     if (h->arch == ARCH_MIMI) { n = (size_t)K * h->mcfg.codebook_size * h->mcfg.codebook_dim; off = h->mimi.cb_plain; }
@@ -2082,6 +2300,7 @@ int ac_embs(ac_handle* h, int K, float* embs, void* stream) {
 int ac_embs_projected(ac_handle* h, int K, float* embs, void* stream) {
     int rc = check_ready(h);
     if (rc) return rc;
+    if ((rc = amax_begin(h, (hipStream_t)stream, 1))) return rc;
     if (h->arch == ARCH_DAC) {   // out_proj_k(codebook_k) + bias, tabulated at ac_finalize (dac.py:68-90)
         if (!embs || K < 1 || K > h->dcfg.n_codebooks) return fail(h, AC_EINVAL, "ac_embs_projected: bad argument");
         const size_t n = (size_t)K * h->dcfg.codebook_size * h->dac.H;
@@ -2104,6 +2323,7 @@ int ac_embs_projected(ac_handle* h, int K, float* embs, void* stream) {
 int ac_encode_quantized(ac_handle* h, const float* sig, int B, int T, int K, int64_t* toks, float* qfeats, void* ws, size_t ws_bytes, void* stream) {
     int rc = check_ready(h);
     if (rc) return rc;
+    if ((rc = amax_begin(h, (hipStream_t)stream, B))) return rc;
     if (h->arch != ARCH_DAC) return fail(h, AC_EINVAL, "ac_encode_quantized: DAC handles only (others: ac_encode + ac_dequantize_ws)");
     if (!sig || !toks || !qfeats || B < 1 || T < 1 || K < 1 || K > num_q(h)) return fail(h, AC_EINVAL, "ac_encode_quantized: bad argument");
     if ((rc = check_len(h, T))) return rc;
@@ -2113,6 +2333,7 @@ int ac_encode_quantized(ac_handle* h, const float* sig, int B, int T, int K, int
 int ac_encode_feats_latent(ac_handle* h, const float* sig, int B, int T, float* feats_latent, void* ws, size_t ws_bytes, void* stream) {
     int rc = check_ready(h);
     if (rc) return rc;
+    if ((rc = amax_begin(h, (hipStream_t)stream, B))) return rc;
     if (h->arch != ARCH_DAC) return fail(h, AC_EINVAL, "ac_encode_feats_latent: DAC handles only");
     if (!sig || !feats_latent || B < 1 || T < 1) return fail(h, AC_EINVAL, "ac_encode_feats_latent: bad argument");
     if ((rc = check_len(h, T))) return rc;
@@ -2208,6 +2429,7 @@ void ac_destroy(ac_handle* h) {
     if (!h) return;
     if (h->blob) (void)hipFree(h->blob);
     if (h->lp_ctl) (void)hipFree(h->lp_ctl);
+    if (h->amax_buf) (void)hipFree(h->amax_buf);
     if (h->sticky) (void)hipHostFree(h->sticky);
     if (h->clk_dev) (void)hipFree(h->clk_dev);
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);

@@ -34,7 +34,28 @@ struct RbFused6Params {
     int lpad;               // rows of left padding of the k3 conv: 2 = causal (EnCodec, Mimi), 1 = centred (WavTokenizer's non-causal SEANet)
     int dbg;                // developer timing modes (AC_RB6_DBG): 1 no stage-A MFMAs, 2 no stage-B MFMAs, 4 no staging,
                             // 8 no output stores, 16 no loads -- results are wrong in every mode but 0
+    // split16.h (NP = 2): amax slot [B] of x, optional slot of the output, per-output-channel 2^-s of the two weight
+    // matrices, and the bound of the hidden activation |ELU(conv_k3(ELU(x)) + b3)| <= hb0 + hb1 * amax(x)
+    // (hb0 = max |b3|, hb1 = largest row 1-norm of the k3 weights) from which its scale is taken
+    const unsigned* amax_in;
+    unsigned* amax_out;
+    const float* winv3;     // [C/2]
+    const float* winvf;     // [C]
+    float hb0, hb1;
 };
+
+// split16.h scales of one clip of a fused block: sx for ELU(x) in the k3 conv; sb for the hidden activation AND the raw x of
+// the second stage (they share an accumulator, so they share a scale)
+struct Rb16Scale {
+    float sx, sb, ix, ib;   // 2^s and 2^-s
+};
+__device__ __forceinline__ Rb16Scale rb16_scale(unsigned amax_x, float hb0, float hb1) {
+    const int ex = s16_exponent(amax_x);
+    const float hb = __fmaf_rn(hb1, __uint_as_float(amax_x), hb0) * 1.0000005f;
+    const int eh = s16_exponent(__float_as_uint(hb));
+    const int eb = eh < ex ? eh : ex;
+    return Rb16Scale{s16_pow2(ex), s16_pow2(eb), s16_pow2(-ex), s16_pow2(-eb)};
+}
 
 template <int C, bool SC>
 struct Rb6Cfg {
@@ -66,7 +87,11 @@ __device__ __forceinline__ void split3(float v, unsigned& h, unsigned& m, unsign
 // 4 fp32 -> 4 bf16 per plane, stored as 8 bytes at element offset `o` of each plane.  NP = 1 (the opt-in bf16 mode,
 // ac_set_precision): ONE plane, rounded to nearest-even -- no split.
 template <int NP = 3>
-__device__ __forceinline__ void split_store4(const f32x4 v, __bf16* p0, int plane, int o) {
+__device__ __forceinline__ void split_store4(const f32x4 v, __bf16* p0, int plane, int o, float scale = 1.f) {
+    if (NP == 2) {   // split16.h
+        split16_store4(v * scale, p0, plane, o);
+        return;
+    }
     if (NP == 1) {
         typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
         *reinterpret_cast<bf16x4_t*>(p0 + o) = __builtin_convertvector(v, bf16x4_t);
@@ -85,6 +110,11 @@ __device__ __forceinline__ void split_store4(const f32x4 v, __bf16* p0, int plan
 template <int NP = 3>
 __device__ __forceinline__ f32x4 mma6(const bf16x8 (&w)[3], const bf16x8 (&x)[3], f32x4 v) {
     if (NP == 1) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[0], x[0], v, 0, 0, 0);
+    if (NP == 2) {   // split16.h: lo hi, hi lo, hi hi on the fp16 pipe
+        v = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w[1]), __builtin_bit_cast(f16x8, x[0]), v, 0, 0, 0);
+        v = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w[0]), __builtin_bit_cast(f16x8, x[1]), v, 0, 0, 0);
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w[0]), __builtin_bit_cast(f16x8, x[0]), v, 0, 0, 0);
+    }
     v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[2], x[0], v, 0, 0, 0);   // l h
     v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[0], x[2], v, 0, 0, 0);   // h l
     v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[1], x[1], v, 0, 0, 0);   // m m
@@ -114,25 +144,30 @@ __global__ __launch_bounds__(256, C == 64 ? 2 : 3) void rb_fused6_kernel(const R
     const int na0 = ng * NA * 16, nb0 = ng * NB * 16;              // this wave's first output channel (stage A / B)
 
     // ---- this wave's weight fragments -> registers (once)
+    constexpr int WPL = NP == 2 ? 2 : 3;                           // planes in the weight images
     bf16x8 w3r[KSA][NA][3], wfr[KSB][NB][3];
     f32x4 b3v[NA], bfv[NB];
+    f32x4 i3v[NA], ifv[NB];                                        // split16: 2^-s of the weight rows
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int c = 0; c < NA; ++c) {
         b3v[c] = *reinterpret_cast<const f32x4*>(p.b3 + na0 + c * 16 + 4 * kq);
+        if (NP == 2) i3v[c] = *reinterpret_cast<const f32x4*>(p.winv3 + na0 + c * 16 + 4 * kq);
 #pragma unroll
         for (int ks = 0; ks < KSA; ++ks)
 #pragma unroll
             for (int pl = 0; pl < NP; ++pl)
-                w3r[ks][c][pl] = *reinterpret_cast<const bf16x8*>(p.w3f + ((((long long)(na0 / 16 + c) * KSA + ks) * 3 + pl) * 64 + lane) * 8);
+                w3r[ks][c][pl] = *reinterpret_cast<const bf16x8*>(p.w3f + ((((long long)(na0 / 16 + c) * KSA + ks) * WPL + pl) * 64 + lane) * 8);
     }
 #pragma unroll
     for (int c = 0; c < NB; ++c) {
         bfv[c] = *reinterpret_cast<const f32x4*>(p.bf + nb0 + c * 16 + 4 * kq);
+        if (NP == 2) ifv[c] = *reinterpret_cast<const f32x4*>(p.winvf + nb0 + c * 16 + 4 * kq);
 #pragma unroll
         for (int ks = 0; ks < KSB; ++ks)
 #pragma unroll
             for (int pl = 0; pl < NP; ++pl)
-                wfr[ks][c][pl] = *reinterpret_cast<const bf16x8*>(p.wff + ((((long long)(nb0 / 16 + c) * KSB + ks) * 3 + pl) * 64 + lane) * 8);
+                wfr[ks][c][pl] = *reinterpret_cast<const bf16x8*>(p.wff + ((((long long)(nb0 / 16 + c) * KSB + ks) * WPL + pl) * 64 + lane) * 8);
     }
     // hidden columns HC .. HCP-1 (C = 32) are K padding: zero once, the matching weight fragments are zero too
     if (HC < Cfg::HCP)
@@ -162,14 +197,16 @@ __global__ __launch_bounds__(256, C == 64 ? 2 : 3) void rb_fused6_kernel(const R
             rx[i] = bufload16(rs, ok ? j * (C * 4) + s_q4[i] : 0x7fff0000, 0);
         }
     };
-    auto store_tile = [&]() {
+    Rb16Scale sc{1.f, 1.f, 1.f, 1.f};                           // scales of the tile that is staged in LDS
+    auto store_tile = [&](int tile) {
+        if (NP == 2) sc = rb16_scale(p.amax_in[tile / p.ntiles], p.hb0, p.hb1);
 #pragma unroll
         for (int i = 0; i < SLOTS; ++i) {
             const int row = s_row[i], q = s_q4[i] / 16;
             if (row < Cfg::XE_ROWS) {
-                split_store4<NP>(elu4(rx[i]), Xe, Cfg::XE_PLANE, row * XP + 4 * q);
+                split_store4<NP>(elu4(rx[i]), Xe, Cfg::XE_PLANE, row * XP + 4 * q, sc.sx);
                 // rows lpad .. lpad + BM - 1 of the slab are the tile's own rows (source index t0 + row - lpad >= 0)
-                if (SC && row >= p.lpad && row < p.lpad + BM) split_store4<NP>(rx[i], Xr, Cfg::XR_PLANE, (row - p.lpad) * XP + 4 * q);
+                if (SC && row >= p.lpad && row < p.lpad + BM) split_store4<NP>(rx[i], Xr, Cfg::XR_PLANE, (row - p.lpad) * XP + 4 * q, sc.sb);
             }
         }
     };
@@ -177,10 +214,13 @@ __global__ __launch_bounds__(256, C == 64 ? 2 : 3) void rb_fused6_kernel(const R
     int tile = blockIdx.x;
     if (tile >= total) return;
     load_tile(tile);
-    store_tile();
+    store_tile(tile);
     __syncthreads();
+    unsigned omax = 0;
+    int omax_b = tile / p.ntiles;
     for (; tile < total; tile += gridDim.x) {
         const int next = tile + gridDim.x;
+        const Rb16Scale cs = sc;                                // this tile's scales (store_tile(next) replaces sc)
         if (next < total && !(p.dbg & 16)) load_tile(next);     // in flight during both MFMA stages
         // ---- stage A: hidden = ELU(conv_k3(xe) + b3) -> Hs planes
         {
@@ -188,7 +228,7 @@ __global__ __launch_bounds__(256, C == 64 ? 2 : 3) void rb_fused6_kernel(const R
 #pragma unroll
             for (int a = 0; a < MS; ++a)
 #pragma unroll
-                for (int c = 0; c < NA; ++c) acc[a][c] = b3v[c];
+                for (int c = 0; c < NA; ++c) acc[a][c] = NP == 2 ? zero4 : b3v[c];
             if (!(p.dbg & 1))
 #pragma unroll
             for (int ks = 0; ks < KSA; ++ks) {
@@ -207,8 +247,14 @@ __global__ __launch_bounds__(256, C == 64 ? 2 : 3) void rb_fused6_kernel(const R
 #pragma unroll
             for (int a = 0; a < MS; ++a)
 #pragma unroll
-                for (int c = 0; c < NA; ++c)
-                    split_store4<NP>(elu4(acc[a][c]), Hs, Cfg::H_PLANE, (r0 + a * 16 + li) * HP + na0 + c * 16 + 4 * kq);
+                for (int c = 0; c < NA; ++c) {
+                    if (NP == 2) {                               // back to true units: exact power-of-two factors, then the bias
+                        const f32x4 iv = i3v[c] * cs.ix;
+                        f32x4& v = acc[a][c];
+                        v = f32x4{__fmaf_rn(v.x, iv.x, b3v[c].x), __fmaf_rn(v.y, iv.y, b3v[c].y), __fmaf_rn(v.z, iv.z, b3v[c].z), __fmaf_rn(v.w, iv.w, b3v[c].w)};
+                    }
+                    split_store4<NP>(elu4(acc[a][c]), Hs, Cfg::H_PLANE, (r0 + a * 16 + li) * HP + na0 + c * 16 + 4 * kq, cs.sb);
+                }
         }
         if (NSPLIT > 1) __syncthreads();                        // C = 32: a wave reads back only its own rows
         // ---- stage B: y = [W1 | Ws] * [hidden | x]^T + bf
@@ -216,7 +262,7 @@ __global__ __launch_bounds__(256, C == 64 ? 2 : 3) void rb_fused6_kernel(const R
 #pragma unroll
         for (int a = 0; a < MS; ++a)
 #pragma unroll
-            for (int c = 0; c < NB; ++c) acc[a][c] = bfv[c];
+            for (int c = 0; c < NB; ++c) acc[a][c] = NP == 2 ? zero4 : bfv[c];
         if (!(p.dbg & 2))
 #pragma unroll
         for (int ks = 0; ks < KSB; ++ks) {
@@ -235,10 +281,15 @@ __global__ __launch_bounds__(256, C == 64 ? 2 : 3) void rb_fused6_kernel(const R
         __syncthreads();                                        // every wave is done reading the slabs
         // the next tile is staged BEFORE this tile's output stores are issued: the wait for its loads must not
         // cover the stores (the memory counter retires in order)
-        if (next < total && !(p.dbg & 4)) store_tile();
+        if (next < total && !(p.dbg & 4)) store_tile(next);
         // ---- output: lane (li, kq) holds channels nb0 + 16c + 4kq .. +3 of time row r0 + 16a + li
         if (!(p.dbg & 8)) {
             const int b = tile / p.ntiles, t0 = (tile % p.ntiles) * BM;
+            if (p.amax_out && b != omax_b) {                     // clip change: hand the finished clip's maximum over
+                amax_flush(omax, p.amax_out + omax_b);
+                omax = 0;
+                omax_b = b;
+            }
             const long long ob = (long long)b * p.L * C;
             const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)(p.y ? p.y + ob : nullptr), 0, p.y ? clip_bytes : 0, 0x00020000);
             const __amdgpu_buffer_rsrc_t re = __builtin_amdgcn_make_buffer_rsrc((void*)(p.y_elu ? p.y_elu + ob : nullptr), 0, p.y_elu ? clip_bytes : 0, 0x00020000);
@@ -251,10 +302,15 @@ __global__ __launch_bounds__(256, C == 64 ? 2 : 3) void rb_fused6_kernel(const R
                 for (int c = 0; c < NB; ++c) {
                     const int o = orow + (nb0 + c * 16 + 4 * kq) * 4;
                     f32x4 v = acc[a][c];
+                    if (NP == 2) {
+                        const f32x4 iv = ifv[c] * cs.ib;
+                        v = f32x4{__fmaf_rn(v.x, iv.x, bfv[c].x), __fmaf_rn(v.y, iv.y, bfv[c].y), __fmaf_rn(v.z, iv.z, bfv[c].z), __fmaf_rn(v.w, iv.w, bfv[c].w)};
+                    }
                     if (!SC) {                                   // identity shortcut: x + block(x)
                         const f32x4 xv = bufload16(rs, o, 0);
                         v = f32x4{__fadd_rn(xv.x, v.x), __fadd_rn(xv.y, v.y), __fadd_rn(xv.z, v.z), __fadd_rn(xv.w, v.w)};
                     }
+                    if (p.amax_out && t < p.L) amax_acc4(omax, v);
                     if (p.y) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), ry, o, 0, 0);
                     if (p.y_elu) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, elu4(v)), re, o, 0, 0);
                 }
@@ -262,6 +318,7 @@ __global__ __launch_bounds__(256, C == 64 ? 2 : 3) void rb_fused6_kernel(const R
         }
         __syncthreads();
     }
+    if (p.amax_out) amax_flush(omax, p.amax_out + omax_b);
 }
 
 }  // namespace ac

@@ -46,19 +46,26 @@ __global__ __launch_bounds__(512, 1) void rb128_fused6_kernel(const RbFused6Para
     const int total = p.B * p.ntiles;
 
     // ---- this wave's weight fragments -> registers (once)
+    constexpr int WPL = NP == 2 ? 2 : 3;                           // planes in the weight images
     bf16x8 w3r[KSA_W][3], wfr[KSB][3];
 #pragma unroll
     for (int i = 0; i < KSA_W; ++i)
 #pragma unroll
         for (int pl = 0; pl < NP; ++pl)
-            w3r[i][pl] = *reinterpret_cast<const bf16x8*>(p.w3f + ((((long long)ng * Cfg::KSA + kg * KSA_W + i) * 3 + pl) * 64 + lane) * 8);
+            w3r[i][pl] = *reinterpret_cast<const bf16x8*>(p.w3f + ((((long long)ng * Cfg::KSA + kg * KSA_W + i) * WPL + pl) * 64 + lane) * 8);
 #pragma unroll
     for (int ks = 0; ks < KSB; ++ks)
 #pragma unroll
         for (int pl = 0; pl < NP; ++pl)
-            wfr[ks][pl] = *reinterpret_cast<const bf16x8*>(p.wff + ((((long long)wave * KSB + ks) * 3 + pl) * 64 + lane) * 8);
+            wfr[ks][pl] = *reinterpret_cast<const bf16x8*>(p.wff + ((((long long)wave * KSB + ks) * WPL + pl) * 64 + lane) * 8);
     const f32x4 b3v = *reinterpret_cast<const f32x4*>(p.b3 + ng * 16 + 4 * kq);
     const f32x4 bfv = *reinterpret_cast<const f32x4*>(p.bf + wave * 16 + 4 * kq);
+    f32x4 i3v = {1.f, 1.f, 1.f, 1.f}, ifv = {1.f, 1.f, 1.f, 1.f};   // split16: 2^-s of this wave's weight rows
+    if (NP == 2) {
+        i3v = *reinterpret_cast<const f32x4*>(p.winv3 + ng * 16 + 4 * kq);
+        ifv = *reinterpret_cast<const f32x4*>(p.winvf + wave * 16 + 4 * kq);
+    }
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
     int s_row[SLOTS], s_q4[SLOTS];
 #pragma unroll
@@ -80,13 +87,15 @@ __global__ __launch_bounds__(512, 1) void rb128_fused6_kernel(const RbFused6Para
             rx[i] = bufload16(rs, ok ? j * (C * 4) + s_q4[i] : 0x7fff0000, 0);
         }
     };
-    auto store_tile = [&]() {
+    Rb16Scale sc{1.f, 1.f, 1.f, 1.f};                           // scales of the tile that is staged in LDS (rb_fused6.h)
+    auto store_tile = [&](int tile) {
+        if (NP == 2) sc = rb16_scale(p.amax_in[tile / p.ntiles], p.hb0, p.hb1);
 #pragma unroll
         for (int i = 0; i < SLOTS; ++i) {
             const int row = s_row[i], q = s_q4[i] / 16;
             if (row < Cfg::XE_ROWS) {
-                split_store4<NP>(elu4(rx[i]), Xe, Cfg::XE_PLANE, row * XP + 4 * q);
-                if (SC && row >= p.lpad && row < p.lpad + BM) split_store4<NP>(rx[i], Xr, Cfg::XR_PLANE, (row - p.lpad) * XP + 4 * q);
+                split_store4<NP>(elu4(rx[i]), Xe, Cfg::XE_PLANE, row * XP + 4 * q, sc.sx);
+                if (SC && row >= p.lpad && row < p.lpad + BM) split_store4<NP>(rx[i], Xr, Cfg::XR_PLANE, (row - p.lpad) * XP + 4 * q, sc.sb);
             }
         }
     };
@@ -94,16 +103,19 @@ __global__ __launch_bounds__(512, 1) void rb128_fused6_kernel(const RbFused6Para
     int tile = blockIdx.x;
     if (tile >= total) return;
     load_tile(tile);
-    store_tile();
+    store_tile(tile);
     __syncthreads();
+    unsigned omax = 0;
+    int omax_b = tile / p.ntiles;
     for (; tile < total; tile += gridDim.x) {
         const int next = tile + gridDim.x;
+        const Rb16Scale cs = sc;
         if (next < total) load_tile(next);                      // in flight during both MFMA stages
         // ---- stage A: this wave's half of K for hidden channels 16 ng ..
         {
             f32x4 acc[TT];
 #pragma unroll
-            for (int a = 0; a < TT; ++a) acc[a] = kg == 0 ? b3v : f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int a = 0; a < TT; ++a) acc[a] = (kg == 0 && NP != 2) ? b3v : zero4;
 #pragma unroll
             for (int i = 0; i < KSA_W; ++i) {
                 const int ks = kg * KSA_W + i;                   // k-step of 32 over k = tap * 128 + ci
@@ -129,8 +141,12 @@ __global__ __launch_bounds__(512, 1) void rb128_fused6_kernel(const RbFused6Para
 #pragma unroll
                 for (int a = 0; a < TT; ++a) {
                     const f32x4 u = *reinterpret_cast<const f32x4*>(&Ps[(a * 16 + li) * PSP + ng * 16 + 4 * kq]);
-                    const f32x4 v = f32x4{acc[a].x + u.x, acc[a].y + u.y, acc[a].z + u.z, acc[a].w + u.w};
-                    split_store4<NP>(elu4(v), Hs, Cfg::H_PLANE, (a * 16 + li) * HP + ng * 16 + 4 * kq);
+                    f32x4 v = f32x4{acc[a].x + u.x, acc[a].y + u.y, acc[a].z + u.z, acc[a].w + u.w};
+                    if (NP == 2) {                               // true units: exact power-of-two factors, then the bias
+                        const f32x4 iv = i3v * cs.ix;
+                        v = f32x4{__fmaf_rn(v.x, iv.x, b3v.x), __fmaf_rn(v.y, iv.y, b3v.y), __fmaf_rn(v.z, iv.z, b3v.z), __fmaf_rn(v.w, iv.w, b3v.w)};
+                    }
+                    split_store4<NP>(elu4(v), Hs, Cfg::H_PLANE, (a * 16 + li) * HP + ng * 16 + 4 * kq, cs.sb);
                 }
             }
         }
@@ -138,7 +154,7 @@ __global__ __launch_bounds__(512, 1) void rb128_fused6_kernel(const RbFused6Para
         // ---- stage B: y = [W1 | Ws] * [hidden | x]^T + bf, output channels 16 wave ..
         f32x4 acc[TT];
 #pragma unroll
-        for (int a = 0; a < TT; ++a) acc[a] = bfv;
+        for (int a = 0; a < TT; ++a) acc[a] = NP == 2 ? zero4 : bfv;
 #pragma unroll
         for (int ks = 0; ks < KSB; ++ks) {
 #pragma unroll
@@ -155,9 +171,14 @@ __global__ __launch_bounds__(512, 1) void rb128_fused6_kernel(const RbFused6Para
             }
         }
         __syncthreads();                                        // every wave is done reading the slabs
-        if (next < total) store_tile();                         // staged before the output stores are issued (rb_fused6.h)
+        if (next < total) store_tile(next);                     // staged before the output stores are issued (rb_fused6.h)
         {
             const int b = tile / p.ntiles, t0 = (tile % p.ntiles) * BM;
+            if (p.amax_out && b != omax_b) {                     // clip change: hand the finished clip's maximum over
+                amax_flush(omax, p.amax_out + omax_b);
+                omax = 0;
+                omax_b = b;
+            }
             const long long ob = (long long)b * p.L * C;
             const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)(p.y ? p.y + ob : nullptr), 0, p.y ? clip_bytes : 0, 0x00020000);
             const __amdgpu_buffer_rsrc_t re = __builtin_amdgcn_make_buffer_rsrc((void*)(p.y_elu ? p.y_elu + ob : nullptr), 0, p.y_elu ? clip_bytes : 0, 0x00020000);
@@ -167,16 +188,22 @@ __global__ __launch_bounds__(512, 1) void rb128_fused6_kernel(const RbFused6Para
                 const int t = t0 + a * 16 + li;
                 const int o = (t < p.L ? t * (C * 4) : 0x7fff0000) + (wave * 16 + 4 * kq) * 4;   // rows past the clip: dropped
                 f32x4 v = acc[a];
+                if (NP == 2) {
+                    const f32x4 iv = ifv * cs.ib;
+                    v = f32x4{__fmaf_rn(v.x, iv.x, bfv.x), __fmaf_rn(v.y, iv.y, bfv.y), __fmaf_rn(v.z, iv.z, bfv.z), __fmaf_rn(v.w, iv.w, bfv.w)};
+                }
                 if (!SC) {                                       // identity shortcut: x + block(x)
                     const f32x4 xv = bufload16(rs, o, 0);
                     v = f32x4{__fadd_rn(xv.x, v.x), __fadd_rn(xv.y, v.y), __fadd_rn(xv.z, v.z), __fadd_rn(xv.w, v.w)};
                 }
+                if (p.amax_out && t < p.L) amax_acc4(omax, v);
                 if (p.y) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), ry, o, 0, 0);
                 if (p.y_elu) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, elu4(v)), re, o, 0, 0);
             }
         }
         __syncthreads();
     }
+    if (p.amax_out) amax_flush(omax, p.amax_out + omax_b);
 }
 
 }  // namespace ac

@@ -1,0 +1,98 @@
+// split16: fp32-fidelity products on the fp16 matrix pipe with TWO planes per operand and THREE partial products.
+//
+//   x * 2^s = hi + lo,   hi = fp16_rn(x * 2^s),   lo = fp16_rn(x * 2^s - hi)            (|lo| <= 2^-12 |x 2^s|)
+//   a * b  ~=  (a_hi b_hi + a_hi b_lo + a_lo b_hi) * 2^-(sa + sb)                          (a_lo b_lo <= 2^-24 |a b| dropped)
+//
+// hi carries 11 significand bits, the residual of a round-to-nearest is itself below half an ulp and lo carries its
+// leading 11 bits: the pair represents x to 2^-24 relative -- the precision of the fp32 value -- wherever lo is a normal
+// fp16 number, and to 2^-25 ABSOLUTE (of the scaled value) below that: v_mfma_f32_*_f16 keeps fp16 denormal inputs
+// (tools/ubench/mfma_f16_probe.hip).  Products of fp16 values are exact in the fp32 accumulator.  Against the three-plane bf16
+// split of tap_gemm6.h (6 partial products) this is half the MFMAs and two thirds of the operand bytes at the same error
+// (K = 1536 dot products of random data, rms error / rms value: fp32 chain 1.8e-7, bf16 x 3 1.9e-7, fp16 x 2 1.9e-7).
+//
+// What fp16 lacks is range, so every operand carries a power-of-two scale (multiplying by it is exact):
+//   * weights: one scale per OUTPUT CHANNEL, chosen offline from the row's largest magnitude; 2^-s comes back in the epilogue;
+//   * activations: one scale per CLIP and tensor, from the tensor's largest magnitude ("amax", bits of |x| as an unsigned
+//     int -- ordered like the values, NaN above everything) which the PRODUCING kernel leaves in an amax slot by atomicMax
+//     (one per wave, skipped when the slot already holds more), or a bound derived from it (ELU never grows a magnitude;
+//     |conv(x)| <= |b| + ||w||_1 amax(x) inside the fused blocks; LSTM output <= 1 + amax(skip); codebook sums).
+//     Scaled magnitudes stay below 2^15, so elements down to 2^-16 of the clip's largest keep fp32-grade RELATIVE
+//     precision and everything smaller an absolute error of 2^-40 of the largest -- far below the rounding of the fp32
+//     accumulation it feeds.  inf / NaN elements do not enter the amax: they convert to fp16 inf / NaN and propagate, the
+//     clip's finite part keeps its scale.
+// A tensor whose producer does not report an amax gets one from amax_kernel (one extra read) -- never a guess.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ac {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+typedef float s16_f32x4 __attribute__((ext_vector_type(4)));
+
+// scale exponent for a tensor whose largest magnitude has the bits `amax_bits` (sign cleared): |x| 2^s < 2^15
+// (clamped to +-lim: 80 for activations, 40 for weight rows -- the product of the two inverse scales stays a normal fp32)
+__host__ __device__ __forceinline__ int s16_exponent(unsigned amax_bits, int lim = 80) {
+    const int e = (int)((amax_bits >> 23) & 0xffu);
+    if (e == 255) return 0;                 // (a bound that overflowed: scale 1)
+    int s = 141 - e;                        // |x| < 2^(e - 126)  ->  |x| 2^s < 2^15
+    return s > lim ? lim : (s < -lim ? -lim : s);
+}
+__host__ __device__ __forceinline__ float s16_pow2(int s) {
+    union { unsigned u; float f; } c;
+    c.u = (unsigned)(s + 127) << 23;
+    return c.f;
+}
+
+// |v| bits into a running maximum
+__device__ __forceinline__ void amax_acc(unsigned& mx, float v) {
+    const unsigned b = __float_as_uint(v) & 0x7fffffffu;
+    mx = (b > mx && b < 0x7f800000u) ? b : mx;     // the largest FINITE magnitude: inf / NaN elements stay what they are in fp16
+}
+__device__ __forceinline__ void amax_acc4(unsigned& mx, const s16_f32x4 v) {
+    amax_acc(mx, v.x); amax_acc(mx, v.y); amax_acc(mx, v.z); amax_acc(mx, v.w);
+}
+// wave maximum -> slot (one atomic per wave at most; none when the slot already holds at least as much)
+__device__ __forceinline__ void amax_flush(unsigned mx, unsigned* slot) {
+#pragma unroll
+    for (int o = 32; o; o >>= 1) {
+        const unsigned t = (unsigned)__shfl_xor((int)mx, o);
+        mx = t > mx ? t : mx;
+    }
+    if ((threadIdx.x & 63) == 0 && mx > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, mx);
+}
+
+// 4 scaled fp32 values -> hi / lo fp16 planes, 8 bytes each at element offset `o` (planes `plane` elements apart)
+__device__ __forceinline__ void split16_store4(const s16_f32x4 v, void* p0, int plane, int o) {
+    const f16x4_t hi = __builtin_convertvector(v, f16x4_t);
+    const s16_f32x4 r = v - __builtin_convertvector(hi, s16_f32x4);
+    const f16x4_t lo = __builtin_convertvector(r, f16x4_t);
+    *reinterpret_cast<f16x4_t*>(reinterpret_cast<_Float16*>(p0) + o) = hi;
+    *reinterpret_cast<f16x4_t*>(reinterpret_cast<_Float16*>(p0) + plane + o) = lo;
+}
+
+// Fallback for tensors whose producer reports no amax: slot[b] = max |x[b]| over [L][C] rows of pitch ts.
+__global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, long long bs, long long ts, int L, int C, unsigned* __restrict__ slot) {
+    const int b = blockIdx.y;
+    const float* xb = x + (long long)b * bs;
+    const long long n = (long long)L * C;
+    unsigned mx = 0;
+    if (ts == C && (C & 3) == 0 && ((reinterpret_cast<uintptr_t>(xb) & 15) == 0)) {
+        const s16_f32x4* v = reinterpret_cast<const s16_f32x4*>(xb);
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n / 4; i += (long long)gridDim.x * 256) amax_acc4(mx, v[i]);
+    } else {
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) amax_acc(mx, xb[(i / C) * ts + i % C]);
+    }
+    amax_flush(mx, slot + b);
+}
+
+// slot_out[b] = bits of (|a| + add): the bound of a sum whose second term is bounded by `add` (LSTM skip: h in (-1, 1))
+__global__ void amax_add_kernel(const unsigned* __restrict__ in, float add, unsigned* __restrict__ out, int B) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const unsigned v = in[b];
+    out[b] = ((v >> 23) & 0xffu) == 255 ? v : __float_as_uint((__uint_as_float(v) + add) * 1.0000002f);   // rounded up
+}
+
+}  // namespace ac

@@ -49,6 +49,8 @@ struct TapSeg {
     int pad;            // left padding in time steps: output row m, tap j, in-row step tp reads time
     int dil;            //   t = (m + j*dil)*s + tp - pad      (causal k-tap conv: pad = (J-1)*s, dil = 1;
                         //   DAC: symmetric pad 3*dil for the dilated k7 conv, ceil(s/2) for the strided ones)
+    const unsigned* amax;   // split16.h: [B] largest-magnitude bits of this tensor (fp16 two-plane arithmetic only)
+    int amax_n;             //   clips the slot covers (host side only)
 };
 
 struct TapGemmParams {
@@ -79,6 +81,10 @@ struct TapGemmParams {
     int tanh_out;
     long long y_off, y_len;
     int n_valid;        // > 0: only columns n < n_valid are stored (N is padded to the tile width with zero weight rows)
+    // split16.h (tap_gemm6 NP = 2): per-output-channel 2^-s of the weight rows; optional amax slot [B] of the output
+    // (largest magnitude over the raw and the activated flavour)
+    const float* winv;
+    unsigned* amax_out;
     unsigned long long* clk;   // diagnostics (ac_debug_clock): [0] += shader-clock ticks, [1] += 100 MHz real-time ticks of
                                // every workgroup of a tap_gemm6 launch; null = off
 };

@@ -18,6 +18,7 @@
 // The exact-product kernel tap_gemm4 stays selectable (environment AC_GEMM=fp32) and serves every other shape.
 #pragma once
 #include "tap_gemm4.h"
+#include "split16.h"
 
 namespace ac {
 
@@ -43,6 +44,9 @@ struct Tap6Cfg {
 // NP = 3: split-operand arithmetic (three bf16 planes per operand, 6 partial products): fp32 fidelity -- the default.
 // NP = 1: the opt-in bf16 mode (ac_set_precision(AC_PRECISION_BF16)): operands ROUNDED to bf16 (nearest-even), one product,
 //         fp32 accumulate; the weight image then holds round(w) in plane 0.  Never the parity path.
+// NP = 2: split16.h -- two fp16 planes per operand, 3 partial products, per-clip / per-output-channel power-of-two scales:
+//         the same fp32 fidelity at half the MFMAs and two thirds of the operand bytes.  Weight image
+//         [n-tile of 32][k-step of 16][plane 2][lane 64][8 fp16] of the SCALED rows; needs seg[].amax and winv.
 template <int WGM, int WGN, int WMT, int WN, int NP = 3>
 __global__ __launch_bounds__(64 * WGM * WGN, WGM* WGN == 4 ? 2 : 1) void tap_gemm6_kernel(const TapGemmParams p, const __bf16* __restrict__ wp) {
     using Cfg = Tap6Cfg<WGM, WGN, WMT, WN>;
@@ -123,6 +127,15 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM* WGN == 4 ? 2 : 1) void tap_gem
             a_boff[i] = (int)((t * tsf + 4 * q) * 4);
         }
     };
+    // split16: one power-of-two scale for the clip's activation operand(s) (both segments share the accumulator)
+    float a_scale = 1.f, a_inv = 1.f;
+    if (NP == 2) {
+        unsigned am = p.seg[0].amax[b];
+        if (p.nseg > 1) { const unsigned a1 = p.seg[1].amax[b]; am = a1 > am ? a1 : am; }
+        const int se = s16_exponent(am);
+        a_scale = s16_pow2(se);
+        a_inv = s16_pow2(-se);
+    }
     f32x4 ra[A_SLOTS];
     auto load_a = [&](int s_, int c_, int j_) {
         if (seg_interior) {
@@ -157,6 +170,10 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM* WGN == 4 ? 2 : 1) void tap_gem
                     *reinterpret_cast<bf16x4_t*>(dst + a_lds[i]) = __builtin_convertvector(v, bf16x4_t);
                     continue;
                 }
+                if (NP == 2) {   // split16.h: scaled value = hi + lo in fp16
+                    split16_store4(v * a_scale, dst, PLANE, a_lds[i]);
+                    continue;
+                }
                 unsigned h[4], m[4], l[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -179,13 +196,14 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM* WGN == 4 ? 2 : 1) void tap_gem
     };
     // B fragments of this wave's WN column tiles for ONE k-step: [plane][c]; k-step index inside the packed rows
     const int ksteps = p.Ktot >> 4;
-    const __bf16* wbase = wp + ((long long)((n0 + wn * 32 * WN) >> 5) * ksteps) * (3 * 64 * 8) + lane * 8;
+    constexpr int WPL = NP == 2 ? 2 : 3;    // planes in the weight image
+    const __bf16* wbase = wp + ((long long)((n0 + wn * 32 * WN) >> 5) * ksteps) * (WPL * 64 * 8) + lane * 8;
     auto load_b = [&](int s_, bf16x8 (&bf)[3][WN]) {
 #pragma unroll
         for (int c = 0; c < WN; ++c)
 #pragma unroll
             for (int pl = 0; pl < NP; ++pl)
-                bf[pl][c] = *reinterpret_cast<const bf16x8*>(wbase + (((long long)c * ksteps + s_) * 3 + pl) * (64 * 8));
+                bf[pl][c] = *reinterpret_cast<const bf16x8*>(wbase + (((long long)c * ksteps + s_) * WPL + pl) * (64 * 8));
     };
 
     // ---- prologue
@@ -214,6 +232,12 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM* WGN == 4 ? 2 : 1) void tap_gem
                 f32x16 v = acc[a][c];
                 if (NP == 1) {
                     acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][a], bf[0][c], v, 0, 0, 0);
+                    continue;
+                }
+                if (NP == 2) {   // lo hi, hi lo, hi hi
+                    v = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[1][a]), __builtin_bit_cast(f16x8, bf[0][c]), v, 0, 0, 0);
+                    v = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[0][a]), __builtin_bit_cast(f16x8, bf[1][c]), v, 0, 0, 0);
+                    acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[0][a]), __builtin_bit_cast(f16x8, bf[0][c]), v, 0, 0, 0);
                     continue;
                 }
                 // smallest partial products first: hl, lh, mm, hm, mh, hh
@@ -294,6 +318,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM* WGN == 4 ? 2 : 1) void tap_gem
     const long long yoff = (long long)b * p.y_bs;
     const bool post = p.gelu || p.scale || p.res || p.tanh_out;
     const int nvalid = p.n_valid ? p.n_valid : p.N;
+    unsigned omax = 0;
 #pragma unroll
     for (int c = 0; c < WN; ++c) {
         __syncthreads();
@@ -301,8 +326,10 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM* WGN == 4 ? 2 : 1) void tap_gem
         for (int a = 0; a < WMT; ++a) {
             const int ng = n0 + (wn * WN + c) * 32 + i32;
             const float bv = (p.bias && ng < p.N) ? p.bias[ng] : 0.f;
+            const float iv = NP == 2 ? a_inv * p.winv[ng] : 1.f;     // exact: powers of two
 #pragma unroll
-            for (int r = 0; r < 16; ++r) Cs[((wm * WMT + a) * 32 + 8 * (r / 4) + 4 * kh + (r % 4)) * CP + wn * 32 + i32] = acc[a][c][r] + bv;
+            for (int r = 0; r < 16; ++r)
+                Cs[((wm * WMT + a) * 32 + 8 * (r / 4) + 4 * kh + (r % 4)) * CP + wn * 32 + i32] = NP == 2 ? __fmaf_rn(acc[a][c][r], iv, bv) : acc[a][c][r] + bv;
         }
         __syncthreads();
         for (int e = tid; e < BM * (CW / 4); e += NT) {
@@ -324,6 +351,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM* WGN == 4 ? 2 : 1) void tap_gem
                     if (p.tanh_out) { v.x = tanhf(v.x); v.y = tanhf(v.y); v.z = tanhf(v.z); v.w = tanhf(v.w); }
                 }
                 const long long o = yoff + fi;
+                if (p.amax_out) amax_acc4(omax, v);
                 if (p.y) *reinterpret_cast<f32x4*>(p.y + o) = v;
                 if (p.y_elu) {
                     f32x4 w;
@@ -331,6 +359,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM* WGN == 4 ? 2 : 1) void tap_gem
                         const int ca = n % p.alpha_n;
                         const f32x4 al = *reinterpret_cast<const f32x4*>(p.alpha + ca), ai = *reinterpret_cast<const f32x4*>(p.alpha_inv + ca);
                         w.x = snake1(v.x, al.x, ai.x); w.y = snake1(v.y, al.y, ai.y); w.z = snake1(v.z, al.z, ai.z); w.w = snake1(v.w, al.w, ai.w);
+                        if (p.amax_out) amax_acc4(omax, w);      // Snake can exceed |v| (ELU cannot)
                     } else {
                         w = elu4(v);
                     }
@@ -339,6 +368,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM* WGN == 4 ? 2 : 1) void tap_gem
             }
         }
     }
+    if (p.amax_out) amax_flush(omax, p.amax_out + b);
     if (p.clk && tid == 0) {   // shader clock while this workgroup lived: sum of ticks / sum of 100 MHz real-time ticks
         atomicAdd(&p.clk[0], (unsigned long long)(__builtin_amdgcn_s_memtime() - clk_t0));
         atomicAdd(&p.clk[1], (unsigned long long)(__builtin_amdgcn_s_memrealtime() - clk_r0));

@@ -9,6 +9,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "tap_gemm.h"
+#include "split16.h"
 
 namespace ac {
 
@@ -26,6 +27,7 @@ struct ThinParams {
     const float* alpha;    // stem: Snake parameters of the consumer -> y_elu = snake(y) instead of ELU(y) (DAC)
     const float* alpha_inv;
     int tanh_out;          // head: tanh on the output (DAC decoder, [HF] dac :439-440)
+    unsigned* amax_out;    // stem: optional split16.h amax slot [B] of the output (raw and activated flavour)
 };
 
 __device__ __forceinline__ int reflect_src(int i, int T, int Lp, int pad) {
@@ -61,6 +63,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const ThinParams p) {
     __syncthreads();
     const int tstep = 256 / cq;
     const long long ob = (long long)b * p.T * p.F;
+    unsigned omax = 0;
     for (int tl = tid / cq; tl < STEM_TT; tl += tstep) {
         const int t = t0 + tl;
         if (t >= p.T) break;
@@ -74,18 +77,21 @@ __global__ __launch_bounds__(256) void stem_kernel(const ThinParams p) {
             }
         }
         const long long o = ob + (long long)t * p.F + c4;
+        amax_acc4(omax, acc);
         if (p.y) *reinterpret_cast<f32x4*>(p.y + o) = acc;
         if (p.y_elu) {
             f32x4 w;
             if (p.alpha) {
                 const f32x4 al = *reinterpret_cast<const f32x4*>(p.alpha + c4), ai = *reinterpret_cast<const f32x4*>(p.alpha_inv + c4);
                 w.x = snake1(acc.x, al.x, ai.x); w.y = snake1(acc.y, al.y, ai.y); w.z = snake1(acc.z, al.z, ai.z); w.w = snake1(acc.w, al.w, ai.w);
+                amax_acc4(omax, w);                  // Snake can exceed |acc| (ELU cannot)
             } else {
                 w = elu4(acc);
             }
             *reinterpret_cast<f32x4*>(p.y_elu + o) = w;
         }
     }
+    if (p.amax_out) amax_flush(omax, p.amax_out + b);
 }
 
 constexpr int HEAD_TT = 256;    // outputs per workgroup (one per thread)

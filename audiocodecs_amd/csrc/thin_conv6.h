@@ -27,6 +27,10 @@ struct ThinConv6Params {
     int B, M, Ls;           // outputs / input super-rows per clip
     int ntiles;             // 64-row tiles per clip
     int edge;               // S[-1]: 0 zeros, 1 reflected pair of 32-wide rows
+    // split16.h (NP = 2): amax slot [B] of x, optional slot of the output, per-output-channel 2^-s of the weight rows
+    const unsigned* amax_in;
+    unsigned* amax_out;
+    const float* winv;      // [64]
 };
 
 constexpr int T6_BM = 64, T6_XP = 72;                       // rows per tile; LDS pitch in bf16 (64 + 8)
@@ -44,13 +48,17 @@ __global__ __launch_bounds__(256, 4) void thin_conv6_kernel(const ThinConv6Param
     const int li = lane & 15, kq = lane >> 4;
     const int total = p.B * p.ntiles;
 
+    constexpr int WPL = NP == 2 ? 2 : 3;                    // planes in the weight image
     bf16x8 wr[4][3];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
         for (int pl = 0; pl < NP; ++pl)
-            wr[ks][pl] = *reinterpret_cast<const bf16x8*>(p.wf + ((((long long)wave * 4 + ks) * 3 + pl) * 64 + lane) * 8);
+            wr[ks][pl] = *reinterpret_cast<const bf16x8*>(p.wf + ((((long long)wave * 4 + ks) * WPL + pl) * 64 + lane) * 8);
     const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + wave * 16 + 4 * kq);
+    f32x4 wiv = {1.f, 1.f, 1.f, 1.f};
+    if (NP == 2) wiv = *reinterpret_cast<const f32x4*>(p.winv + wave * 16 + 4 * kq);
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
     int s_row[T6_SLOTS], s_q[T6_SLOTS];
 #pragma unroll
@@ -73,23 +81,32 @@ __global__ __launch_bounds__(256, 4) void thin_conv6_kernel(const ThinConv6Param
             rx[i] = bufload16(rs, off, 0);                  // super-rows past the clip: out of range -> 0
         }
     };
-    auto store_tile = [&]() {
+    float sx = 1.f, ix = 1.f;                               // split16 scale of the clip staged in LDS
+    auto store_tile = [&](int tile) {
+        if (NP == 2) {
+            const int se = s16_exponent(p.amax_in[tile / p.ntiles]);
+            sx = s16_pow2(se);
+            ix = s16_pow2(-se);
+        }
 #pragma unroll
         for (int i = 0; i < T6_SLOTS; ++i)
-            if (s_row[i] < T6_ROWS) split_store4<NP>(rx[i], Xs, T6_PLANE, s_row[i] * T6_XP + 4 * s_q[i]);
+            if (s_row[i] < T6_ROWS) split_store4<NP>(rx[i], Xs, T6_PLANE, s_row[i] * T6_XP + 4 * s_q[i], sx);
     };
 
     int tile = blockIdx.x;
     if (tile >= total) return;
     load_tile(tile);
-    store_tile();
+    store_tile(tile);
     __syncthreads();
+    unsigned omax = 0;
+    int omax_b = tile / p.ntiles;
     for (; tile < total; tile += gridDim.x) {
         const int next = tile + gridDim.x;
+        const f32x4 iv = wiv * ix;                          // this tile's inverse scales (store_tile(next) replaces ix)
         if (next < total) load_tile(next);
         f32x4 acc[4];
 #pragma unroll
-        for (int a = 0; a < 4; ++a) acc[a] = bv;
+        for (int a = 0; a < 4; ++a) acc[a] = NP == 2 ? zero4 : bv;
         // k-steps 0, 1: S[m-1] (slab row r), k-steps 2, 3: S[m] (slab row r + 1)
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
@@ -103,9 +120,14 @@ __global__ __launch_bounds__(256, 4) void thin_conv6_kernel(const ThinConv6Param
             for (int a = 0; a < 4; ++a) acc[a] = mma6<NP>(wr[ks], xf[a], acc[a]);
         }
         __syncthreads();                                    // every wave is done reading the slab
-        if (next < total) store_tile();                     // staged before the output stores are issued (rb_fused6.h)
+        if (next < total) store_tile(next);                 // staged before the output stores are issued (rb_fused6.h)
         {
             const int b = tile / p.ntiles, m0 = (tile % p.ntiles) * T6_BM;
+            if (p.amax_out && b != omax_b) {
+                amax_flush(omax, p.amax_out + omax_b);
+                omax = 0;
+                omax_b = b;
+            }
             const long long ob = (long long)b * p.M * 64;
             const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)(p.y ? p.y + ob : nullptr), 0, p.y ? out_bytes : 0, 0x00020000);
             const __amdgpu_buffer_rsrc_t re = __builtin_amdgcn_make_buffer_rsrc((void*)(p.y_elu ? p.y_elu + ob : nullptr), 0, p.y_elu ? out_bytes : 0, 0x00020000);
@@ -113,12 +135,16 @@ __global__ __launch_bounds__(256, 4) void thin_conv6_kernel(const ThinConv6Param
             for (int a = 0; a < 4; ++a) {
                 const int m = m0 + a * 16 + li;
                 const int o = (m < p.M ? m * 256 : 0x7fff0000) + (wave * 16 + 4 * kq) * 4;
-                if (p.y) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, acc[a]), ry, o, 0, 0);
-                if (p.y_elu) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, elu4(acc[a])), re, o, 0, 0);
+                f32x4 v = acc[a];
+                if (NP == 2) v = f32x4{__fmaf_rn(v.x, iv.x, bv.x), __fmaf_rn(v.y, iv.y, bv.y), __fmaf_rn(v.z, iv.z, bv.z), __fmaf_rn(v.w, iv.w, bv.w)};
+                if (p.amax_out && m < p.M) amax_acc4(omax, v);
+                if (p.y) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), ry, o, 0, 0);
+                if (p.y_elu) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, elu4(v)), re, o, 0, 0);
             }
         }
         __syncthreads();
     }
+    if (p.amax_out) amax_flush(omax, p.amax_out + omax_b);
 }
 
 }  // namespace ac

@@ -213,6 +213,7 @@ int ac_load_weights(ac_handle* h, const char* name, const void* host_ptr, size_t
 #define AC_PRECISION_FP32 0
 #define AC_PRECISION_FP32_EXACT 1
 #define AC_PRECISION_BF16 2
+#define AC_PRECISION_FP32_BF16X3 3
 int ac_set_precision(ac_handle* h, int precision);
 
 /* Check that every tensor of the configuration arrived, fold/pack them into the kernels' layouts
