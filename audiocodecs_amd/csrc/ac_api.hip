@@ -180,6 +180,9 @@ struct ac_handle {
     // amax slots (split16.h): [slot][amax_B] words, handed out in launch order, cleared at the start of every pass
     unsigned* amax_buf = nullptr;
     int amax_B = 0, amax_next = 0;
+    // row mode (linear layers over merged row matrices): a ring of per-row words
+    unsigned* row_buf = nullptr;
+    size_t row_cap = 0, row_next = 0;
     int precision = -1;             // ac_set_precision; -1: take AC_GEMM from the environment
     // persistent LSTM (lstm_persist.h): control words, device shape, opt-out (AC_LSTM=step)
     unsigned* lp_ctl = nullptr;
@@ -794,6 +797,21 @@ const unsigned* amax_of(ac_handle* h, hipStream_t st, const float* x, long long 
     return slot;
 }
 
+// `rows` words of the row ring (split16.h row mode); zeroed when a kernel is going to atomicMax into them
+unsigned* rowmax_new(ac_handle* h, hipStream_t st, long long rows, bool zero) {
+    if ((size_t)rows * 8 > h->row_cap) {     // grows before any word of this size class has been handed out
+        if (h->row_buf) { if (hipStreamSynchronize(st) != hipSuccess) return nullptr; (void)hipFree(h->row_buf); h->row_buf = nullptr; }
+        h->row_cap = (size_t)rows * 8;
+        if (hipMalloc(&h->row_buf, h->row_cap * 4) != hipSuccess) { h->row_cap = 0; return nullptr; }
+        h->row_next = 0;
+    }
+    if (h->row_next + (size_t)rows > h->row_cap) h->row_next = 0;
+    unsigned* r = h->row_buf + h->row_next;
+    h->row_next += ((size_t)rows + 63) / 64 * 64;
+    if (zero && hipMemsetAsync(r, 0, (size_t)rows * 4, st) != hipSuccess) return nullptr;
+    return r;
+}
+
 // slot holding the bound amax(x) + add of a tensor y with |y| <= |x| + add (LSTM with skip: |h| < 1); null when x has no amax
 const unsigned* amax_plus(ac_handle* h, hipStream_t st, const Act& x, float add, int B) {
     if (!x.amax || x.amax_n != B) return nullptr;
@@ -904,10 +922,29 @@ int run_tap(ac_handle* h, hipStream_t st, TapGemmParams& p) {
             launch_tap<WGM, WGN, WM, WN, false>(p, st);                                                     \
         }                                                                                                   \
     } while (0)
+    const bool want_rows = p.amax_out_rows != nullptr;    // (any non-null value is a request)
+    p.amax_out_rows = nullptr;
     if (w6) {
         p.clk = h->clk_dev;
         auto iv = h->winv_of.find((size_t)(p.w - h->blob));
-        if (iv != h->winv_of.end()) {     // split16.h: every operand tensor needs its amax; the output reports its own
+        const bool rowmode = iv != h->winv_of.end() && p.B == 1 && p.nseg == 1 && p.seg[0].J == 1 && p.seg[0].s == 1 && p.seg[0].pad == 0 &&
+                             p.seg[0].lim >= p.M && p.seg[0].L >= p.M && p.y_off == 0;
+        if (rowmode) {                    // split16.h row mode: a linear layer over a merged row matrix -- one scale per row
+            TapSeg& sg = p.seg[0];
+            if (!(sg.amax && sg.amax_n == -p.M)) {
+                unsigned* rm = rowmax_new(h, st, p.M, false);
+                if (!rm) return fail(h, AC_EHIP, "row-amax ring allocation failed");
+                ProfScope ps(h, st, "rowmax_kernel", 0.0, (double)p.M * sg.cin * 4.0);
+                hipLaunchKernelGGL(rowmax_kernel, dim3((unsigned)cdiv(p.M, 4)), dim3(256), 0, st, sg.x, sg.ts, (long long)p.M, sg.cin, rm);
+                sg.amax = rm;
+            }
+            p.amax_rows = 1;
+            p.winv = h->blob + iv->second;
+            if (want_rows) {              // the caller asked for the output's row words: a fresh, zeroed array
+                p.amax_out_rows = rowmax_new(h, st, p.M, true);
+                if (!p.amax_out_rows) return fail(h, AC_EHIP, "row-amax ring allocation failed");
+            }
+        } else if (iv != h->winv_of.end()) {     // split16.h: every operand tensor needs its amax; the output reports its own
             for (int i = 0; i < p.nseg; ++i) {
                 TapSeg& sg = p.seg[i];
                 sg.amax = amax_of(h, st, sg.x, sg.bs, sg.ts, sg.L, sg.cin, p.B, sg.amax_n == p.B ? sg.amax : nullptr);
@@ -2430,6 +2467,7 @@ void ac_destroy(ac_handle* h) {
     if (h->blob) (void)hipFree(h->blob);
     if (h->lp_ctl) (void)hipFree(h->lp_ctl);
     if (h->amax_buf) (void)hipFree(h->amax_buf);
+    if (h->row_buf) (void)hipFree(h->row_buf);
     if (h->sticky) (void)hipHostFree(h->sticky);
     if (h->clk_dev) (void)hipFree(h->clk_dev);
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);

@@ -17,6 +17,10 @@ struct Epi {
     const float* res = nullptr;
     long long res_bs = 0, res_rs = 0;
     int gelu = 0;
+    // split16.h row mode (mimi_linear): per-row amax words of the input when the producing linear layer left them, and
+    // where to return the output's (null: not wanted)
+    const unsigned* rowmax_in = nullptr;
+    const unsigned** rowmax_out = nullptr;
 };
 
 // conv (stride 1 or k = 2*stride) with the given padding rule, output contiguous [B][M][N]
@@ -63,7 +67,10 @@ int mimi_linear(ac_handle* h, hipStream_t st, const PackedGemm& g, const float* 
         TapGemmParams p{};
         p.nseg = 1;
         Act xa{x + r0 * x_pitch, 0, x_pitch, (int)n, cin};
+        const bool one = r0 == 0 && n == rows;     // row words are chained between launches that cover the whole matrix
+        if (one && epi.rowmax_in) { xa.amax = epi.rowmax_in; xa.amax_n = -(int)n; }
         p.seg[0] = make_seg(xa, 1, 1, PAD_ZERO, 0, kofs, nullptr);
+        if (one && epi.rowmax_out) p.amax_out_rows = reinterpret_cast<unsigned*>(1);   // request; run_tap allocates
         p.w = h->blob + g.w_off;
         p.bias = g.has_bias ? h->blob + g.b_off : nullptr;
         p.y = y + r0 * y_pitch;
@@ -79,6 +86,7 @@ int mimi_linear(ac_handle* h, hipStream_t st, const PackedGemm& g, const float* 
         p.res_rs = epi.res_rs;
         p.gelu = epi.gelu;
         if (int rc = run_tap(h, st, p)) return rc;
+        if (epi.rowmax_out) *epi.rowmax_out = one ? p.amax_out_rows : nullptr;
     }
     return AC_OK;
 }
@@ -184,8 +192,11 @@ int transformer_fwd(ac_handle* h, hipStream_t st, const std::vector<MimiTfLayer>
         if ((rc = layernorm_fwd(h, st, x, L.ln2_w, L.ln2_b, s.ln, rows, H, c.norm_eps))) return rc;
         Epi eg;
         eg.gelu = 1;
+        const unsigned* hid_rows = nullptr;      // split16.h row mode: fc1's epilogue leaves the row amax of its output for fc2
+        eg.rowmax_out = &hid_rows;
         if ((rc = mimi_linear(h, st, L.fc1, s.ln, rows, H, H, 0, s.hid, I, eg))) return rc;
         Epi em;
+        em.rowmax_in = hid_rows;
         em.scale = h->blob + L.sc_m;
         em.res = x;
         em.res_rs = H;

@@ -87,6 +87,26 @@ __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, 
     amax_flush(mx, slot + b);
 }
 
+// Row mode (linear layers over a merged row matrix): out[r] = max |x[r][0 .. C)|, one wave per row
+__global__ __launch_bounds__(256) void rowmax_kernel(const float* __restrict__ x, long long pitch, long long rows, int C, unsigned* __restrict__ out) {
+    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float* xr = x + r * pitch;
+    unsigned mx = 0;
+    if ((C & 3) == 0 && (pitch & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+        for (int i = lane; i < C / 4; i += 64) amax_acc4(mx, reinterpret_cast<const s16_f32x4*>(xr)[i]);
+    } else {
+        for (int i = lane; i < C; i += 64) amax_acc(mx, xr[i]);
+    }
+#pragma unroll
+    for (int o = 32; o; o >>= 1) {
+        const unsigned t = (unsigned)__shfl_xor((int)mx, o);
+        mx = t > mx ? t : mx;
+    }
+    if (lane == 0) out[r] = mx;
+}
+
 // slot_out[b] = bits of (|a| + add): the bound of a sum whose second term is bounded by `add` (LSTM skip: h in (-1, 1))
 __global__ void amax_add_kernel(const unsigned* __restrict__ in, float add, unsigned* __restrict__ out, int B) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;

@@ -85,6 +85,11 @@ struct TapGemmParams {
     // (largest magnitude over the raw and the activated flavour)
     const float* winv;
     unsigned* amax_out;
+    // ROW mode (a linear layer over a merged row matrix: B = 1, one segment, one tap): seg[0].amax holds one word per ROW, the
+    // scale is the row's own -- the result of a row then depends on nothing but that row (clips stay independent of their
+    // batch neighbours); amax_out_rows: optional per-row words of the output
+    int amax_rows;
+    unsigned* amax_out_rows;
     unsigned long long* clk;   // diagnostics (ac_debug_clock): [0] += shader-clock ticks, [1] += 100 MHz real-time ticks of
                                // every workgroup of a tap_gemm6 launch; null = off
 };

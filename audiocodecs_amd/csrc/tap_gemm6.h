@@ -128,13 +128,26 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM* WGN == 4 ? 2 : 1) void tap_gem
         }
     };
     // split16: one power-of-two scale for the clip's activation operand(s) (both segments share the accumulator)
+    // (row mode: one scale per ROW of the merged row matrix instead -- a_rsc[slot])
     float a_scale = 1.f, a_inv = 1.f;
+    float a_rsc[A_SLOTS];
+    const bool rowmode = NP == 2 && p.amax_rows;
     if (NP == 2) {
-        unsigned am = p.seg[0].amax[b];
-        if (p.nseg > 1) { const unsigned a1 = p.seg[1].amax[b]; am = a1 > am ? a1 : am; }
-        const int se = s16_exponent(am);
-        a_scale = s16_pow2(se);
-        a_inv = s16_pow2(-se);
+        if (!rowmode) {
+            unsigned am = p.seg[0].amax[b];
+            if (p.nseg > 1) { const unsigned a1 = p.seg[1].amax[b]; am = a1 > am ? a1 : am; }
+            const int se = s16_exponent(am);
+            a_scale = s16_pow2(se);
+            a_inv = s16_pow2(-se);
+        }
+#pragma unroll
+        for (int i = 0; i < A_SLOTS; ++i) {
+            a_rsc[i] = a_scale;
+            if (rowmode) {
+                const int m = m0 + (tid + i * NT) / (KC / 4);
+                a_rsc[i] = s16_pow2(s16_exponent(p.seg[0].amax[m < p.M ? m : p.M - 1]));
+            }
+        }
     }
     f32x4 ra[A_SLOTS];
     auto load_a = [&](int s_, int c_, int j_) {
@@ -171,7 +184,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM* WGN == 4 ? 2 : 1) void tap_gem
                     continue;
                 }
                 if (NP == 2) {   // split16.h: scaled value = hi + lo in fp16
-                    split16_store4(v * a_scale, dst, PLANE, a_lds[i]);
+                    split16_store4(v * a_rsc[i], dst, PLANE, a_lds[i]);
                     continue;
                 }
                 unsigned h[4], m[4], l[4];
@@ -327,17 +340,24 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM* WGN == 4 ? 2 : 1) void tap_gem
             const int ng = n0 + (wn * WN + c) * 32 + i32;
             const float bv = (p.bias && ng < p.N) ? p.bias[ng] : 0.f;
             const float iv = NP == 2 ? a_inv * p.winv[ng] : 1.f;     // exact: powers of two
+            const float bq = rowmode ? 0.f : bv;                     // row mode: the row's 2^-s and the bias follow in the store pass
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                Cs[((wm * WMT + a) * 32 + 8 * (r / 4) + 4 * kh + (r % 4)) * CP + wn * 32 + i32] = NP == 2 ? __fmaf_rn(acc[a][c][r], iv, bv) : acc[a][c][r] + bv;
+                Cs[((wm * WMT + a) * 32 + 8 * (r / 4) + 4 * kh + (r % 4)) * CP + wn * 32 + i32] = NP == 2 ? __fmaf_rn(acc[a][c][r], iv, bq) : acc[a][c][r] + bv;
         }
         __syncthreads();
         for (int e = tid; e < BM * (CW / 4); e += NT) {
             const int row = e / (CW / 4), q = e % (CW / 4);
             const int m = m0 + row, n = n0 + (q / 8) * (32 * WN) + 32 * c + 4 * (q % 8);
             const long long fi = (long long)m * p.y_rs + n + p.y_off;
+            unsigned rmax = 0;
             if (m < p.M && n < nvalid && (p.y_len == 0 || (fi >= 0 && fi < p.y_len))) {
                 f32x4 v = *reinterpret_cast<const f32x4*>(&Cs[row * CP + 4 * q]);
+                if (rowmode) {
+                    const float ri = s16_pow2(-s16_exponent(p.seg[0].amax[m]));
+                    const f32x4 b4 = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    v = f32x4{__fmaf_rn(v.x, ri, b4.x), __fmaf_rn(v.y, ri, b4.y), __fmaf_rn(v.z, ri, b4.z), __fmaf_rn(v.w, ri, b4.w)};
+                }
                 if (post) {
                     if (p.gelu) { v.x = gelu1(v.x); v.y = gelu1(v.y); v.z = gelu1(v.z); v.w = gelu1(v.w); }
                     if (p.scale) {
@@ -352,6 +372,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM* WGN == 4 ? 2 : 1) void tap_gem
                 }
                 const long long o = yoff + fi;
                 if (p.amax_out) amax_acc4(omax, v);
+                if (NP == 2 && p.amax_out_rows) amax_acc4(rmax, v);
                 if (p.y) *reinterpret_cast<f32x4*>(p.y + o) = v;
                 if (p.y_elu) {
                     f32x4 w;
@@ -365,6 +386,14 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM* WGN == 4 ? 2 : 1) void tap_gem
                     }
                     *reinterpret_cast<f32x4*>(p.y_elu + o) = w;
                 }
+            }
+            if (NP == 2 && p.amax_out_rows) {      // the CW / 4 lanes that share this row (every lane runs every iteration)
+#pragma unroll
+                for (int o2 = CW / 8; o2; o2 >>= 1) {
+                    const unsigned t2 = (unsigned)__shfl_xor((int)rmax, o2);
+                    rmax = t2 > rmax ? t2 : rmax;
+                }
+                if (q == 0 && m < p.M && rmax) atomicMax(p.amax_out_rows + m, rmax);
             }
         }
     }

@@ -282,8 +282,11 @@ int wavtok_decoder_fwd(ac_handle* h, hipStream_t st, const float* feats, int B, 
         }
         Epi eg;
         eg.gelu = 1;
+        const unsigned* u_rows = nullptr;        // split16.h row mode: p1's epilogue leaves the row amax of its output for p2
+        eg.rowmax_out = &u_rows;
         if ((rc = mimi_linear(h, st, L.p1, t, rows, C, C, 0, u, I, eg))) return rc;
         Epi em;
+        em.rowmax_in = u_rows;
         em.scale = h->blob + L.gamma;
         em.res = x;
         em.res_rs = C;
