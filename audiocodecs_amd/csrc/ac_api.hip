@@ -61,6 +61,7 @@ struct LstmPlan {
     std::vector<size_t> ihpk_off;   // W_ih per layer, same order (used by the in-step projection of layers >= 1)
     size_t persist_off = 0;         // register images of W_hh0, W_ih1, W_hh1 for lstm_persist_kernel (D = 512, 2 layers)
     size_t persist6_off = 0;        // the same as three bf16 planes for lstm_persist6_kernel (float offset into the blob)
+    size_t persist16_inv = 0;       // split16.h: persist6_off holds two fp16 planes of the scaled rows; [2 layers][4D] 2^-s
     bool has_persist = false;
 };
 
@@ -676,11 +677,49 @@ struct Packer {
                                     for (int e = 0; e < 4; ++e)
                                         blob[lp.persist_off + m * mat + ((((size_t)idx * 4 + w) * 4 + n) * 8 + ks) * 256 + lane * 4 + e] =
                                             (*mats[m])[(size_t)(n * D + idx * 16 + (lane & 15)) * D + (w * 8 + ks) * 16 + 4 * (lane >> 4) + e];
+            const std::vector<float>* mats6[4] = {mats[0], mats[1], mats[2], get(prefix + ".weight_ih_l0", (size_t)4 * D * D)};
+            if (use16()) {
+                // lstm_persist6_kernel<2>: [hh0, ih1, hh1, ih0][32 slices][4 waves][4 gates][4 k-steps of 32][2 planes][64 lanes][8 fp16] of the
+                // scaled rows; the two matrices of a layer share the accumulator, so their rows share the scale
+                const size_t mat16 = (size_t)LP_SLICES * 4 * 4 * 4 * 2 * 512;
+                lp.persist6_off = reserve((4 * mat16 + 1) / 2);
+                lp.persist16_inv = reserve((size_t)2 * 4 * D);
+                std::vector<int> sc((size_t)2 * 4 * D);
+                const int layer_of[4] = {0, 1, 1, 0};
+                for (int l = 0; l < 2; ++l)
+                    for (int row = 0; row < 4 * D; ++row) {
+                        uint32_t mx = 0;
+                        for (int m = 0; m < 4; ++m)
+                            if (layer_of[m] == l)
+                                for (int k = 0; k < D; ++k) {
+                                    uint32_t b;
+                                    std::memcpy(&b, &(*mats6[m])[(size_t)row * D + k], 4);
+                                    mx = std::max(mx, b & 0x7fffffffu);
+                                }
+                        sc[(size_t)l * 4 * D + row] = s16_exponent(mx, 40);
+                        blob[lp.persist16_inv + (size_t)l * 4 * D + row] = s16_pow2(-sc[(size_t)l * 4 * D + row]);
+                    }
+                std::vector<uint16_t> pl16(4 * mat16);
+                for (int m = 0; m < 4; ++m)
+                    for (int idx = 0; idx < LP_SLICES; ++idx)
+                        for (int w = 0; w < 4; ++w)
+                            for (int n = 0; n < 4; ++n)
+                                for (int ks = 0; ks < 4; ++ks)
+                                    for (int lane = 0; lane < 64; ++lane)
+                                        for (int e = 0; e < 8; ++e) {
+                                            const int row = n * D + idx * 16 + (lane & 15);
+                                            uint16_t t[3];
+                                            split16h((*mats6[m])[(size_t)row * D + w * 128 + ks * 32 + 8 * (lane >> 4) + e], sc[(size_t)layer_of[m] * 4 * D + row], t);
+                                            const size_t base = m * mat16 + (((((size_t)idx * 4 + w) * 4 + n) * 4 + ks) * 2) * 512 + (size_t)lane * 8 + e;
+                                            pl16[base] = t[0];
+                                            pl16[base + 512] = t[1];
+                                        }
+                std::memcpy(&blob[lp.persist6_off], pl16.data(), pl16.size() * 2);
+            } else {
             // lstm_persist6_kernel: [hh0, ih1, hh1, ih0][32 slices][4 waves][4 gates][4 k-steps of 32][3 planes][64 lanes][8 bf16]
             const size_t mat6 = (size_t)LP_SLICES * 4 * 4 * 4 * 3 * 512;
             lp.persist6_off = reserve((4 * mat6 + 1) / 2);
             std::vector<uint16_t> pl6(4 * mat6);
-            const std::vector<float>* mats6[4] = {mats[0], mats[1], mats[2], get(prefix + ".weight_ih_l0", (size_t)4 * D * D)};
             for (int m = 0; m < 4; ++m)
                 for (int idx = 0; idx < LP_SLICES; ++idx)
                     for (int w = 0; w < 4; ++w)
@@ -709,6 +748,7 @@ struct Packer {
                                         pl6[base + 1024] = (uint16_t)(b2 >> 16);
                                     }
             std::memcpy(&blob[lp.persist6_off], pl6.data(), pl6.size() * 2);
+            }
             lp.has_persist = true;
         }
         return true;
@@ -1045,7 +1085,7 @@ int try_thin6(ac_handle* h, hipStream_t st, const PackedGemm& g, const Act& x, i
     }
     const long long total = (long long)B * p.ntiles;
     const int grid = (int)std::min<long long>(total, 4 * 256);   // persistent, four workgroups per CU
-    ProfScope ps(h, st, "thin_conv6_kernel", 2.0 * B * p.M * 64.0 * 128.0,
+    ProfScope ps(h, st, h->gemm_bf16 ? "thin_conv6_kernel<1>" : s16 ? "thin_conv6_kernel<2>" : "thin_conv6_kernel<3>", 2.0 * B * p.M * 64.0 * 128.0,
                  (double)B * p.M * 256.0 * (1 + (out.raw ? 1 : 0) + (out.elu ? 1 : 0)));
     if (h->gemm_bf16) hipLaunchKernelGGL(thin_conv6_kernel<1>, dim3(grid), dim3(256), T6_LDS, st, p);
     else if (s16) hipLaunchKernelGGL(thin_conv6_kernel<2>, dim3(grid), dim3(256), T6_LDS, st, p);
@@ -1198,7 +1238,8 @@ int launch_rb_fused6(ac_handle* h, hipStream_t st, const ResBlockPlan& rb, const
     const int per_cu = C == 64 ? 2 : 3;
     const int grid = (int)std::min<long long>(total, (long long)per_cu * 256);   // persistent
     const double L = x.raw.L;
-    ProfScope ps(h, st, !SC ? "rb_fused6_kernel<64, false>" : C == 32 ? "rb_fused6_kernel<32, true>" : "rb_fused6_kernel<64, true>",
+    const std::string np6 = h->gemm_bf16 ? ", 1>" : s16 ? ", 2>" : ", 3>";
+    ProfScope ps(h, st, ((!SC ? "rb_fused6_kernel<64, false" : C == 32 ? "rb_fused6_kernel<32, true" : "rb_fused6_kernel<64, true") + np6).c_str(),
                  2.0 * B * L * ((double)(C / 2) * 3 * C + (double)C * (C / 2 + (SC ? C : 0))),
                  (double)B * L * C * 4.0 * (1 + (out.raw ? 1 : 0) + (out.elu ? 1 : 0)));
     if (h->gemm_bf16) hipLaunchKernelGGL((rb_fused6_kernel<C, SC, 1>), dim3(grid), dim3(256), Cfg::lds_bytes, st, p);
@@ -1231,7 +1272,8 @@ int launch_rb128_fused6(ac_handle* h, hipStream_t st, const ResBlockPlan& rb, co
     const long long total = (long long)B * p.ntiles;
     const int grid = (int)std::min<long long>(total, 256);   // persistent, one workgroup per CU
     const double L = x.raw.L;
-    ProfScope ps(h, st, SC ? "rb128_fused6_kernel<true>" : "rb128_fused6_kernel<false>",
+    const std::string np6 = h->gemm_bf16 ? ", 1>" : s16 ? ", 2>" : ", 3>";
+    ProfScope ps(h, st, ((SC ? "rb128_fused6_kernel<true" : "rb128_fused6_kernel<false") + np6).c_str(),
                  2.0 * B * L * (64.0 * 384 + 128.0 * (64 + (SC ? 128 : 0))),
                  (double)B * L * 128 * 4.0 * (1 + (out.raw ? 1 : 0) + (out.elu ? 1 : 0)));
     if (h->gemm_bf16) hipLaunchKernelGGL((rb128_fused6_kernel<SC, 1>), dim3(grid), dim3(512), Cfg::lds_bytes, st, p);
@@ -1408,9 +1450,14 @@ int lstm_fwd(ac_handle* h, hipStream_t st, const LstmPlan& lp, const Act& x, con
     if (persist) {
         // one cooperative launch per 64 clips walks all T steps (lstm_persist.h)
         const int chunks = cdiv(B, 64);
+        const unsigned* x_amax = nullptr;       // split16.h: the fused input projection scales x by its clip's amax
+        if (fuse_in && lp.persist16_inv) {
+            x_amax = amax_of(h, st, x.p, x.bs, x.ts, x.L, x.C, B, x.amax_n == B ? x.amax : nullptr);
+            if (!x_amax) return fail(h, AC_ESTATE, "out of amax slots (split16.h)");
+        }
         int* poison = reinterpret_cast<int*>(ws.c);   // the cell-state buffer of the per-step kernels is free on this path
         if (!h->gemm_fp32) HIPCHK(h, hipMemsetAsync(poison, 0x7f, (size_t)B * sizeof(int), st));
-        ProfScope ps(h, st, h->gemm_fp32 ? "lstm_persist_kernel" : "lstm_persist6_kernel", 2.0 * T * (double)B * 4 * D * D * (nroles + (fuse_in ? 1 : 0)),
+        ProfScope ps(h, st, h->gemm_fp32 ? "lstm_persist_kernel" : lp.persist16_inv ? "lstm_persist6_kernel<2>" : "lstm_persist6_kernel<3>", 2.0 * T * (double)B * 4 * D * D * (nroles + (fuse_in ? 1 : 0)),
                      (double)T * ((double)B * 4 * D * 4 + 3.0 * B * D * 4) + 12.0 * D * D * 4, chunks);
         auto tail = [&](int c0, int nb, const int* pz) {
             LstmTailParams tp{};
@@ -1451,7 +1498,12 @@ int lstm_fwd(ac_handle* h, hipStream_t st, const LstmPlan& lp, const Act& x, con
             if (!h->gemm_fp32) {   // split-operand products on the bf16 pipe (lstm_persist6.h): h travels as bf16 plane blocks
                 LstmPersist6Params q6{};
                 q6.base = q;
-                q6.base.h_ts = (long long)((B + 31) / 32 * 2) * LP6_GROUP_BYTES;
+                const bool l16 = lp.persist16_inv != 0;     // split16.h planes
+                q6.base.h_ts = (long long)((B + 31) / 32 * 2) * (l16 ? LP16_GROUP_BYTES : LP6_GROUP_BYTES);
+                if (l16) {
+                    q6.winv = h->blob + lp.persist16_inv;
+                    q6.amax_x = fuse_in ? x_amax : nullptr;
+                }
                 q6.w_pk6 = reinterpret_cast<const __bf16*>(h->blob + lp.persist6_off);
                 q6.bias0 = h->blob + lp.ih[0].b_off;
                 q6.fuse_in = fuse_in ? 1 : 0;
@@ -1462,7 +1514,8 @@ int lstm_fwd(ac_handle* h, hipStream_t st, const LstmPlan& lp, const Act& x, con
                 HIPCHK(h, hipMemsetAsync(ws.hseq0, 0xFF, hbytes, st));
                 HIPCHK(h, hipMemsetAsync(ws.hseq1, 0xFF, hbytes, st));
                 void* args6[] = {&q6};
-                HIPCHK(h, hipLaunchCooperativeKernel(reinterpret_cast<const void*>(lstm_persist6_kernel), dim3(256), dim3(256), args6, 0, st));
+                HIPCHK(h, hipLaunchCooperativeKernel(l16 ? reinterpret_cast<const void*>(lstm_persist6_kernel<2>) : reinterpret_cast<const void*>(lstm_persist6_kernel<3>),
+                                                     dim3(256), dim3(256), args6, 0, st));
                 tail(c0, q.B, poison);
                 continue;
             }

@@ -18,6 +18,13 @@ namespace ac {
 
 constexpr int LP6_SLICE_BYTES = 3 * 16 * 16 * 2;     // 1536
 constexpr long long LP6_GROUP_BYTES = (long long)LP_SLICES * LP6_SLICE_BYTES;   // 48 KB per 16-clip group and time step
+// NP = 2 (split16.h): two fp16 planes.  h lies in (-1, 1): it travels as 2 h = hi + lo (|hi| < 2 keeps bit 14 clear -- the
+// exchange's "has arrived" test works unchanged on fp16), the weight rows of the two matrices that share an accumulator
+// ([W_ih | W_hh] of a layer) carry ONE power-of-two scale per gate row, and the fused layer-0 input projection scales x[t] by
+// its clip's amax scale and rescales the projection to the recurrent product's units (exact: powers of two) before use.
+// 48 MFMAs and 8 operand loads per matrix, wave and step instead of 96 and 12; a slice block is 1024 B.
+constexpr int LP16_SLICE_BYTES = 2 * 16 * 16 * 2;    // 1024
+constexpr long long LP16_GROUP_BYTES = (long long)LP_SLICES * LP16_SLICE_BYTES;
 
 struct LstmPersist6Params {
     LstmPersistParams base;     // hseq0 / hseq1 are byte buffers of bf16 plane blocks here; h_ts = bytes per time step
@@ -28,6 +35,10 @@ struct LstmPersist6Params {
                                 //    layer 0 has the slack (its step is shorter than layer 1's, which bounds the kernel)
     int* poison;                // [all clips] first time step at which a clip's state went non-finite (INT_MAX-like fill
                                 //    = never): see the publish step and lstm_tail_kernel
+    // NP = 2: per gate row 2^-s of layer 0's [W_ih0 | W_hh0] and of layer 1's [W_ih1 | W_hh1] rows ([2][4D]); amax slot of x
+    // (indexed by clip, fuse_in only)
+    const float* winv;
+    const unsigned* amax_x;
 };
 
 // workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every outstanding global access (its
@@ -38,9 +49,12 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("" ::: "memory");
 }
 
+template <int NP = 3>
 __global__ __launch_bounds__(256) void lstm_persist6_kernel(const LstmPersist6Params pp) {
     const LstmPersistParams& p = pp.base;
     constexpr int D = LP_D;
+    constexpr int SLICE_BYTES = NP == 2 ? LP16_SLICE_BYTES : LP6_SLICE_BYTES;
+    constexpr long long GROUP_BYTES = NP == 2 ? LP16_GROUP_BYTES : LP6_GROUP_BYTES;
     __shared__ float part[2][4][4][16][17];      // by step parity: one barrier per step separates its write from its reads
     __shared__ unsigned s_x, s_slot;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -74,8 +88,8 @@ __global__ __launch_bounds__(256) void lstm_persist6_kernel(const LstmPersist6Pa
     // ---- weights -> registers: [gate][k-step of 32][plane]
     bf16x8 wa[4][4][3], wb[4][4][3];                          // layer 0: wa = W_hh0;  layer 1: wa = W_ih1, wb = W_hh1
     {
-        const long long mat = (long long)LP_SLICES * 4 * 4 * 4 * 3 * 512;      // bf16 elements per matrix
-        const __bf16* base = pp.w_pk6 + ((long long)idx * 4 + wave) * (4 * 4 * 3 * 512) + lane * 8;
+        const long long mat = (long long)LP_SLICES * 4 * 4 * 4 * NP * 512;     // 16-bit elements per matrix
+        const __bf16* base = pp.w_pk6 + ((long long)idx * 4 + wave) * (4 * 4 * NP * 512) + lane * 8;
         const __bf16* pa = base + (layer == 0 ? 0 : mat);
         const __bf16* pb = base + (layer == 0 ? 3 : 2) * mat;  // layer 0 (fuse_in): W_ih0
 #pragma unroll
@@ -83,16 +97,16 @@ __global__ __launch_bounds__(256) void lstm_persist6_kernel(const LstmPersist6Pa
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) {
-                    wa[n][ks][pl] = *reinterpret_cast<const bf16x8*>(pa + ((n * 4 + ks) * 3 + pl) * 512);
-                    if (layer || pp.fuse_in) wb[n][ks][pl] = *reinterpret_cast<const bf16x8*>(pb + ((n * 4 + ks) * 3 + pl) * 512);
+                for (int pl = 0; pl < NP; ++pl) {
+                    wa[n][ks][pl] = *reinterpret_cast<const bf16x8*>(pa + ((n * 4 + ks) * NP + pl) * 512);
+                    if (layer || pp.fuse_in) wb[n][ks][pl] = *reinterpret_cast<const bf16x8*>(pb + ((n * 4 + ks) * NP + pl) * 512);
                     else wb[n][ks][pl] = wa[n][ks][pl];
                 }
     }
     char* h0b = reinterpret_cast<char*>(p.hseq0);
     char* h1b = reinterpret_cast<char*>(p.hseq1);
     char* hmine = layer ? h1b : h0b;
-    const long long goff = (long long)(p.group0 + g) * LP6_GROUP_BYTES;
+    const long long goff = (long long)(p.group0 + g) * GROUP_BYTES;
 
     const int ec = tid >> 4, ej = tid & 15;
     const int eb = g * 16 + ec;
@@ -106,18 +120,23 @@ __global__ __launch_bounds__(256) void lstm_persist6_kernel(const LstmPersist6Pa
 #pragma unroll
         for (int q = 0; q < 4; ++q) bq[q] = (layer ? p.bias1 : pp.bias0)[q * D + eu];
     }
+    float wiv[4] = {1.f, 1.f, 1.f, 1.f};                      // NP = 2: 2^-s of this thread's gate rows, times 1/2 for the 2 h planes
+    if (NP == 2) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) wiv[q] = 0.5f * pp.winv[layer * 4 * D + q * D + eu];
+    }
     const int hpos = ec * 32 + ej * 2;                         // byte offset of (clip, unit) inside a plane of the slice block
 
     // A operand: for k-step ks of this wave's K quarter, lane (clip li, kq) reads units 8 kq .. 8 kq + 7 of the 32
     auto load_a = [&](const char* seq, int t, bf16x8 (&a)[4][3]) {
-        const char* src = seq + (long long)t * p.h_ts + goff + (long long)(wave * 8) * LP6_SLICE_BYTES;
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, 8 * LP6_SLICE_BYTES, 0x00020000);
-        const int lo = (kq >> 1) * LP6_SLICE_BYTES + li * 32 + (kq & 1) * 16;
+        const char* src = seq + (long long)t * p.h_ts + goff + (long long)(wave * 8) * SLICE_BYTES;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, 8 * SLICE_BYTES, 0x00020000);
+        const int lo = (kq >> 1) * SLICE_BYTES + li * 32 + (kq & 1) * 16;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl)
-                a[ks][pl] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, ks * 2 * LP6_SLICE_BYTES + pl * 512 + lo, 0, LP_SC1));
+            for (int pl = 0; pl < NP; ++pl)
+                a[ks][pl] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, ks * 2 * SLICE_BYTES + pl * 512 + lo, 0, LP_SC1));
     };
     auto mac = [&](const bf16x8 (&a)[4][3], const bf16x8 (&w)[4][4][3], f32x4 (&acc)[4]) {
 #pragma unroll
@@ -125,6 +144,12 @@ __global__ __launch_bounds__(256) void lstm_persist6_kernel(const LstmPersist6Pa
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
                 f32x4 v = acc[n];
+                if (NP == 2) {   // split16.h: lo hi, hi lo, hi hi on the fp16 pipe
+                    v = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a[ks][1]), __builtin_bit_cast(f16x8, w[n][ks][0]), v, 0, 0, 0);
+                    v = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a[ks][0]), __builtin_bit_cast(f16x8, w[n][ks][1]), v, 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a[ks][0]), __builtin_bit_cast(f16x8, w[n][ks][0]), v, 0, 0, 0);
+                    continue;
+                }
                 v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks][0], w[n][ks][2], v, 0, 0, 0);   // hl
                 v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks][2], w[n][ks][0], v, 0, 0, 0);   // lh
                 v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks][1], w[n][ks][1], v, 0, 0, 0);   // mm
@@ -146,7 +171,7 @@ __global__ __launch_bounds__(256) void lstm_persist6_kernel(const LstmPersist6Pa
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) {
+                for (int pl = 0; pl < NP; ++pl) {
                     const u32x4_t w = __builtin_bit_cast(u32x4_t, a[ks][pl]);
                     bad |= (w.x | w.y) | (w.z | w.w);
                 }
@@ -171,6 +196,15 @@ __global__ __launch_bounds__(256) void lstm_persist6_kernel(const LstmPersist6Pa
             __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void*)&xs_lds[wave][i][0], 16,
                                                      xlive ? xoff + (t * D + (i >> 1) * 32 + (i & 1) * 4) * 4 : 0x7fff0000, 0, 0, 0);
     };
+    // NP = 2: x[t] of clip li is scaled by its clip's 2^ex; the projection's rows (clips kq*4 + r) then go to the units of the
+    // recurrent product (h planes carry 2 h): * 2^(1 - ex)
+    float xsc = 1.f, xcr[4] = {1.f, 1.f, 1.f, 1.f};
+    if (NP == 2 && fuse0) {
+        const int cb = p.clip0 + g * 16, cl = p.clip0 + p.B - 1;
+        xsc = s16_pow2(s16_exponent(pp.amax_x[cb + li <= cl ? cb + li : cl]));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) xcr[r] = s16_pow2(1 - s16_exponent(pp.amax_x[cb + kq * 4 + r <= cl ? cb + kq * 4 + r : cl]));
+    }
     auto project0 = [&](int t) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // the pieces of x[t] have landed
         bf16x8 a[4][3];
@@ -178,6 +212,16 @@ __global__ __launch_bounds__(256) void lstm_persist6_kernel(const LstmPersist6Pa
         for (int ks = 0; ks < 4; ++ks) {
             const f32x4 v0 = *reinterpret_cast<const f32x4*>(&xs_lds[wave][2 * ks][lane * 4]);
             const f32x4 v1 = *reinterpret_cast<const f32x4*>(&xs_lds[wave][2 * ks + 1][lane * 4]);
+            if (NP == 2) {
+                typedef _Float16 f16x4v __attribute__((ext_vector_type(4)));
+                const f32x4 s0 = v0 * xsc, s1 = v1 * xsc;
+                const f16x4v h0 = __builtin_convertvector(s0, f16x4v), h1 = __builtin_convertvector(s1, f16x4v);
+                const f16x4v l0 = __builtin_convertvector(s0 - __builtin_convertvector(h0, f32x4), f16x4v);
+                const f16x4v l1 = __builtin_convertvector(s1 - __builtin_convertvector(h1, f32x4), f16x4v);
+                a[ks][0] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7));
+                a[ks][1] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7));
+                continue;
+            }
             unsigned h[8], m[8], l[8];
 #pragma unroll
             for (int e = 0; e < 4; ++e) { split3(v0[e], h[e], m[e], l[e]); split3(v1[e], h[4 + e], m[4 + e], l[4 + e]); }
@@ -197,6 +241,12 @@ __global__ __launch_bounds__(256) void lstm_persist6_kernel(const LstmPersist6Pa
 #pragma unroll
         for (int n = 0; n < 4; ++n) accP[n] = f32x4{0.f, 0.f, 0.f, 0.f};
         mac(a, wb, accP);
+        if (NP == 2) {
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) accP[n][r] *= xcr[r];
+        }
     };
     auto project = [&](int t) -> bool {
         bf16x8 a[4][3];
@@ -240,7 +290,10 @@ __global__ __launch_bounds__(256) void lstm_persist6_kernel(const LstmPersist6Pa
         lds_barrier();
         float pre[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) pre[q] = gpre[q] + ((pt[0][q][ec][ej] + pt[1][q][ec][ej]) + (pt[2][q][ec][ej] + pt[3][q][ec][ej]));
+        for (int q = 0; q < 4; ++q) {
+            const float sum = (pt[0][q][ec][ej] + pt[1][q][ec][ej]) + (pt[2][q][ec][ej] + pt[3][q][ec][ej]);
+            pre[q] = NP == 2 ? __fmaf_rn(sum, wiv[q], gpre[q]) : gpre[q] + sum;
+        }
         const float ig = sigmoidf_(pre[0]), fg = sigmoidf_(pre[1]), gg = tanhf_(pre[2]), og = sigmoidf_(pre[3]);
         cstate = fg * cstate + ig * gg;
         const float hn = og * tanhf_(cstate);
@@ -253,6 +306,15 @@ __global__ __launch_bounds__(256) void lstm_persist6_kernel(const LstmPersist6Pa
             const bool nonfinite = !(fabsf(hn) < 2.0f);
             if (nonfinite && live) atomicMin(pp.poison + erow, t);
             const float hp = nonfinite ? 0.f : hn;
+            if (NP == 2) {
+                const float h2 = hp + hp;
+                const _Float16 hh = (_Float16)h2;
+                const _Float16 hl = (_Float16)(h2 - (float)hh);
+                char* dst = hmine + (long long)t * p.h_ts + goff + (long long)idx * SLICE_BYTES;
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)dst, 0, SLICE_BYTES, 0x00020000);
+                __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, hh), rs, hpos, 0, LP_SC1);
+                __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, hl), rs, 512 + hpos, 0, LP_SC1);
+            } else {
             const unsigned bh = __float_as_uint(hp) & 0xffff0000u;
             const float r1 = hp - __uint_as_float(bh);
             const unsigned bm = __float_as_uint(r1) & 0xffff0000u;
@@ -262,6 +324,7 @@ __global__ __launch_bounds__(256) void lstm_persist6_kernel(const LstmPersist6Pa
             __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(bh >> 16), rs, hpos, 0, LP_SC1);
             __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(bm >> 16), rs, 512 + hpos, 0, LP_SC1);
             __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(bl >> 16), rs, 1024 + hpos, 0, LP_SC1);
+            }
         }
         if (layer == 1) {
             if (live) {

@@ -10,9 +10,9 @@ exist offline).  Clips are independent units: every rank encodes/decodes its own
 (weak scaling); with N > 1 the only collective is the RCCL all_gather of the token ids, and it is
 inside the timed step.  Rank 0 prints ONE JSON line (contract in the task statement) carrying
   roofline     -- dominant kernel (by HIP-event time measured in the timed steps) against the pipe that bounds it:
-                  the dense bf16 MFMA peak (2.5 PF) for the split-operand tap-GEMM (6 bf16 partial products per fp32
-                  product, tap_gemm6.h; AC_GEMM=fp32 selects the exact-product kernels, bounded by the 157.3 TF fp32
-                  MFMA peak) or HBM (8 TB/s)
+                  the dense fp16 MFMA peak (2.5 PF) for the split-operand tap-GEMM (3 fp16 partial products per fp32
+                  product, split16.h; --precision fp32_bf16x3: 6 bf16 products, tap_gemm6.h; fp32_exact: the exact-product
+                  kernels, bounded by the 157.3 TF fp32 MFMA peak) or HBM (8 TB/s)
   cpu_baseline -- the CPU oracle (torch-CPU restatement of the reference) timed on this host's
                   cores on a bounded sample of the same workload.  Baseline only.
 """
@@ -30,7 +30,11 @@ sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # same guide: dense bf16 MFMA peak (the 5 PF headline includes 2:1 sparsity)
-SPLIT_TERMS = 6                 # tap_gemm6.h: bf16 partial products executed per fp32 product
+SPLIT_TERMS = 6                 # tap_gemm6.h, three bf16 planes: partial products executed per fp32 product
+SPLIT16_TERMS = 3               # split16.h, two fp16 planes (the default arithmetic): partial products per fp32 product
+PEAK_F16_MFMA_TFLOPS = 2500.0   # same guide: dense fp16 MFMA peak = the bf16 one
+# bare v_mfma_f32_32x32x16_f16 stream on random operands (tools/ubench/mfma_f16_probe.hip): 1.58-1.68 PF at 1.54-1.69 GHz
+SUSTAINED_F16_MFMA_TFLOPS = 1680.0
 PEAK_HBM_GBS = 8000.0          # same guide, "HBM3E peak BW" (spec; 6.29 TB/s achievable)
 # What the bf16 matrix pipe SUSTAINS on random operands: the bare v_mfma_f32_32x32x16_bf16 stream keeps the pipe 100 % busy and
 # power management drops the shader clock to 1.66-1.8 GHz (measured in-kernel, profiles/r2_tapgemm_variants.md): 1.69-1.83 PF
@@ -188,7 +192,7 @@ def main():
                     help="encodec = BASELINE.json configs[1] (the contract's default); mimi = configs[3] shape (SURVEY.md §8 f3); "
                          "dac = configs[2] (DAC 44.1 kHz, 9 codebooks; use --batch 256); wavtokenizer = configs[4] (40 tok/s, 64 clips per GPU)")
     ap.add_argument("--seconds", type=float, default=10.0)
-    ap.add_argument("--precision", choices=["fp32", "fp32_exact", "bf16"], default=None,
+    ap.add_argument("--precision", choices=["fp32", "fp32_exact", "bf16", "fp32_bf16x3"], default=None,
                     help="arithmetic of the GEMM-shaped kernels: default = fp32 fidelity (split-operand; the parity arithmetic, what `value` is "
                          "quoted for); bf16 = OPT-IN reduced precision, a reported side mode with its own parity figures")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -296,9 +300,13 @@ def main():
             # split-operand kernels (tap_gemm6.h arithmetic): every fp32 product is 6 bf16 MFMA partial products, so the kernel's
             # roofline is the dense bf16 MFMA peak; `achieved` counts the bf16 flops it actually executes
             eq = flops / (tot_ms * 1e-3) / 1e12
-            roof = {"bound": "mfma", "achieved": round(SPLIT_TERMS * eq, 1), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "pipe": f"bf16 MFMA, {SPLIT_TERMS} partial products per fp32 product", "fp32_equivalent_tflops": round(eq, 2),
-                    "power_capped_peak": SUSTAINED_BF16_MFMA_TFLOPS, "frac_of_power_capped_peak": round(SPLIT_TERMS * eq / SUSTAINED_BF16_MFMA_TFLOPS, 4)}
+            s16 = all(m_[0].rstrip().endswith(", 2>") for m_ in members)     # split16.h instantiations (template argument NP = 2)
+            terms, cap = (SPLIT16_TERMS, SUSTAINED_F16_MFMA_TFLOPS) if s16 else (SPLIT_TERMS, SUSTAINED_BF16_MFMA_TFLOPS)
+            roof = {"bound": "mfma", "achieved": round(terms * eq, 1), "peak": PEAK_F16_MFMA_TFLOPS if s16 else PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "pipe": (f"fp16 MFMA, {terms} partial products per fp32 product (two fp16 planes per operand, split16.h)" if s16 else
+                             f"bf16 MFMA, {terms} partial products per fp32 product"), "fp32_equivalent_tflops": round(eq, 2),
+                    "fp32_equivalent_peak": round((PEAK_F16_MFMA_TFLOPS if s16 else PEAK_BF16_MFMA_TFLOPS) / terms, 1),
+                    "power_capped_peak": cap, "frac_of_power_capped_peak": round(terms * eq / cap, 4)}
         elif ai > PEAK_FP32_MFMA_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9):
             roof = {"bound": "mfma", "achieved": round(flops / (tot_ms * 1e-3) / 1e12, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
                     "unit": "TFLOP/s"}
@@ -341,7 +349,9 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": {"fp32_exact": "f32", "bf16": "bf16 operands / f32 accumulate in the tap-GEMMs (OPT-IN side mode, not the parity arithmetic); everything else f32-faithful"}.get(
-                mode_, "f32 (GEMMs and LSTM products: operands split exactly into 3 bf16 terms, 6 partial products, fp32 accumulate)"),
+                mode_, "f32 (GEMM-shaped kernels: operands as two scaled fp16 planes, 3 partial products, fp32 accumulate -- split16.h; LSTM "
+                       "products: three bf16 planes, 6 partial products)" if mode_ == "fp32" else
+                       "f32 (GEMMs and LSTM products: operands split exactly into 3 bf16 terms, 6 partial products, fp32 accumulate)"),
             "data": f"synthetic (0.1*N(0,1) clips, seeded synthetic weights of the {label} architecture)",
             "config": {"workload": f"{label} {ncb} codebooks, encode+decode, {B} clips x {args.seconds:g} s per GPU, resident in HBM",
                        "clips_per_gpu": B, "seconds_per_clip": args.seconds, "parallelism": f"clip-sharded x{world}"},
