@@ -16,6 +16,7 @@
 #include "lstm.h"
 #include "lstm_persist.h"
 #include "lstm_persist6.h"
+#include "lstm_persist16.h"
 #include "rvq.h"
 #include "tap_gemm.h"
 #include "tap_gemm4.h"
@@ -1457,7 +1458,7 @@ int lstm_fwd(ac_handle* h, hipStream_t st, const LstmPlan& lp, const Act& x, con
         }
         int* poison = reinterpret_cast<int*>(ws.c);   // the cell-state buffer of the per-step kernels is free on this path
         if (!h->gemm_fp32) HIPCHK(h, hipMemsetAsync(poison, 0x7f, (size_t)B * sizeof(int), st));
-        ProfScope ps(h, st, h->gemm_fp32 ? "lstm_persist_kernel" : lp.persist16_inv ? "lstm_persist6_kernel<2>" : "lstm_persist6_kernel<3>", 2.0 * T * (double)B * 4 * D * D * (nroles + (fuse_in ? 1 : 0)),
+        ProfScope ps(h, st, h->gemm_fp32 ? "lstm_persist_kernel" : lp.persist16_inv ? "lstm_persist16_kernel" : "lstm_persist6_kernel<3>", 2.0 * T * (double)B * 4 * D * D * (nroles + (fuse_in ? 1 : 0)),
                      (double)T * ((double)B * 4 * D * 4 + 3.0 * B * D * 4) + 12.0 * D * D * 4, chunks);
         auto tail = [&](int c0, int nb, const int* pz) {
             LstmTailParams tp{};
@@ -1508,15 +1509,33 @@ int lstm_fwd(ac_handle* h, hipStream_t st, const LstmPlan& lp, const Act& x, con
                 q6.bias0 = h->blob + lp.ih[0].b_off;
                 q6.fuse_in = fuse_in ? 1 : 0;
                 q6.poison = poison;
+                q6.hseq0_local = ws.gin1;     // free on this path (the per-step kernels' layer-1 pre-activations)
                 HIPCHK(h, hipMemsetAsync(h->lp_ctl, 0, LP_CTL_WORDS * sizeof(unsigned), st));
                 // the exchange validates itself: every element of the h buffers starts as the "not yet written" pattern
                 const size_t hbytes = (size_t)T * (size_t)q6.base.h_ts;
                 HIPCHK(h, hipMemsetAsync(ws.hseq0, 0xFF, hbytes, st));
                 HIPCHK(h, hipMemsetAsync(ws.hseq1, 0xFF, hbytes, st));
+                if (l16) HIPCHK(h, hipMemsetAsync(ws.gin1, 0xFF, hbytes, st));
                 void* args6[] = {&q6};
-                HIPCHK(h, hipLaunchCooperativeKernel(l16 ? reinterpret_cast<const void*>(lstm_persist6_kernel<2>) : reinterpret_cast<const void*>(lstm_persist6_kernel<3>),
-                                                     dim3(256), dim3(256), args6, 0, st));
+                const void* kfn = l16 ? (fuse_in ? reinterpret_cast<const void*>(lstm_persist16_kernel<true>) : reinterpret_cast<const void*>(lstm_persist16_kernel<false>))
+                                      : reinterpret_cast<const void*>(lstm_persist6_kernel<3>);
+                HIPCHK(h, hipLaunchCooperativeKernel(kfn, dim3(256), dim3(l16 ? 512 : 256), args6, 0, st));
                 tail(c0, q.B, poison);
+                if (q.dbg & 32) {   // developer trace: 100 MHz real-time stamps of steps 100 .. 103 (lstm_persist6.h)
+                    HIPCHK(h, hipStreamSynchronize(st));
+                    std::vector<unsigned long long> tr(8 * 64);
+                    HIPCHK(h, hipMemcpy(tr.data(), h->lp_ctl + LP_CTL_FLAGS, tr.size() * 8, hipMemcpyDeviceToHost));
+                    for (int role = 0; role < 2; ++role) {
+                        std::fprintf(stderr, "lstm trace role %d (layer %d), 10 ns units from step start: ", role, role & 1);
+                        for (int s_ = 0; s_ < 4; ++s_) {
+                            const unsigned long long* r = &tr[role * 64 + s_ * 8];
+                            std::fprintf(stderr, "| t=%d:", 100 + s_);
+                            for (int k = 1; k < 8; ++k) std::fprintf(stderr, " %lld", r[k] ? (long long)(r[k] - r[0]) : -1LL);
+                            if (s_ < 3) std::fprintf(stderr, " next %lld ", (long long)(r[8] - r[0]));
+                        }
+                        std::fprintf(stderr, "\n");
+                    }
+                }
                 continue;
             }
             HIPCHK(h, hipMemsetAsync(h->lp_ctl, 0, LP_CTL_WORDS * sizeof(unsigned), st));
@@ -1690,8 +1709,8 @@ Workspace plan_ws(const ac_handle* h, int B, int T_in /*samples, encoder*/, int 
     }
     mx = std::max(mx, (size_t)N * std::max(h->D, c.hidden_size));
     w.act_floats = align_up(mx * B, 64);
-    w.gin = align_up((size_t)N * B * 4 * h->D, 64);
     w.hseq = align_up((size_t)N * ((B + 31) / 32 * 32) * h->D * 3 / 2, 64);   // clips padded to the 32-clip workgroup tile; x1.5: bf16 plane blocks (lstm_persist6.h)
+    w.gin = std::max(align_up((size_t)N * B * 4 * h->D, 64), w.hseq);          // gin1 doubles as layer 0's local h copy on the persistent path
     w.c = align_up((size_t)2 * B * h->D, 64);
     w.total_bytes = (NACT * w.act_floats + 2 * w.gin + 2 * w.hseq + w.c) * sizeof(float) + 256;
     return w;

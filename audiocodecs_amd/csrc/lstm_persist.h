@@ -54,6 +54,7 @@ constexpr int LP_CTL_WORDS = LP_CTL_FLAGS + 4 * 2 * LP_SLICES * LP_FLAG_STRIDE;
 typedef unsigned u32x4_lp __attribute__((ext_vector_type(4)));
 #define LP_RLX __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 constexpr int LP_SC1 = 16;   // buffer cache-policy bit: agent scope
+constexpr int LP_SC0 = 1;    // buffer cache-policy bit: workgroup scope (a store is complete when the XCD's L2 has it)
 
 __device__ __forceinline__ unsigned lp_xcc_id() { return __builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xf; }   // hwreg(HW_REG_XCC_ID, 0, 4)
 

@@ -1,0 +1,336 @@
+// lstm_persist16: the persistent 2-layer LSTM (lstm_persist.h: mathematics, control words, bounded waits, tail kernel;
+// lstm_persist6.h: self-validating exchange) in split16.h arithmetic -- two fp16 planes per operand, 3 partial products --
+// re-scheduled around what the round-2 traces of the 4-wave kernel showed (tools/ubench/xcd_exchange2.hip, AC_LSTM_DBG=32):
+//   * EIGHT waves per workgroup (one workgroup per CU, two waves per SIMD): a wave owns an EIGHTH of K for the workgroup's 64 gate
+//     columns, so its share of the two weight matrices of its layer is 128 registers and everything fits the 256 architectural
+//     VGPRs.  With four waves the weights spilled into AccVGPRs and every MFMA was preceded by four v_accvgpr_read copies and a
+//     hazard nop: the 48 MFMAs of a product took 0.6 us instead of 0.4.
+//   * PLACEMENT: XCD x hosts all 32 unit slices of layer x & 1 of clip group x >> 1.  The recurrent exchange of a layer stays
+//     inside one XCD's L2: h is published with workgroup-scope (sc0) stores -- complete when the L2 has them, no write-through
+//     -- and read by the 32 peers with agent-scope (sc1) loads that miss the per-CU L1 and hit that L2: 1.1 us per
+//     publish / read-32 KB round against 2.2 us for a role spread over an XCD pair or published with sc1 stores.
+//   * layer 0 -> layer 1 crosses to the neighbouring XCD.  An sc1 store is acknowledged only when written through, and the
+//     memory counter is in order, so the next recurrent load would wait for it: layer 0 keeps its last LP16_BATCH published
+//     values in LDS and writes them to hseq0 once per batch; layer 1 runs that far behind.
+//   * the CU's load path RETURNS IN ORDER: every request that takes an HBM or cross-XCD round trip (x[t+3] of the fused input
+//     projection, h0[t+2] for layer 1's projection, the skip value) is issued right BEHIND the request for the next recurrent
+//     operand and has a whole step to arrive; the recurrent request itself is issued in the middle of the projection that
+//     follows the publish (the peers publish at about the same time), so its round trip runs under the projection's MFMAs; when
+//     it comes back incomplete, the step starts with the ordinary polling load.
+// h lies in (-1, 1): it travels as 2 h = hi + lo (|hi| < 2 keeps bit 14 clear, the exchange's "has arrived" test); the rows of
+// [W_ih | W_hh] of a layer share one power-of-two scale per gate row; the fused layer-0 projection scales x[t] by its clip's amax
+// scale and rescales the result to the recurrent product's units (exact).  A slice block is [2 planes][16 clips][16 units] fp16.
+#pragma once
+#include "lstm_persist6.h"
+
+namespace ac {
+
+constexpr int LP16_BATCH = 8;                        // steps of h0 per hand-over to layer 1
+
+// FUSE: compile-time copy of LstmPersist6Params::fuse_in (a run-time branch around the gin loads would make the compiler wait
+// for ALL outstanding memory operations in front of the gate arithmetic)
+template <bool FUSE>
+__global__ __launch_bounds__(512) void lstm_persist16_kernel(const LstmPersist6Params pp) {
+    const LstmPersistParams& p = pp.base;
+    constexpr int D = LP_D, NP = 2;
+    constexpr int SLICE_BYTES = LP16_SLICE_BYTES;
+    constexpr long long GROUP_BYTES = LP16_GROUP_BYTES;
+    __shared__ float part[2][8][4][16][17];      // [step parity][wave = K eighth][gate][clip][unit]
+    __shared__ unsigned s_x, s_slot;
+    __shared__ unsigned short hist[LP16_BATCH][2][256];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // uniform for the compiler too (buffer descriptors depend on it)
+    const int li = lane & 15, kq = lane >> 4;
+    unsigned* tmo = p.ctl + LP_CTL_TIMEOUT;
+    if (tid == 0) {
+        s_x = lp_xcc_id();
+        s_slot = __hip_atomic_fetch_add(&p.ctl[LP_CTL_SLOTS + (s_x & 7) * 16], 1u, LP_RLX);
+    }
+    __syncthreads();
+    const int x = s_x & 7, slot = s_slot;
+    const int g = x >> 1;
+    const int G = (p.B + 15) >> 4;
+    if (slot >= 32) {   // more than 32 workgroups on this XCD: the placement the roles rely on does not hold -> everybody leaves
+        if (tid == 0) __hip_atomic_store(tmo, 2u, LP_RLX);
+        return;
+    }
+    if (g >= G) return;
+    if (p.dbg & 16) {   // test hook (AC_LSTM_DBG=16): behave like a launch whose bounded waits expired
+        if (tid == 0) __hip_atomic_store(tmo, 1u, LP_RLX);
+        return;
+    }
+    if ((p.dbg & 1) && (x & 1) == 1) return;
+    const int layer_rt = x & 1, idx = slot, u0 = idx * 16;
+    auto body = [&](auto layer_tag) {
+    constexpr int layer = decltype(layer_tag)::value;
+
+    // ---- weights -> registers: [gate][k-step of 32 inside this wave's 64 k][plane].  The packed image is
+    // [matrix][32 slices][4 K quarters][4 gates][4 k-steps][2 planes][64 lanes][8]: wave w = quarter w / 2, k-steps 2 (w & 1) ..
+    bf16x8 wa[4][2][2], wb[4][2][2];                          // layer 0: wa = W_hh0, wb = W_ih0;  layer 1: wa = W_ih1, wb = W_hh1
+    {
+        const long long mat = (long long)LP_SLICES * 4 * 4 * 4 * NP * 512;     // 16-bit elements per matrix
+        const __bf16* base = pp.w_pk6 + ((long long)idx * 4 + (wave >> 1)) * (4 * 4 * NP * 512) + lane * 8;
+        const __bf16* pa = base + (layer == 0 ? 0 : mat);
+        const __bf16* pb = base + (layer == 0 ? 3 : 2) * mat;
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl) {
+                    const int o = ((n * 4 + (wave & 1) * 2 + ks) * NP + pl) * 512;
+                    wa[n][ks][pl] = *reinterpret_cast<const bf16x8*>(pa + o);
+                    if (layer || FUSE) wb[n][ks][pl] = *reinterpret_cast<const bf16x8*>(pb + o);
+                    else wb[n][ks][pl] = wa[n][ks][pl];
+                }
+    }
+    char* h0b = reinterpret_cast<char*>(p.hseq0);
+    char* h1b = reinterpret_cast<char*>(p.hseq1);
+    char* hmine = layer ? h1b : reinterpret_cast<char*>(pp.hseq0_local);
+    const long long goff = (long long)(p.group0 + g) * GROUP_BYTES;
+
+    // gate threads: the first 256 threads own (clip ec, unit ej) of the slice, as in the 4-wave kernels
+    const bool gate_thr = tid < 256;
+    const int ec = (tid & 255) >> 4, ej = tid & 15;
+    const int eb = g * 16 + ec;
+    const bool live = gate_thr && eb < p.B;
+    const long long erow = (long long)(p.clip0 + eb);
+    const int eu = u0 + ej;
+    float cstate = 0.f;
+    float bq[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool fuse0 = layer == 0 && FUSE;
+    if (layer == 1 || fuse0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bq[q] = (layer ? p.bias1 : pp.bias0)[q * D + eu];
+    }
+    float wiv[4];                                             // 2^-s of this thread's gate rows, times 1/2 for the 2 h planes
+#pragma unroll
+    for (int q = 0; q < 4; ++q) wiv[q] = 0.5f * pp.winv[layer * 4 * D + q * D + eu];
+    const int hpos = ec * 32 + ej * 2;                         // byte offset of (clip, unit) inside a plane of the slice block
+
+    // A operand: for k-step ks of this wave's K eighth (slices 4 wave .. 4 wave + 3), lane (clip li, kq) reads units 8 kq .. 8 kq + 7
+    auto load_a = [&](const char* seq, int t, bf16x8 (&a)[2][2]) {
+        const char* src = seq + (long long)t * p.h_ts + goff + (long long)(wave * 4) * SLICE_BYTES;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, 4 * SLICE_BYTES, 0x00020000);
+        const int lo = (kq >> 1) * SLICE_BYTES + li * 32 + (kq & 1) * 16;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl)
+                a[ks][pl] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, ks * 2 * SLICE_BYTES + pl * 512 + lo, 0, LP_SC1));
+    };
+    auto mac = [&](const bf16x8 (&a)[2][2], const bf16x8 (&w)[4][2][2], f32x4 (&acc)[4], int ks0 = 0, int ks1 = 2) {
+#pragma unroll
+        for (int ks = ks0; ks < ks1; ++ks)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {   // split16.h: lo hi, hi lo, hi hi on the fp16 pipe
+                f32x4 v = acc[n];
+                v = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a[ks][1]), __builtin_bit_cast(f16x8, w[n][ks][0]), v, 0, 0, 0);
+                v = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a[ks][0]), __builtin_bit_cast(f16x8, w[n][ks][1]), v, 0, 0, 0);
+                acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a[ks][0]), __builtin_bit_cast(f16x8, w[n][ks][0]), v, 0, 0, 0);
+            }
+    };
+    auto valid = [&](const bf16x8 (&a)[2][2]) -> bool {        // bit 14 of every element clear = every piece has arrived
+        unsigned bad = 0;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl) {
+                const u32x4_t w = __builtin_bit_cast(u32x4_t, a[ks][pl]);
+                bad |= (w.x | w.y) | (w.z | w.w);
+            }
+        return __all((bad & 0x40004000u) == 0u);
+    };
+    // SELF-VALIDATING exchange (lstm_persist6.h): the h buffers start as 0xFF bytes; spins are bounded by the timeout word
+    auto load_valid = [&](const char* seq, int t, bf16x8 (&a)[2][2]) -> bool {
+        for (unsigned spins = 0;; ++spins) {
+            load_a(seq, t, a);
+            if (valid(a) || (p.dbg & 4)) return true;
+            if ((spins & 63) == 63 && __hip_atomic_load(tmo, LP_RLX)) return false;
+            if (spins > (1u << 18)) { __hip_atomic_store(tmo, 1u, LP_RLX); return false; }
+            __builtin_amdgcn_s_sleep(4);
+        }
+    };
+    bf16x8 arec[2][2];               // recurrent operand requested ahead (see the header)
+    float skip_next = 0.f;           // layer 1: x[t+1] of this thread's (clip, unit), requested a step ahead
+    f32x4 accP[4];
+    // layer 0 (fused input projection): x[t] of clip li, this wave's K eighth: 16 fp32 per lane in registers, requested one step
+    // ahead right behind the recurrent request (plain loads: the compiler then waits for exactly the registers it needs; an
+    // LDS-DMA fetch made every later LDS access wait for it)
+    const bool xlive = g * 16 + li < p.B;
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.skip + (long long)(p.clip0 + g * 16) * p.skip_bs), 0, (int)(((long long)(p.B - g * 16 < 16 ? p.B - g * 16 : 16)) * p.skip_bs * 4), 0x00020000);
+    const int xoff = xlive ? (int)((long long)li * p.skip_bs * 4) + (wave * 64 + 8 * kq) * 4 : 0x7fff0000;
+    f32x4 xr[2][2];                                           // [k-step][half]: floats 8 kq .. 8 kq + 3 / + 4 .. + 7 of the k-step
+    auto fetch0 = [&](int t) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf)
+                xr[ks][hf] = bufload16(xrs, xlive ? xoff + (t * D + ks * 32 + hf * 4) * 4 : 0x7fff0000, 0);
+    };
+    // x[t] of clip li is scaled by its clip's 2^ex; the projection's rows (clips kq*4 + r) then go to the units of the recurrent
+    // product (h planes carry 2 h): * 2^(1 - ex)
+    float xsc = 1.f, xcr[4] = {1.f, 1.f, 1.f, 1.f};
+    if (fuse0) {
+        const int cb = p.clip0 + g * 16, cl = p.clip0 + p.B - 1;
+        xsc = s16_pow2(s16_exponent(pp.amax_x[cb + li <= cl ? cb + li : cl]));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) xcr[r] = s16_pow2(1 - s16_exponent(pp.amax_x[cb + kq * 4 + r <= cl ? cb + kq * 4 + r : cl]));
+    }
+    // layer 0: accP = W_ih0 * x[t] from xr; trec >= 0: the requests for the peers' h[trec] and for x[t + 1] go out after the first
+    // k-step
+    auto project0 = [&](int t, int trec, auto rec_tag) {
+        bf16x8 a[2][2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            typedef _Float16 f16x4v __attribute__((ext_vector_type(4)));
+            const f32x4 s0 = xr[ks][0] * xsc, s1 = xr[ks][1] * xsc;
+            const f16x4v h0 = __builtin_convertvector(s0, f16x4v), h1 = __builtin_convertvector(s1, f16x4v);
+            const f16x4v l0 = __builtin_convertvector(s0 - __builtin_convertvector(h0, f32x4), f16x4v);
+            const f16x4v l1 = __builtin_convertvector(s1 - __builtin_convertvector(h1, f32x4), f16x4v);
+            a[ks][0] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7));
+            a[ks][1] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7));
+        }
+#pragma unroll
+        for (int n = 0; n < 4; ++n) accP[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // NO request below sits under a condition: a register that is loaded on one path and carried on the other becomes a
+        // copy at the join -- and the copy waits for the load (the loop latch then waited for every request of the step)
+        mac(a, wb, accP, 0, 1);
+        if constexpr (decltype(rec_tag)::value) load_a(hmine, trec, arec);
+        mac(a, wb, accP, 1, 2);
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) accP[n][r] *= xcr[r];
+        fetch0(t + 1 < p.T ? t + 1 : t);          // behind the recurrent request (in-order load path), into registers nothing else wants
+    };
+    auto project = [&](int t) -> bool {                        // layer 1, polling path
+        bf16x8 a[2][2];
+        if (!load_valid(h0b, t, a)) return false;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) accP[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        mac(a, wa, accP);
+        return true;
+    };
+#pragma unroll
+    for (int n = 0; n < 4; ++n) accP[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (layer == 1 && !project(0)) return;
+    if (fuse0) {
+        fetch0(0);
+        project0(0, 0, std::false_type{});                     // (leaves x[1] on its way)
+    }
+    // layer 1's skip value: requested without a divergent branch around the load (threads without a clip read clip0's row) --
+    // the join of such a branch made the compiler wait for every outstanding request in the middle of the projection
+    const float* skip_row = p.skip + (live ? erow : (long long)p.clip0) * p.skip_bs + eu;
+    if (layer == 1) skip_next = skip_row[0];
+    // layer 1: the operand of the projection of step t+1 (h0[t+1], written by the neighbouring XCD) is requested at the very end
+    // of step t-1 (its registers are free once that step's projection has consumed them); it validates itself like every operand
+    bf16x8 ap[2][2];
+    if (layer == 1) load_a(h0b, p.T > 1 ? 1 : 0, ap);
+
+    // developer trace (AC_LSTM_DBG & 32): 100 MHz stamps of slice 0 / thread 0 of every role at steps 100 .. 103 into the (unused)
+    // flag words of the control block: [role = 2 g + layer][step][point]
+    const bool trc = (p.dbg & 32) && idx == 0 && tid == 0;
+    unsigned long long* trw = reinterpret_cast<unsigned long long*>(p.ctl + LP_CTL_FLAGS) + (g * 2 + layer) * 64;
+#define LP16_TRC(pt_) do { if (trc && t >= 100 && t < 104) trw[(t - 100) * 8 + (pt_)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+    auto step = [&](int t) -> bool {
+        if (trc && t >= 100 && t < 104) { trw[(t - 100) * 8 + 6] = 0; trw[(t - 100) * 8 + 7] = 0; }
+        LP16_TRC(0);
+        float gpre[4] = {bq[0], bq[1], bq[2], bq[3]};
+        const float skipv = skip_next;
+        if (live && layer == 0 && !FUSE) {
+            const float* gp = p.gin0 + (long long)t * p.gin_ts + erow * (4 * D);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) gpre[q] = gp[q * D + eu];
+        }
+        f32x4 acc[4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[n] = accP[n];
+        if (t > 0) {
+            // (arec: requested in the previous step's projection; incomplete, or never requested without a projection: poll)
+            if (!((layer == 1 || fuse0) && (valid(arec) || (p.dbg & 4))) && !load_valid(hmine, t - 1, arec)) return false;
+            LP16_TRC(1);
+            if (layer == 0) mac(arec, wa, acc);
+            else mac(arec, wb, acc);
+        }
+        LP16_TRC(2);
+        float (&pt)[8][4][16][17] = part[t & 1];
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pt[wave][n][kq * 4 + r][li] = acc[n][r];
+        lds_barrier();
+        LP16_TRC(3);
+        float hn = 0.f;
+        if (gate_thr) {
+            float pre[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float sum = ((pt[0][q][ec][ej] + pt[1][q][ec][ej]) + (pt[2][q][ec][ej] + pt[3][q][ec][ej])) +
+                                  ((pt[4][q][ec][ej] + pt[5][q][ec][ej]) + (pt[6][q][ec][ej] + pt[7][q][ec][ej]));
+                pre[q] = __fmaf_rn(sum, wiv[q], gpre[q]);
+            }
+            LP16_TRC(6);
+            const float ig = sigmoidf_(pre[0]), fg = sigmoidf_(pre[1]), gg = tanhf_(pre[2]), og = sigmoidf_(pre[3]);
+            cstate = fg * cstate + ig * gg;
+            hn = og * tanhf_(cstate);
+            LP16_TRC(7);
+            // ---- publish h[t] (no flag, no wait).  A non-finite state must not look like "not yet written": publish a finite
+            // stand-in and record the step; lstm_tail_kernel turns this clip's outputs from that step on into NaN (lstm_persist6.h)
+            const bool nonfinite = !(fabsf(hn) < 2.0f);
+            if (nonfinite && live) atomicMin(pp.poison + erow, t);
+            const float hp = nonfinite ? 0.f : hn;
+            const float h2 = hp + hp;
+            const _Float16 hh = (_Float16)h2;
+            const _Float16 hl = (_Float16)(h2 - (float)hh);
+            char* dst = hmine + (long long)t * p.h_ts + goff + (long long)idx * SLICE_BYTES;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)dst, 0, SLICE_BYTES, 0x00020000);
+            __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, hh), rs, hpos, 0, LP_SC0);
+            __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, hl), rs, 512 + hpos, 0, LP_SC0);
+            if (layer == 0) {   // the copy layer 1 reads from the neighbouring XCD: kept for the batch store below
+                hist[t % LP16_BATCH][0][tid] = __builtin_bit_cast(unsigned short, hh);
+                hist[t % LP16_BATCH][1][tid] = __builtin_bit_cast(unsigned short, hl);
+            }
+        }
+        LP16_TRC(4);
+        if (layer == 0 && gate_thr && ((t + 1) % LP16_BATCH == 0 || t + 1 == p.T)) {   // hand the batch over (own slots: no barrier)
+            for (int tb = t - (t % LP16_BATCH); tb <= t; ++tb) {
+                const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(h0b + (long long)tb * p.h_ts + goff + (long long)idx * SLICE_BYTES), 0, SLICE_BYTES, 0x00020000);
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl) __builtin_amdgcn_raw_buffer_store_b16(hist[tb % LP16_BATCH][pl][tid], rx, pl * 512 + hpos, 0, LP_SC1);
+            }
+        }
+        if (layer == 1) {
+            if (live) {
+                const float yv = hn + skipv;
+                const long long o = erow * p.y_bs + (long long)t * D + eu;
+                if (p.yout) p.yout[o] = yv;
+                if (p.yout_elu) p.yout_elu[o] = elu1(yv);
+            }
+            // projection of step t+1 (the last step repeats its own: no request sits under a condition, see project0)
+            const int t1 = t + 1 < p.T ? t + 1 : t;
+            if (!(valid(ap) || (p.dbg & 4)) && !load_valid(h0b, t1, ap)) return false;   // layer 0 is steps ahead: normally complete
+#pragma unroll
+            for (int n = 0; n < 4; ++n) accP[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+            mac(ap, wa, accP, 0, 1);
+            load_a(hmine, t, arec);
+            // cross-XCD / HBM round trips go BEHIND the recurrent request and have a whole step to arrive
+            skip_next = skip_row[(long long)t1 * D];
+            mac(ap, wa, accP, 1, 2);
+            load_a(h0b, t + 2 < p.T ? t + 2 : t1, ap);
+        } else if (fuse0) {
+            project0(t + 1 < p.T ? t + 1 : t, t, std::true_type{});
+        }
+        LP16_TRC(5);
+        return true;
+    };
+    for (int t = 0; t < p.T; ++t)
+        if (!step(t)) return;
+#undef LP16_TRC
+    };
+    if (layer_rt == 0) body(std::integral_constant<int, 0>{});
+    else body(std::integral_constant<int, 1>{});
+}
+
+}  // namespace ac

@@ -39,6 +39,7 @@ struct LstmPersist6Params {
     // (indexed by clip, fuse_in only)
     const float* winv;
     const unsigned* amax_x;
+    void* hseq0_local;          // lstm_persist16.h: layer 0's own copy of h0 (same layout as hseq0)
 };
 
 // workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every outstanding global access (its
