@@ -840,15 +840,16 @@ const unsigned* amax_of(ac_handle* h, hipStream_t st, const float* x, long long 
 
 // `rows` words of the row ring (split16.h row mode); zeroed when a kernel is going to atomicMax into them
 unsigned* rowmax_new(ac_handle* h, hipStream_t st, long long rows, bool zero) {
-    if ((size_t)rows * 8 > h->row_cap) {     // grows before any word of this size class has been handed out
+    const size_t need = ((size_t)rows + 63) / 64 * 64;      // allocations are 64-word granules; the ring holds eight of them
+    if (need * 8 > h->row_cap) {             // grows before any word of this size class has been handed out
         if (h->row_buf) { if (hipStreamSynchronize(st) != hipSuccess) return nullptr; (void)hipFree(h->row_buf); h->row_buf = nullptr; }
-        h->row_cap = (size_t)rows * 8;
+        h->row_cap = need * 8;
         if (hipMalloc(&h->row_buf, h->row_cap * 4) != hipSuccess) { h->row_cap = 0; return nullptr; }
         h->row_next = 0;
     }
-    if (h->row_next + (size_t)rows > h->row_cap) h->row_next = 0;
+    if (h->row_next + need > h->row_cap) h->row_next = 0;
     unsigned* r = h->row_buf + h->row_next;
-    h->row_next += ((size_t)rows + 63) / 64 * 64;
+    h->row_next += need;
     if (zero && hipMemsetAsync(r, 0, (size_t)rows * 4, st) != hipSuccess) return nullptr;
     return r;
 }
@@ -965,10 +966,14 @@ int run_tap(ac_handle* h, hipStream_t st, TapGemmParams& p) {
     } while (0)
     const bool want_rows = p.amax_out_rows != nullptr;    // (any non-null value is a request)
     p.amax_out_rows = nullptr;
+    const int want_rowmode = p.amax_rows;
+    p.amax_rows = 0;
     if (w6) {
         p.clk = h->clk_dev;
         auto iv = h->winv_of.find((size_t)(p.w - h->blob));
-        const bool rowmode = iv != h->winv_of.end() && p.B == 1 && p.nseg == 1 && p.seg[0].J == 1 && p.seg[0].s == 1 && p.seg[0].pad == 0 &&
+        // (row mode only on the caller's request -- the linear layers over merged token matrices: a conv that merely happens to
+        // run with one clip must scale like the same conv in a batch, or a clip's result would depend on the batch size)
+        const bool rowmode = want_rowmode && iv != h->winv_of.end() && p.B == 1 && p.nseg == 1 && p.seg[0].J == 1 && p.seg[0].s == 1 && p.seg[0].pad == 0 &&
                              p.seg[0].lim >= p.M && p.seg[0].L >= p.M && p.y_off == 0;
         if (rowmode) {                    // split16.h row mode: a linear layer over a merged row matrix -- one scale per row
             TapSeg& sg = p.seg[0];

@@ -71,6 +71,7 @@ int mimi_linear(ac_handle* h, hipStream_t st, const PackedGemm& g, const float* 
         if (one && epi.rowmax_in) { xa.amax = epi.rowmax_in; xa.amax_n = -(int)n; }
         p.seg[0] = make_seg(xa, 1, 1, PAD_ZERO, 0, kofs, nullptr);
         if (one && epi.rowmax_out) p.amax_out_rows = reinterpret_cast<unsigned*>(1);   // request; run_tap allocates
+        p.amax_rows = 1;                           // split16.h row mode: every row scales by its own amax
         p.w = h->blob + g.w_off;
         p.bias = g.has_bias ? h->blob + g.b_off : nullptr;
         p.y = y + r0 * y_pitch;
@@ -280,6 +281,7 @@ int mimi_rvq_decode(ac_handle* h, hipStream_t st, const long long* toks, int F, 
     p.M = F;
     p.N = H;
     p.Ktot = 2 * Dq;
+    p.amax_rows = 1;                               // split16.h row mode: a merged row matrix, every row scales by its own amax
     return run_tap(h, st, p);
 }
 
