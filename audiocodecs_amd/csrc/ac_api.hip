@@ -389,6 +389,8 @@ struct Packer {
         o[2] = 0;
     }
     bool use16() const { return h->split16 && !h->gemm_bf16 && !h->gemm_fp32; }
+    // the LSTM stays fp32-faithful in the opt-in bf16 mode: split16 there too (three bf16 planes only in AC_PRECISION_FP32_BF16X3)
+    bool lstm16() const { return !h->gemm_fp32 && (h->split16 || h->gemm_bf16); }
     // tap_gemm6 NP = 2 image: [n-tile of 32][k-step of 16][plane 2][lane 64][8 fp16] of the scaled rows + winv[N]
     void pack16(const PackedGemm& g) {
         const size_t n_el = (size_t)g.N * g.Ktot;
@@ -679,8 +681,8 @@ struct Packer {
                                         blob[lp.persist_off + m * mat + ((((size_t)idx * 4 + w) * 4 + n) * 8 + ks) * 256 + lane * 4 + e] =
                                             (*mats[m])[(size_t)(n * D + idx * 16 + (lane & 15)) * D + (w * 8 + ks) * 16 + 4 * (lane >> 4) + e];
             const std::vector<float>* mats6[4] = {mats[0], mats[1], mats[2], get(prefix + ".weight_ih_l0", (size_t)4 * D * D)};
-            if (use16()) {
-                // lstm_persist6_kernel<2>: [hh0, ih1, hh1, ih0][32 slices][4 waves][4 gates][4 k-steps of 32][2 planes][64 lanes][8 fp16] of the
+            if (lstm16()) {
+                // lstm_persist16_kernel: [hh0, ih1, hh1, ih0][32 slices][4 waves][4 gates][4 k-steps of 32][2 planes][64 lanes][8 fp16] of the
                 // scaled rows; the two matrices of a layer share the accumulator, so their rows share the scale
                 const size_t mat16 = (size_t)LP_SLICES * 4 * 4 * 4 * 2 * 512;
                 lp.persist6_off = reserve((4 * mat16 + 1) / 2);
@@ -810,7 +812,7 @@ constexpr int AMAX_SLOTS = 4096;
 
 // start of a pass over B clips: all slots back to zero
 int amax_begin(ac_handle* h, hipStream_t st, int B) {
-    if (!h->split16 || h->gemm_fp32 || h->gemm_bf16) return AC_OK;
+    if (!(h->split16 || h->gemm_bf16) || h->gemm_fp32) return AC_OK;
     if (B > h->amax_B) {
         if (h->amax_buf) { HIPCHK(h, hipStreamSynchronize(st)); HIPCHK(h, hipFree(h->amax_buf)); h->amax_buf = nullptr; }
         h->amax_B = std::max(B, 64);
@@ -823,7 +825,7 @@ int amax_begin(ac_handle* h, hipStream_t st, int B) {
 }
 // a fresh slot for a producer's output (null when the arithmetic does not use them)
 unsigned* amax_new(ac_handle* h) {
-    if (!h->split16 || h->gemm_fp32 || h->gemm_bf16 || !h->amax_buf || h->amax_next >= AMAX_SLOTS) return nullptr;
+    if (!(h->split16 || h->gemm_bf16) || h->gemm_fp32 || !h->amax_buf || h->amax_next >= AMAX_SLOTS) return nullptr;
     return h->amax_buf + (size_t)(h->amax_next++) * h->amax_B;
 }
 // the amax of a tensor a consumer is about to split: the producer's, or one more read of the tensor

@@ -52,11 +52,12 @@ int dac_conv(ac_handle* h, hipStream_t st, const PackedGemm& g, const Act& x, in
     p.alpha_inv = sn.ai;
     p.alpha_n = sn.n;
     p.tanh_out = tanh_out;
+    const int rc = run_tap(h, st, p);
     if (y) {
-        y->raw = Act{out.raw, p.y_bs, p.y_rs, M, g.N};
-        y->elu = Act{out.elu, p.y_bs, p.y_rs, M, g.N};
+        y->raw = Act{out.raw, p.y_bs, p.y_rs, M, g.N, p.amax_out, p.B};
+        y->elu = Act{out.elu, p.y_bs, p.y_rs, M, g.N, p.amax_out, p.B};
     }
-    return run_tap(h, st, p);
+    return rc;
 }
 
 // transposed conv k = 2s, stride s, padding pp: rows m' = 0..L of s*cout floats, row m' = [x[m'-1] | x[m']] * Wp,
@@ -82,9 +83,10 @@ int dac_convtr(ac_handle* h, hipStream_t st, const PackedGemm& g, const Act& x, 
     p.alpha = sn.a;
     p.alpha_inv = sn.ai;
     p.alpha_n = sn.n;
-    y->raw = Act{out.raw, p.y_bs, cout, Lout, cout};
-    y->elu = Act{out.elu, p.y_bs, cout, Lout, cout};
-    return run_tap(h, st, p);
+    const int rc = run_tap(h, st, p);
+    y->raw = Act{out.raw, p.y_bs, cout, Lout, cout, p.amax_out, p.B};
+    y->elu = Act{out.elu, p.y_bs, cout, Lout, cout, p.amax_out, p.B};
+    return rc;
 }
 
 // one ResidualUnit; `next`: Snake of whatever consumes the unit's output; `want_raw`: the next layer is another unit

@@ -47,11 +47,12 @@ int mimi_conv(ac_handle* h, hipStream_t st, const PackedGemm& g, const Act& x, i
     p.res_bs = epi.res_bs;
     p.res_rs = epi.res_rs;
     p.gelu = epi.gelu;
+    const int rc = run_tap(h, st, p);
     if (y) {
-        y->raw = Act{out.raw, p.y_bs, p.y_rs, M, g.N};
-        y->elu = Act{out.elu, p.y_bs, p.y_rs, M, g.N};
+        y->raw = Act{out.raw, p.y_bs, p.y_rs, M, g.N, p.amax_out, p.B};
+        y->elu = Act{out.elu, p.y_bs, p.y_rs, M, g.N, p.amax_out, p.B};
     }
-    return run_tap(h, st, p);
+    return rc;
 }
 
 // y[rows][N] = epi(x[rows][cin-slice] * W^T): a 1-tap GEMM over the merged token matrix.  `x_pitch` is the row
@@ -98,21 +99,23 @@ int mimi_resblock(ac_handle* h, hipStream_t st, const ResBlockPlan& rb, const Ac
     const long long bs = (long long)x.raw.L * rb.C;
     if (rb128_ok(h, rb) && c.residual_kernel_size == 3 && c.compress == 2 && x.raw.ts == 128 && x.raw.bs == bs && aligned16(x.raw.p) &&
         bs * 4 < 0x70000000LL) {
-        int rc = launch_rb128_fused6<false>(h, st, rb, x, out, B, PAD_ZERO);
+        const unsigned* am = nullptr;
+        int rc = launch_rb128_fused6<false>(h, st, rb, x, out, B, PAD_ZERO, &am);
         if (rc) return rc;
         HIPCHK(h, hipGetLastError());
-        y->raw = Act{out.raw, bs, rb.C, x.raw.L, rb.C};
-        y->elu = Act{out.elu, bs, rb.C, x.raw.L, rb.C};
+        y->raw = Act{out.raw, bs, rb.C, x.raw.L, rb.C, am, B};
+        y->elu = Act{out.elu, bs, rb.C, x.raw.L, rb.C, am, B};
         return AC_OK;
     }
     if (rb.C == 64 && c.residual_kernel_size == 3 && c.compress == 2 && x.raw.ts == rb.C && x.raw.bs == bs && aligned16(x.raw.p) &&
         (!x.elu.p || (x.elu.ts == rb.C && x.elu.bs == bs && aligned16(x.elu.p)))) {
-        int rc = rb.has6 && !h->gemm_fp32 ? launch_rb_fused6<64, false>(h, st, rb, x, out, B, PAD_ZERO)
+        const unsigned* am = nullptr;
+        int rc = rb.has6 && !h->gemm_fp32 ? launch_rb_fused6<64, false>(h, st, rb, x, out, B, PAD_ZERO, &am)
                                           : launch_rb_fused<64, 64, 2, false>(h, st, rb, x, out, B, PAD_ZERO);
         if (rc) return rc;
         HIPCHK(h, hipGetLastError());
-        y->raw = Act{out.raw, bs, rb.C, x.raw.L, rb.C};
-        y->elu = Act{out.elu, bs, rb.C, x.raw.L, rb.C};
+        y->raw = Act{out.raw, bs, rb.C, x.raw.L, rb.C, am, B};
+        y->elu = Act{out.elu, bs, rb.C, x.raw.L, rb.C, am, B};
         return AC_OK;
     }
     Act2 hv;
@@ -376,6 +379,8 @@ int mimi_encoder_fwd(ac_handle* h, hipStream_t st, const float* sig, int B, int 
     rc = transformer_fwd(h, st, m.enc_tf, stream, B, T25, s);
     if (rc) return rc;
     ws.give(s.ln); ws.give(s.qkv); ws.give(s.att); ws.give(s.hid);
+    y.raw.amax = nullptr;   // the transformer rewrote `stream` in place: the conv's amax (split16.h) no longer describes it
+    y.raw.amax_n = 0;
     rc = mimi_conv(h, st, m.down, y.raw, 2 * c.resample_stride, c.resample_stride, PAD_REPLICATE, Out{feats, nullptr}, B, &x);
     ws.give(stream);
     if (rc) return rc;
