@@ -1241,9 +1241,10 @@ int launch_rb_fused6(ac_handle* h, hipStream_t st, const ResBlockPlan& rb, const
     if (const char* d = std::getenv("AC_RB6_DBG")) p.dbg = std::atoi(d);
     const bool s16 = rb_split16(h, st, rb, x, B, p, amax_out);
     if (s16 && !p.amax_in) return fail(h, AC_ESTATE, "out of amax slots (split16.h)");
-    if (int rc = ensure_lds(h, h->gemm_bf16 ? reinterpret_cast<const void*>(rb_fused6_kernel<C, SC, 1>) : s16 ? reinterpret_cast<const void*>(rb_fused6_kernel<C, SC, 2>) : reinterpret_cast<const void*>(rb_fused6_kernel<C, SC, 3>), Cfg::lds_bytes)) return rc;
+    const size_t lds6 = s16 ? Cfg::lds_bytes16 : Cfg::lds_bytes;
+    if (int rc = ensure_lds(h, h->gemm_bf16 ? reinterpret_cast<const void*>(rb_fused6_kernel<C, SC, 1>) : s16 ? reinterpret_cast<const void*>(rb_fused6_kernel<C, SC, 2>) : reinterpret_cast<const void*>(rb_fused6_kernel<C, SC, 3>), lds6)) return rc;
     const long long total = (long long)B * p.ntiles;
-    const int per_cu = C == 64 ? 2 : 3;
+    const int per_cu = s16 ? rb6_occupancy<C, SC, 2>() : rb6_occupancy<C, SC, 3>();
     const int grid = (int)std::min<long long>(total, (long long)per_cu * 256);   // persistent
     const double L = x.raw.L;
     const std::string np6 = h->gemm_bf16 ? ", 1>" : s16 ? ", 2>" : ", 3>";
@@ -1251,7 +1252,7 @@ int launch_rb_fused6(ac_handle* h, hipStream_t st, const ResBlockPlan& rb, const
                  2.0 * B * L * ((double)(C / 2) * 3 * C + (double)C * (C / 2 + (SC ? C : 0))),
                  (double)B * L * C * 4.0 * (1 + (out.raw ? 1 : 0) + (out.elu ? 1 : 0)));
     if (h->gemm_bf16) hipLaunchKernelGGL((rb_fused6_kernel<C, SC, 1>), dim3(grid), dim3(256), Cfg::lds_bytes, st, p);
-    else if (s16) hipLaunchKernelGGL((rb_fused6_kernel<C, SC, 2>), dim3(grid), dim3(256), Cfg::lds_bytes, st, p);
+    else if (s16) hipLaunchKernelGGL((rb_fused6_kernel<C, SC, 2>), dim3(grid), dim3(256), lds6, st, p);
     else hipLaunchKernelGGL((rb_fused6_kernel<C, SC, 3>), dim3(grid), dim3(256), Cfg::lds_bytes, st, p);
     return AC_OK;
 }

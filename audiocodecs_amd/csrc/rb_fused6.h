@@ -72,6 +72,7 @@ struct Rb6Cfg {
     static constexpr int XE_PLANE = XE_ROWS * XP, XR_PLANE = SC ? BM * XP : 0, H_PLANE = BM * HP;
     static constexpr int SLOTS = (XE_ROWS * (C / 4) + 255) / 256;
     static constexpr size_t lds_bytes = (size_t)3 * (XE_PLANE + XR_PLANE + H_PLANE) * 2;
+    static constexpr size_t lds_bytes16 = (size_t)2 * (XE_PLANE + XR_PLANE + H_PLANE) * 2;   // split16.h: two planes
 };
 
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
@@ -124,16 +125,22 @@ __device__ __forceinline__ f32x4 mma6(const bf16x8 (&w)[3], const bf16x8 (&x)[3]
     return v;
 }
 
+// split16: two LDS planes and two thirds of the weight registers leave room for one more workgroup per CU where the kernel
+// then still fits the register file without spilling -- the identity-shortcut block (Mimi) only; the 1x1-shortcut blocks spill
+// 12 / 43 registers at the higher occupancy and run 1.2-1.8x slower
+template <int C, bool SC, int NP>
+constexpr int rb6_occupancy() { return (C == 64 ? 2 : 3) + ((NP == 2 && C == 64 && !SC) ? 1 : 0); }
 template <int C, bool SC, int NP = 3>
-__global__ __launch_bounds__(256, C == 64 ? 2 : 3) void rb_fused6_kernel(const RbFused6Params p) {
+__global__ __launch_bounds__(256, (rb6_occupancy<C, SC, NP>())) void rb_fused6_kernel(const RbFused6Params p) {
     using Cfg = Rb6Cfg<C, SC>;
     constexpr int BM = Cfg::BM, HC = Cfg::HC, XP = Cfg::XP, HP = Cfg::HP;
     constexpr int MS = Cfg::MS, NA = Cfg::NA, NB = Cfg::NB, KSA = Cfg::KSA, KSH = Cfg::KSH, KSB = Cfg::KSB;
     constexpr int NSPLIT = Cfg::NSPLIT, SLOTS = Cfg::SLOTS;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __bf16* Xe = reinterpret_cast<__bf16*>(smem);                  // [3][XE_ROWS][XP]
-    __bf16* Xr = Xe + 3 * Cfg::XE_PLANE;                           // [3][BM][XP]       (SC only)
-    __bf16* Hs = Xr + 3 * Cfg::XR_PLANE;                           // [3][BM][HP]
+    constexpr int NPL = NP == 2 ? 2 : 3;                           // planes held in LDS
+    __bf16* Xr = Xe + NPL * Cfg::XE_PLANE;                         // [NPL][BM][XP]     (SC only)
+    __bf16* Hs = Xr + NPL * Cfg::XR_PLANE;                         // [NPL][BM][HP]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -171,7 +178,7 @@ __global__ __launch_bounds__(256, C == 64 ? 2 : 3) void rb_fused6_kernel(const R
     }
     // hidden columns HC .. HCP-1 (C = 32) are K padding: zero once, the matching weight fragments are zero too
     if (HC < Cfg::HCP)
-        for (int e = tid; e < 3 * BM * (Cfg::HCP - HC); e += 256) {
+        for (int e = tid; e < NPL * BM * (Cfg::HCP - HC); e += 256) {
             const int pl = e / (BM * (Cfg::HCP - HC)), r = e % (BM * (Cfg::HCP - HC));
             Hs[pl * Cfg::H_PLANE + (r / (Cfg::HCP - HC)) * HP + HC + r % (Cfg::HCP - HC)] = (__bf16)0.f;
         }
