@@ -1032,6 +1032,8 @@ int run_tap(ac_handle* h, hipStream_t st, TapGemmParams& p) {
             const double s256 = 1.10 * fill(wg256, 512.0);
             const double s8 = (kk >= 2048 ? 1.12 : 0.95) * fill(wg256, 256.0);
             pick = s256 >= s128 && s256 >= s8 ? 1 : (s8 > s128 ? 2 : 0);
+            static const char* force = std::getenv("AC_TAP_PICK");     // developer override: 0 / 1 / 2
+            if (force && force[0] >= '0' && force[0] <= '2') pick = force[0] - '0';
         }
         if (pick == 1) TAP6_CASE(1, 4, 4, 2);
         else if (pick == 2) TAP6_CASE(1, 8, 4, 1);

@@ -1,0 +1,98 @@
+"""split16 arithmetic (csrc/split16.h: two scaled fp16 planes per operand, 3 partial products -- the default fp32-fidelity
+arithmetic of the GEMM-shaped kernels): what fp16 lacks is RANGE, so these cases push the per-clip / per-row / per-channel
+power-of-two scales: input gains from 1e-3 to 50, a loud burst inside a quiet clip, all-zero and denormal-small clips, and the
+legacy three-bf16-plane arithmetic (precision="fp32_bf16x3") beside it.  Checked against the CPU oracle with the usual policy
+(tokens exact outside fp64 near-ties, waveform within 1e-5 of the signal's scale) and for independence of batch neighbours."""
+import numpy as np
+import pytest
+import torch
+
+import parity_record
+from conftest import GOLDEN_DIR
+from golden_cases import noise
+from test_oracle_golden import TAU, tokens_match_up_to_ties
+
+pytestmark = pytest.mark.gpu
+
+
+def rms(a):
+    return float(np.sqrt(np.mean(np.asarray(a.detach().cpu().numpy(), dtype=np.float64) ** 2)))
+
+
+@pytest.fixture(scope="module")
+def enc(checkpoints):
+    from audiocodecs_amd import Encodec
+    from oracle import encodec_oracle as O
+
+    cfg, sd = checkpoints("full", 0)
+    codec = Encodec(24000, num_codebooks=8, state_dict=sd).eval()
+    return cfg, sd, codec, O.fold_weight_norm(sd), O.fold_weight_norm(sd, torch.float64)
+
+
+def _against_oracle(enc, sig, name):
+    from oracle import encodec_oracle as O
+
+    cfg, sd, codec, W, W64 = enc
+    toks = codec.sig_to_toks(sig.cuda())
+    rec = codec.toks_to_sig(toks)
+    torch.set_num_threads(min(16, max(1, torch.get_num_threads())))
+    with torch.no_grad():
+        otoks = O.sig_to_toks(cfg, W, sig)
+        _, m64 = O.sig_to_toks(cfg, W64, sig.double(), None, 8, True)
+        orec = O.toks_to_sig(cfg, W, toks.cpu())
+    diff, bad, excused = parity_record.tokens("encodec", f"split16_{name}", toks.cpu().numpy(), otoks.numpy(), m64.numpy(), TAU)
+    err = rms(rec.cpu() - orec)
+    parity_record.record("encodec", f"split16_{name}", waveform_rms_err=err)
+    assert bad == 0, f"{bad} tokens differ outside fp64 near-ties"
+    assert diff <= excused
+    assert bool(torch.isfinite(rec).all())
+    assert err < 1e-5 * max(1.0, rms(orec)), (err, rms(orec))
+    return toks, rec
+
+
+@pytest.mark.parametrize("gain", [1e-3, 1.0, 50.0])
+def test_input_gain(enc, gain):
+    sig = noise(7100, 2, 24000) * gain
+    _against_oracle(enc, sig, f"gain_{gain:g}")
+
+
+def test_loud_burst_in_a_quiet_clip_and_its_neighbours(enc):
+    cfg, sd, codec, W, W64 = enc
+    sig = noise(7101, 3, 24000) * 1e-3
+    sig[1, 9000:9400] += noise(7102, 1, 400)[0] * 30.0          # 90 dB above the rest of the clip
+    toks, rec = _against_oracle(enc, sig, "burst")
+    # the quiet neighbours do not see the burst: a clip's scales are its own
+    for b in (0, 2):
+        tb = codec.sig_to_toks(sig[b : b + 1].cuda())
+        assert torch.equal(tb, toks[b : b + 1])
+        assert torch.equal(codec.toks_to_sig(tb), rec[b : b + 1])
+    assert torch.equal(codec.sig_to_toks(sig[1:2].cuda()), toks[1:2])
+
+
+def test_zero_and_vanishing_clips(enc):
+    sig = torch.zeros(3, 16000)
+    sig[1] = noise(7103, 1, 16000)[0] * 1e-30
+    sig[2] = noise(7104, 1, 16000)[0]
+    _against_oracle(enc, sig, "zero_tiny")
+
+
+def test_three_bf16_plane_arithmetic_beside_it(enc, golden, checkpoints):
+    import golden_cases
+    from audiocodecs_amd import Encodec
+
+    cfg, sd, codec, W, W64 = enc
+    legacy = Encodec(24000, num_codebooks=8, state_dict=sd, precision="fp32_bf16x3").eval()
+    sig = noise(7105, 2, 48000).cuda()
+    fa, fb = codec.sig_to_feats(sig), legacy.sig_to_feats(sig)
+    assert rms(fa - fb) < 1e-5 * max(1.0, rms(fb))
+    ta, tb = codec.sig_to_toks(sig), legacy.sig_to_toks(sig)
+    assert float((ta == tb).float().mean()) > 0.995
+    assert rms(codec.toks_to_sig(ta) - legacy.toks_to_sig(ta)) < 1e-5
+    z, meta = golden
+    case = next(c for c in golden_cases.CASES if c["name"] == "full_noise_b2")
+    inp = golden_cases.make_input(case, GOLDEN_DIR)
+    toks = legacy.sig_to_toks(inp["sig"].cuda())
+    n, bad, excused = tokens_match_up_to_ties(toks.cpu().numpy(), z["full_noise_b2.toks"].astype(np.int64), z["full_noise_b2.margin64"])
+    assert bad == 0
+    nat = next(iter(legacy._natives.values()))
+    assert nat.lib.ac_lstm_status(nat.h) >= 0
