@@ -1468,7 +1468,7 @@ int lstm_fwd(ac_handle* h, hipStream_t st, const LstmPlan& lp, const Act& x, con
         }
         int* poison = reinterpret_cast<int*>(ws.c);   // the cell-state buffer of the per-step kernels is free on this path
         if (!h->gemm_fp32) HIPCHK(h, hipMemsetAsync(poison, 0x7f, (size_t)B * sizeof(int), st));
-        ProfScope ps(h, st, h->gemm_fp32 ? "lstm_persist_kernel" : lp.persist16_inv ? "lstm_persist16_kernel" : "lstm_persist6_kernel<3>", 2.0 * T * (double)B * 4 * D * D * (nroles + (fuse_in ? 1 : 0)),
+        ProfScope ps(h, st, h->gemm_fp32 ? "lstm_persist_kernel" : lp.persist16_inv ? (fuse_in ? "lstm_persist16_kernel<true>" : "lstm_persist16_kernel<false>") : "lstm_persist6_kernel<3>", 2.0 * T * (double)B * 4 * D * D * (nroles + (fuse_in ? 1 : 0)),
                      (double)T * ((double)B * 4 * D * 4 + 3.0 * B * D * 4) + 12.0 * D * D * 4, chunks);
         auto tail = [&](int c0, int nb, const int* pz) {
             LstmTailParams tp{};

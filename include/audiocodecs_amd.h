@@ -200,16 +200,21 @@ int ac_wavtok_create(const ac_wavtok_config* cfg, ac_handle** out);
 int ac_load_weights(ac_handle* h, const char* name, const void* host_ptr, size_t bytes);
 
 /* Arithmetic of the GEMM-shaped kernels; call before ac_finalize (weights are packed for one arithmetic).
- *   AC_PRECISION_FP32        default: fp32 fidelity on the bf16 matrix pipe (operands split exactly into three bf16 terms,
- *                            6 partial products, fp32 accumulate) -- the arithmetic every parity claim is made for;
+ *   AC_PRECISION_FP32        default: fp32 fidelity on the fp16 matrix pipe ("split16", csrc/split16.h): every operand as two
+ *                            scaled fp16 planes (x 2^s = hi + lo, both round-to-nearest), 3 partial products, fp32 accumulate;
+ *                            power-of-two scales per clip (activations: largest magnitude reported by the producing kernel), per
+ *                            row (linear layers over merged token matrices) and per output channel (weights) -- the arithmetic
+ *                            every parity claim is made for;
+ *   AC_PRECISION_FP32_BF16X3 the round-1/2 arithmetic: three bf16 planes (exact truncation split), 6 partial products; same
+ *                            fidelity, no scales, ~1.3x slower; same as AC_GEMM=bf16x3;
  *   AC_PRECISION_FP32_EXACT  exact fp32 products (v_mfma_f32_16x16x4_f32) everywhere; same as AC_GEMM=fp32;
  *   AC_PRECISION_BF16        OPT-IN, not a parity mode (BASELINE.json configs[1] says "bf16"): the
  *                            tap-GEMMs, the fused residual blocks and the [64][128] layers -- i.e. every conv of the SEANet
  *                            stacks incl. the T >= 120 000 stages, and the dense layers of the transformers / backbone --
  *                            round both operands to bf16 (nearest-even) and do ONE product per pair with fp32 accumulate;
- *                            activations stay fp32 in HBM; LSTM, stem / head, codebook search stay fp32-faithful.  Reported
+ *                            activations stay fp32 in HBM; LSTM (split16), stem / head, codebook search stay fp32-faithful.  Reported
  *                            with its own token-mismatch rate and waveform error (bench.py --precision bf16); = AC_GEMM=bf16.
- * Without this call the environment variable AC_GEMM (fp32 | bf16) decides, default AC_PRECISION_FP32. */
+ * Without this call the environment variable AC_GEMM (fp32 | bf16 | bf16x3) decides, default AC_PRECISION_FP32. */
 #define AC_PRECISION_FP32 0
 #define AC_PRECISION_FP32_EXACT 1
 #define AC_PRECISION_BF16 2
