@@ -816,17 +816,17 @@ int amax_begin(ac_handle* h, hipStream_t st, int B) {
     if (B > h->amax_B) {
         if (h->amax_buf) { HIPCHK(h, hipStreamSynchronize(st)); HIPCHK(h, hipFree(h->amax_buf)); h->amax_buf = nullptr; }
         h->amax_B = std::max(B, 64);
-        HIPCHK(h, hipMalloc(&h->amax_buf, (size_t)AMAX_SLOTS * h->amax_B * 4));
+        HIPCHK(h, hipMalloc(&h->amax_buf, (size_t)AMAX_SLOTS * h->amax_B * AMAX_STRIDE * 4));
         h->amax_next = AMAX_SLOTS;
     }
-    if (h->amax_next) HIPCHK(h, hipMemsetAsync(h->amax_buf, 0, (size_t)std::min(h->amax_next, AMAX_SLOTS) * h->amax_B * 4, st));
+    if (h->amax_next) HIPCHK(h, hipMemsetAsync(h->amax_buf, 0, (size_t)std::min(h->amax_next, AMAX_SLOTS) * h->amax_B * AMAX_STRIDE * 4, st));
     h->amax_next = 0;
     return AC_OK;
 }
 // a fresh slot for a producer's output (null when the arithmetic does not use them)
 unsigned* amax_new(ac_handle* h) {
     if (!(h->split16 || h->gemm_bf16) || h->gemm_fp32 || !h->amax_buf || h->amax_next >= AMAX_SLOTS) return nullptr;
-    return h->amax_buf + (size_t)(h->amax_next++) * h->amax_B;
+    return h->amax_buf + (size_t)(h->amax_next++) * h->amax_B * AMAX_STRIDE;
 }
 // the amax of a tensor a consumer is about to split: the producer's, or one more read of the tensor
 const unsigned* amax_of(ac_handle* h, hipStream_t st, const float* x, long long bs, long long ts, int L, int C, int B, const unsigned* known) {
@@ -834,7 +834,7 @@ const unsigned* amax_of(ac_handle* h, hipStream_t st, const float* x, long long 
     unsigned* slot = amax_new(h);
     if (!slot || B > h->amax_B) return nullptr;
     const long long n = (long long)L * C;
-    const int gx = (int)std::max<long long>(1, std::min<long long>(cdiv((int)std::min<long long>(n / 4 + 1, 1 << 30), 256 * 8), 2048 / std::max(1, std::min(B, 64))));
+    const int gx = (int)std::max<long long>(1, std::min<long long>((n / 4 + 256 * 8 - 1) / (256 * 8), std::max(4, 8192 / std::max(1, B))));   // >= 8 vectors per thread, <= 8192 workgroups
     ProfScope ps(h, st, "amax_kernel", 0.0, (double)B * n * 4.0);
     hipLaunchKernelGGL(amax_kernel, dim3(gx, B), dim3(256), 0, st, x, bs, ts, L, C, slot);
     return slot;

@@ -174,9 +174,9 @@ __global__ __launch_bounds__(512) void lstm_persist16_kernel(const LstmPersist6P
     float xsc = 1.f, xcr[4] = {1.f, 1.f, 1.f, 1.f};
     if (fuse0) {
         const int cb = p.clip0 + g * 16, cl = p.clip0 + p.B - 1;
-        xsc = s16_pow2(s16_exponent(pp.amax_x[cb + li <= cl ? cb + li : cl]));
+        xsc = s16_pow2(s16_exponent(*amax_at(pp.amax_x, cb + li <= cl ? cb + li : cl)));
 #pragma unroll
-        for (int r = 0; r < 4; ++r) xcr[r] = s16_pow2(1 - s16_exponent(pp.amax_x[cb + kq * 4 + r <= cl ? cb + kq * 4 + r : cl]));
+        for (int r = 0; r < 4; ++r) xcr[r] = s16_pow2(1 - s16_exponent(*amax_at(pp.amax_x, cb + kq * 4 + r <= cl ? cb + kq * 4 + r : cl)));
     }
     // layer 0: accP = W_ih0 * x[t] from xr; trec >= 0: the requests for the peers' h[trec] and for x[t + 1] go out after the first
     // k-step

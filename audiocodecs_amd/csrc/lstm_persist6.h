@@ -202,9 +202,9 @@ __global__ __launch_bounds__(256) void lstm_persist6_kernel(const LstmPersist6Pa
     float xsc = 1.f, xcr[4] = {1.f, 1.f, 1.f, 1.f};
     if (NP == 2 && fuse0) {
         const int cb = p.clip0 + g * 16, cl = p.clip0 + p.B - 1;
-        xsc = s16_pow2(s16_exponent(pp.amax_x[cb + li <= cl ? cb + li : cl]));
+        xsc = s16_pow2(s16_exponent(*amax_at(pp.amax_x, cb + li <= cl ? cb + li : cl)));
 #pragma unroll
-        for (int r = 0; r < 4; ++r) xcr[r] = s16_pow2(1 - s16_exponent(pp.amax_x[cb + kq * 4 + r <= cl ? cb + kq * 4 + r : cl]));
+        for (int r = 0; r < 4; ++r) xcr[r] = s16_pow2(1 - s16_exponent(*amax_at(pp.amax_x, cb + kq * 4 + r <= cl ? cb + kq * 4 + r : cl)));
     }
     auto project0 = [&](int t) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // the pieces of x[t] have landed

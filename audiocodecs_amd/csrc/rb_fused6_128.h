@@ -89,7 +89,7 @@ __global__ __launch_bounds__(512, 1) void rb128_fused6_kernel(const RbFused6Para
     };
     Rb16Scale sc{1.f, 1.f, 1.f, 1.f};                           // scales of the tile that is staged in LDS (rb_fused6.h)
     auto store_tile = [&](int tile) {
-        if (NP == 2) sc = rb16_scale(p.amax_in[tile / p.ntiles], p.hb0, p.hb1);
+        if (NP == 2) sc = rb16_scale(*amax_at(p.amax_in, tile / p.ntiles), p.hb0, p.hb1);
 #pragma unroll
         for (int i = 0; i < SLOTS; ++i) {
             const int row = s_row[i], q = s_q4[i] / 16;
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(512, 1) void rb128_fused6_kernel(const RbFused6Para
         {
             const int b = tile / p.ntiles, t0 = (tile % p.ntiles) * BM;
             if (p.amax_out && b != omax_b) {                     // clip change: hand the finished clip's maximum over
-                amax_flush(omax, p.amax_out + omax_b);
+                amax_flush(omax, amax_at(p.amax_out, omax_b));
                 omax = 0;
                 omax_b = b;
             }
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(512, 1) void rb128_fused6_kernel(const RbFused6Para
         }
         __syncthreads();
     }
-    if (p.amax_out) amax_flush(omax, p.amax_out + omax_b);
+    if (p.amax_out) amax_flush(omax, amax_at(p.amax_out, omax_b));
 }
 
 }  // namespace ac

@@ -134,8 +134,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM* WGN == 4 ? 2 : 1) void tap_gem
     const bool rowmode = NP == 2 && p.amax_rows;
     if (NP == 2) {
         if (!rowmode) {
-            unsigned am = p.seg[0].amax[b];
-            if (p.nseg > 1) { const unsigned a1 = p.seg[1].amax[b]; am = a1 > am ? a1 : am; }
+            unsigned am = *amax_at(p.seg[0].amax, b);
+            if (p.nseg > 1) { const unsigned a1 = *amax_at(p.seg[1].amax, b); am = a1 > am ? a1 : am; }
             const int se = s16_exponent(am);
             a_scale = s16_pow2(se);
             a_inv = s16_pow2(-se);
@@ -397,7 +397,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM* WGN == 4 ? 2 : 1) void tap_gem
             }
         }
     }
-    if (p.amax_out) amax_flush(omax, p.amax_out + b);
+    if (p.amax_out) amax_flush(omax, amax_at(p.amax_out, b));
     if (p.clk && tid == 0) {   // shader clock while this workgroup lived: sum of ticks / sum of 100 MHz real-time ticks
         atomicAdd(&p.clk[0], (unsigned long long)(__builtin_amdgcn_s_memtime() - clk_t0));
         atomicAdd(&p.clk[1], (unsigned long long)(__builtin_amdgcn_s_memrealtime() - clk_r0));

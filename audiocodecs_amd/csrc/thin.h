@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const ThinParams p) {
             *reinterpret_cast<f32x4*>(p.y_elu + o) = w;
         }
     }
-    if (p.amax_out) amax_flush(omax, p.amax_out + b);
+    if (p.amax_out) amax_flush(omax, amax_at(p.amax_out, b));
 }
 
 constexpr int HEAD_TT = 256;    // outputs per workgroup (one per thread)

@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256, 4) void thin_conv6_kernel(const ThinConv6Param
     float sx = 1.f, ix = 1.f;                               // split16 scale of the clip staged in LDS
     auto store_tile = [&](int tile) {
         if (NP == 2) {
-            const int se = s16_exponent(p.amax_in[tile / p.ntiles]);
+            const int se = s16_exponent(*amax_at(p.amax_in, tile / p.ntiles));
             sx = s16_pow2(se);
             ix = s16_pow2(-se);
         }
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256, 4) void thin_conv6_kernel(const ThinConv6Param
         {
             const int b = tile / p.ntiles, m0 = (tile % p.ntiles) * T6_BM;
             if (p.amax_out && b != omax_b) {
-                amax_flush(omax, p.amax_out + omax_b);
+                amax_flush(omax, amax_at(p.amax_out, omax_b));
                 omax = 0;
                 omax_b = b;
             }
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256, 4) void thin_conv6_kernel(const ThinConv6Param
         }
         __syncthreads();
     }
-    if (p.amax_out) amax_flush(omax, p.amax_out + omax_b);
+    if (p.amax_out) amax_flush(omax, amax_at(p.amax_out, omax_b));
 }
 
 }  // namespace ac

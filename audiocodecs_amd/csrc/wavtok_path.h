@@ -238,6 +238,8 @@ int wavtok_decoder_fwd(ac_handle* h, hipStream_t st, const float* feats, int B, 
     capture(h, st, xa, B);
     auto resnet = [&](const WtResnetPlan& r) -> int {
         int e;
+        // (the normalisation kernel's waves are too many and too short to report an amax -- 144 K flushes on 64 words; the convs
+        // take it from amax_kernel: split16.h)
         if ((e = wt_groupnorm(h, st, x, r.n1w, r.n1b, stats, t, B, N, 1))) return e;
         if ((e = wt_conv(h, st, r.c1, Act{t, (long long)N * C, C, N, C}, 3, 1, 1, u, B))) return e;
         if ((e = wt_groupnorm(h, st, u, r.n2w, r.n2b, stats, t, B, N, 1))) return e;
@@ -307,7 +309,18 @@ int wavtok_decoder_fwd(ac_handle* h, hipStream_t st, const float* feats, int B, 
     {
         TapGemmParams p{};
         p.nseg = 1;
-        p.seg[0] = make_seg(Act{u, (long long)N * m.npad, m.npad, N, m.npad}, 1, m.taps, PAD_ZERO, 0, 0, nullptr);
+        Act ua{u, (long long)N * m.npad, m.npad, N, m.npad};
+        if (unsigned* slot = amax_new(h)) {      // split16.h: polar_kernel clamps the magnitude at 100 -- a bound instead of a pass
+            const float bound = 100.0f;
+            unsigned bits;
+            std::memcpy(&bits, &bound, 4);
+            if (B <= h->amax_B) {
+                hipLaunchKernelGGL(amax_fill_kernel, dim3(cdiv(B, 64)), dim3(64), 0, st, slot, bits, B);
+                ua.amax = slot;
+                ua.amax_n = B;
+            }
+        }
+        p.seg[0] = make_seg(ua, 1, m.taps, PAD_ZERO, 0, 0, nullptr);
         p.w = h->blob + m.istft.w_off;
         p.bias = nullptr;
         p.y = sig;
