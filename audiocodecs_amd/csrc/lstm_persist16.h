@@ -180,8 +180,12 @@ __global__ __launch_bounds__(512) void lstm_persist16_kernel(const LstmPersist6P
     }
     // layer 0: accP = W_ih0 * x[t] from xr; trec >= 0: the requests for the peers' h[trec] and for x[t + 1] go out after the first
     // k-step
-    auto project0 = [&](int t, int trec, auto rec_tag) {
-        bf16x8 a[2][2];
+    // The operands of the projection that FOLLOWS the publish are made ready BEFORE it (x[t+1] converted to planes in the step's
+    // head; layer 1: h0[t+1] validated there): a wait for an older load placed after the publish / output stores is a wait for
+    // those stores' acknowledgements too (one in-order counter), 0.5-0.8 us in front of the projection's MFMAs.
+    bf16x8 xa[2][2];
+    auto convert0 = [&]() {
+        bf16x8 (&a)[2][2] = xa;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             typedef _Float16 f16x4v __attribute__((ext_vector_type(4)));
@@ -192,6 +196,9 @@ __global__ __launch_bounds__(512) void lstm_persist16_kernel(const LstmPersist6P
             a[ks][0] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7));
             a[ks][1] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7));
         }
+    };
+    auto project0 = [&](int t, int trec, auto rec_tag) {
+        bf16x8 (&a)[2][2] = xa;
 #pragma unroll
         for (int n = 0; n < 4; ++n) accP[n] = f32x4{0.f, 0.f, 0.f, 0.f};
         // NO request below sits under a condition: a register that is loaded on one path and carried on the other becomes a
@@ -218,6 +225,7 @@ __global__ __launch_bounds__(512) void lstm_persist16_kernel(const LstmPersist6P
     if (layer == 1 && !project(0)) return;
     if (fuse0) {
         fetch0(0);
+        convert0();
         project0(0, 0, std::false_type{});                     // (leaves x[1] on its way)
     }
     // layer 1's skip value: requested without a divergent branch around the load (threads without a clip read clip0's row) --
@@ -254,6 +262,9 @@ __global__ __launch_bounds__(512) void lstm_persist16_kernel(const LstmPersist6P
             if (layer == 0) mac(arec, wa, acc);
             else mac(arec, wb, acc);
         }
+        bool ap_ok = true;
+        if (fuse0) convert0();                                 // x[t+1] (requested at the end of the previous step) -> planes
+        if (layer == 1) ap_ok = valid(ap) || (p.dbg & 4);      // h0[t+1] (requested at the end of the previous step) complete?
         LP16_TRC(2);
         float (&pt)[8][4][16][17] = part[t & 1];
 #pragma unroll
@@ -310,7 +321,7 @@ __global__ __launch_bounds__(512) void lstm_persist16_kernel(const LstmPersist6P
             }
             // projection of step t+1 (the last step repeats its own: no request sits under a condition, see project0)
             const int t1 = t + 1 < p.T ? t + 1 : t;
-            if (!(valid(ap) || (p.dbg & 4)) && !load_valid(h0b, t1, ap)) return false;   // layer 0 is steps ahead: normally complete
+            if (!ap_ok && !load_valid(h0b, t1, ap)) return false;   // layer 0 is steps ahead: normally complete
 #pragma unroll
             for (int n = 0; n < 4; ++n) accP[n] = f32x4{0.f, 0.f, 0.f, 0.f};
             mac(ap, wa, accP, 0, 1);
