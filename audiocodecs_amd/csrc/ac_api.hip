@@ -2470,6 +2470,18 @@ int ac_lstm_status(ac_handle* h) {
     return usable ? 1 : 0;
 }
 
+int ac_debug_split_row(const float* w, int n, uint16_t* hi, uint16_t* lo) {
+    if (!w || n < 1) return AC_EINVAL;
+    const int s = Packer::row_scale(w, (size_t)n);
+    for (int k = 0; k < n; ++k) {
+        uint16_t t[3];
+        Packer::split16h(w[k], s, t);
+        if (hi) hi[k] = t[0];
+        if (lo) lo[k] = t[1];
+    }
+    return s;
+}
+
 int ac_debug_clock(ac_handle* h, int enable, double* shader_mhz) {
     if (!h || !h->finalized) return AC_EINVAL;
     if (shader_mhz) *shader_mhz = 0.0;

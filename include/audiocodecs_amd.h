@@ -330,6 +330,11 @@ size_t ac_debug_captured(const ac_handle* h);
  * clock under a GEMM is the missing half of its roofline. */
 int ac_debug_clock(ac_handle* h, int enable, double* shader_mhz);
 
+/* Test hook (no GPU): the host-side packer's split of ONE weight row in split16 arithmetic (csrc/split16.h): the row's scale
+ * exponent s (|w| 2^s < 2^15, chosen from the row's largest magnitude), and per element the fp16 bit patterns of
+ * hi = fp16_rn(w 2^s) and lo = fp16_rn(w 2^s - hi).  Returns s.  The CPU tests compare it with numpy's float16. */
+int ac_debug_split_row(const float* w, int n, uint16_t* hi, uint16_t* lo);
+
 /* Which LSTM path the handle uses (SYNCHRONISES the device; tests / diagnostics): 1 = the persistent single-launch kernel
  * (D = 512, 2 layers, 256-CU device; opt out with the environment variable AC_LSTM=step), 0 = one launch per
  * time step, AC_EHIP = a persistent launch failed since the handle was created (a bounded wait expired, or the launch
