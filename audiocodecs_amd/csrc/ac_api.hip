@@ -1895,7 +1895,7 @@ int decoder_fwd(ac_handle* h, hipStream_t st, const long long* toks, int B, int 
 // ---------------------------------------------------------------------------------------------
 extern "C" {
 
-int ac_version(void) { return 300; }
+int ac_version(void) { return 310; }   // 310: split16 arithmetic (AC_PRECISION_FP32_BF16X3 beside it), ac_debug_split_row
 
 int ac_create(const ac_config* cfg, ac_handle** out) {
     if (!cfg || !out) return AC_EINVAL;
