@@ -36,10 +36,20 @@ struct Tap6Cfg {
     static constexpr int A_SLOTS = (A_ROWS * (KC / 4) + NT - 1) / NT;
     static constexpr int PLANE = A_ROWS * T6_PITCH;                 // bf16 elements per plane
     static constexpr int CP = 32 * WGN + 4;      // epilogue staging: one wave column tile per pass
-    static constexpr size_t main_bytes = (size_t)2 * 3 * PLANE * 2;
-    static constexpr size_t epi_bytes = (size_t)BM * CP * 4;
-    static constexpr size_t lds_bytes = main_bytes > epi_bytes ? main_bytes : epi_bytes;
+    // the epilogue stages EH 32-row tiles of the workgroup's rows at a time (WGM = 1: two of the four -- half the staging tile)
+    static constexpr int EH = WGM == 1 && WMT == 4 ? 2 : WMT;
+    static constexpr size_t epi_bytes = (size_t)32 * WGM * EH * CP * 4;
+    static constexpr size_t lds_for(int np) {               // np = 2 (split16.h): two planes in the slab
+        const size_t main_bytes = (size_t)2 * (np == 2 ? 2 : 3) * PLANE * 2;
+        return main_bytes > epi_bytes ? main_bytes : epi_bytes;
+    }
+    static constexpr size_t lds_bytes = lds_for(3);
 };
+// workgroups per CU the kernel is compiled for: the 128 x 32 wave tile in split16 arithmetic runs the lean main loop (one
+// fragment set) and fits three -- the epilogue of a workgroup (as long as its output takes to reach HBM) is then covered by two
+// others' main loops (profiles/r2_tapgemm_variants.md)
+template <int WGM, int WGN, int WMT, int WN, int NP>
+constexpr int tap6_occupancy() { return WGM * WGN == 8 ? 1 : (NP == 2 && WMT * WN == 4 && WGM == 1 ? 3 : 2); }
 
 // NP = 3: split-operand arithmetic (three bf16 planes per operand, 6 partial products): fp32 fidelity -- the default.
 // NP = 1: the opt-in bf16 mode (ac_set_precision(AC_PRECISION_BF16)): operands ROUNDED to bf16 (nearest-even), one product,
@@ -48,13 +58,14 @@ struct Tap6Cfg {
 //         the same fp32 fidelity at half the MFMAs and two thirds of the operand bytes.  Weight image
 //         [n-tile of 32][k-step of 16][plane 2][lane 64][8 fp16] of the SCALED rows; needs seg[].amax and winv.
 template <int WGM, int WGN, int WMT, int WN, int NP = 3>
-__global__ __launch_bounds__(64 * WGM * WGN, WGM* WGN == 4 ? 2 : 1) void tap_gemm6_kernel(const TapGemmParams p, const __bf16* __restrict__ wp) {
+__global__ __launch_bounds__(64 * WGM * WGN, (tap6_occupancy<WGM, WGN, WMT, WN, NP>())) void tap_gemm6_kernel(const TapGemmParams p, const __bf16* __restrict__ wp) {
     using Cfg = Tap6Cfg<WGM, WGN, WMT, WN>;
     constexpr int BM = Cfg::BM, BN = Cfg::BN, NT = Cfg::NT, A_SLOTS = Cfg::A_SLOTS, PLANE = Cfg::PLANE;
     unsigned long long clk_t0 = 0, clk_r0 = 0;
     if (p.clk) { clk_t0 = __builtin_amdgcn_s_memtime(); clk_r0 = __builtin_amdgcn_s_memrealtime(); }
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    __bf16* As0 = reinterpret_cast<__bf16*>(smem);            // [2 buffers][3 planes][A_ROWS][T6_PITCH]
+    __bf16* As0 = reinterpret_cast<__bf16*>(smem);            // [2 buffers][NPL planes][A_ROWS][T6_PITCH]
+    constexpr int NPL = NP == 2 ? 2 : 3;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -266,7 +277,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM* WGN == 4 ? 2 : 1) void tap_gem
     // LEAN (wave tile of 6-8 accumulator tiles: 128 x 64, 64 x 96): 96-128 accumulator registers leave room for ONE fragment set and TWO
     // weight sets only -- a weight set is reloaded right after the k-step that used it (one k-step ahead of its next use), the
     // A fragments of a k-step are read just before its MFMAs (the co-resident workgroup covers the LDS latency).
-    constexpr bool LEAN = WMT * WN >= 6;
+    constexpr bool LEAN = WMT * WN >= 6 || tap6_occupancy<WGM, WGN, WMT, WN, NP>() == 3;
     // one stage; returns true when it was the last one
     auto stage = [&](bf16x8 (&u0)[3][WN], bf16x8 (&u1)[3][WN], bf16x8 (&sp)[3][WN]) -> bool {
         int nsi = si, nc0 = c0, nj = j + 1;
@@ -287,7 +298,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM* WGN == 4 ? 2 : 1) void tap_gem
             if (!LEAN) load_b(s_next, sp);
             if (new_chunk) load_a(nsi, nc0, nj);
         }
-        const __bf16* Ac = As0 + abuf * 3 * PLANE + a_frag + cur_j * T6_PITCH;
+        const __bf16* Ac = As0 + abuf * NPL * PLANE + a_frag + cur_j * T6_PITCH;
         if constexpr (LEAN) {
             bf16x8 af[3][WMT];
             read_a(Ac, 0, af);
@@ -307,7 +318,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM* WGN == 4 ? 2 : 1) void tap_gem
         if (!has_next) return true;
         if (new_chunk) {                                       // the A loads had the whole stage to arrive
             abuf ^= 1;
-            store_a(As0 + abuf * 3 * PLANE);
+            store_a(As0 + abuf * NPL * PLANE);
         }
         __syncthreads();
         si = nsi; c0 = nc0; j = nj;
@@ -332,23 +343,27 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM* WGN == 4 ? 2 : 1) void tap_gem
     const bool post = p.gelu || p.scale || p.res || p.tanh_out;
     const int nvalid = p.n_valid ? p.n_valid : p.N;
     unsigned omax = 0;
+    constexpr int EH = Cfg::EH, ER = 32 * WGM * EH;       // 32-row tiles / rows staged per pass
 #pragma unroll
-    for (int c = 0; c < WN; ++c) {
+    for (int c = 0; c < WN; ++c)
+#pragma unroll
+    for (int a0 = 0; a0 < WMT; a0 += EH) {
         __syncthreads();
 #pragma unroll
-        for (int a = 0; a < WMT; ++a) {
+        for (int a = a0; a < a0 + EH; ++a) {
             const int ng = n0 + (wn * WN + c) * 32 + i32;
             const float bv = (p.bias && ng < p.N) ? p.bias[ng] : 0.f;
             const float iv = NP == 2 ? a_inv * p.winv[ng] : 1.f;     // exact: powers of two
             const float bq = rowmode ? 0.f : bv;                     // row mode: the row's 2^-s and the bias follow in the store pass
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                Cs[((wm * WMT + a) * 32 + 8 * (r / 4) + 4 * kh + (r % 4)) * CP + wn * 32 + i32] = NP == 2 ? __fmaf_rn(acc[a][c][r], iv, bq) : acc[a][c][r] + bv;
+                Cs[((wm * EH + a - a0) * 32 + 8 * (r / 4) + 4 * kh + (r % 4)) * CP + wn * 32 + i32] = NP == 2 ? __fmaf_rn(acc[a][c][r], iv, bq) : acc[a][c][r] + bv;
         }
         __syncthreads();
-        for (int e = tid; e < BM * (CW / 4); e += NT) {
+        for (int e = tid; e < ER * (CW / 4); e += NT) {
             const int row = e / (CW / 4), q = e % (CW / 4);
-            const int m = m0 + row, n = n0 + (q / 8) * (32 * WN) + 32 * c + 4 * (q % 8);
+            // staged row -> row of the workgroup tile: wave row group row / (32 EH), then the pass's EH tiles
+            const int m = m0 + (row / (32 * EH)) * (32 * WMT) + a0 * 32 + row % (32 * EH), n = n0 + (q / 8) * (32 * WN) + 32 * c + 4 * (q % 8);
             const long long fi = (long long)m * p.y_rs + n + p.y_off;
             unsigned rmax = 0;
             if (m < p.M && n < nvalid && (p.y_len == 0 || (fi >= 0 && fi < p.y_len))) {
