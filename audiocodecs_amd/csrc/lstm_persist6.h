@@ -42,14 +42,6 @@ struct LstmPersist6Params {
     void* hseq0_local;          // lstm_persist16.h: layer 0's own copy of h0 (same layout as hseq0)
 };
 
-// workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every outstanding global access (its
-// release fence), i.e. it would drain the LDS-DMA fetch that is meant to stay in flight across it
-__device__ __forceinline__ void lds_barrier() {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-}
-
 template <int NP = 3>
 __global__ __launch_bounds__(256) void lstm_persist6_kernel(const LstmPersist6Params pp) {
     const LstmPersistParams& p = pp.base;

@@ -263,7 +263,7 @@ __global__ __launch_bounds__(256, (rb6_occupancy<C, SC, NP>())) void rb_fused6_k
                     split_store4<NP>(elu4(acc[a][c]), Hs, Cfg::H_PLANE, (r0 + a * 16 + li) * HP + na0 + c * 16 + 4 * kq, cs.sb);
                 }
         }
-        if (NSPLIT > 1) __syncthreads();                        // C = 32: a wave reads back only its own rows
+        if (NSPLIT > 1) lds_barrier();                          // C = 32: a wave reads back only its own rows
         // ---- stage B: y = [W1 | Ws] * [hidden | x]^T + bf
         f32x4 acc[MS][NB];
 #pragma unroll
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(256, (rb6_occupancy<C, SC, NP>())) void rb_fused6_k
 #pragma unroll
                 for (int c = 0; c < NB; ++c) acc[a][c] = mma6<NP>(wfr[ks][c], xf[a], acc[a][c]);
         }
-        __syncthreads();                                        // every wave is done reading the slabs
+        lds_barrier();                                          // every wave is done reading the slabs
         // the next tile is staged BEFORE this tile's output stores are issued: the wait for its loads must not
         // cover the stores (the memory counter retires in order)
         if (next < total && !(p.dbg & 4)) store_tile(next);
@@ -323,7 +323,7 @@ __global__ __launch_bounds__(256, (rb6_occupancy<C, SC, NP>())) void rb_fused6_k
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();  
     }
     if (p.amax_out) amax_flush(omax, amax_at(p.amax_out, omax_b));
 }

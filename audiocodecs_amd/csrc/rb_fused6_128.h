@@ -136,7 +136,7 @@ __global__ __launch_bounds__(512, 1) void rb128_fused6_kernel(const RbFused6Para
 #pragma unroll
                 for (int a = 0; a < TT; ++a) *reinterpret_cast<f32x4*>(&Ps[(a * 16 + li) * PSP + ng * 16 + 4 * kq]) = acc[a];
             }
-            __syncthreads();
+            lds_barrier();  
             if (kg == 0) {
 #pragma unroll
                 for (int a = 0; a < TT; ++a) {
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(512, 1) void rb128_fused6_kernel(const RbFused6Para
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();  
         // ---- stage B: y = [W1 | Ws] * [hidden | x]^T + bf, output channels 16 wave ..
         f32x4 acc[TT];
 #pragma unroll
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(512, 1) void rb128_fused6_kernel(const RbFused6Para
                 for (int a = 0; a < 2; ++a) acc[a0 + a] = mma6<NP>(wfr[ks], xf[a], acc[a0 + a]);
             }
         }
-        __syncthreads();                                        // every wave is done reading the slabs
+        lds_barrier();                                          // every wave is done reading the slabs
         if (next < total) store_tile(next);                     // staged before the output stores are issued (rb_fused6.h)
         {
             const int b = tile / p.ntiles, t0 = (tile % p.ntiles) * BM;
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(512, 1) void rb128_fused6_kernel(const RbFused6Para
                 if (p.y_elu) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, elu4(v)), re, o, 0, 0);
             }
         }
-        __syncthreads();
+        lds_barrier();  
     }
     if (p.amax_out) amax_flush(omax, amax_at(p.amax_out, omax_b));
 }

@@ -25,6 +25,14 @@ namespace ac {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every outstanding global access (its release
+// fence) -- in a persistent tile loop that is a wait for the previous tile's output stores to reach HBM, once per tile
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 constexpr int T6_PITCH = 40;        // bf16 per LDS row (32 + 8): 80-byte rows keep 16-byte alignment, spread banks
 
 template <int WGM, int WGN, int WMT, int WN>

@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256, 4) void thin_conv6_kernel(const ThinConv6Param
 #pragma unroll
             for (int a = 0; a < 4; ++a) acc[a] = mma6<NP>(wr[ks], xf[a], acc[a]);
         }
-        __syncthreads();                                    // every wave is done reading the slab
+        lds_barrier();                                      // every wave is done reading the slab
         if (next < total) store_tile(next);                 // staged before the output stores are issued (rb_fused6.h)
         {
             const int b = tile / p.ntiles, m0 = (tile % p.ntiles) * T6_BM;
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256, 4) void thin_conv6_kernel(const ThinConv6Param
                 if (p.y_elu) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, elu4(v)), re, o, 0, 0);
             }
         }
-        __syncthreads();
+        lds_barrier();  
     }
     if (p.amax_out) amax_flush(omax, amax_at(p.amax_out, omax_b));
 }
