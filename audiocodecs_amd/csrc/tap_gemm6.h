@@ -57,7 +57,9 @@ struct Tap6Cfg {
 // fragment set) and fits three -- the epilogue of a workgroup (as long as its output takes to reach HBM) is then covered by two
 // others' main loops (profiles/r2_tapgemm_variants.md)
 template <int WGM, int WGN, int WMT, int WN, int NP>
-constexpr int tap6_occupancy() { return WGM * WGN == 8 ? 1 : (NP == 2 && WMT * WN == 4 && WGM == 1 ? 3 : 2); }
+constexpr int tap6_occupancy() {
+    return WGM * WGN == 8 ? 1 : (NP == 2 && ((WMT * WN == 4 && WGM == 1) || (WGM == 2 && WGN == 2 && WMT == 2 && WN == 1)) ? 3 : 2);   // (64 x 32 wave tiles, N % 64: 156 VGPRs as they are)
+}
 
 // NP = 3: split-operand arithmetic (three bf16 planes per operand, 6 partial products): fp32 fidelity -- the default.
 // NP = 1: the opt-in bf16 mode (ac_set_precision(AC_PRECISION_BF16)): operands ROUNDED to bf16 (nearest-even), one product,
@@ -285,7 +287,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (tap6_occupancy<WGM, WGN, WMT, WN, 
     // LEAN (wave tile of 6-8 accumulator tiles: 128 x 64, 64 x 96): 96-128 accumulator registers leave room for ONE fragment set and TWO
     // weight sets only -- a weight set is reloaded right after the k-step that used it (one k-step ahead of its next use), the
     // A fragments of a k-step are read just before its MFMAs (the co-resident workgroup covers the LDS latency).
-    constexpr bool LEAN = WMT * WN >= 6 || tap6_occupancy<WGM, WGN, WMT, WN, NP>() == 3;
+    constexpr bool LEAN = WMT * WN >= 6 || (WGM == 1 && tap6_occupancy<WGM, WGN, WMT, WN, NP>() == 3);
     // one stage; returns true when it was the last one
     auto stage = [&](bf16x8 (&u0)[3][WN], bf16x8 (&u1)[3][WN], bf16x8 (&sp)[3][WN]) -> bool {
         int nsi = si, nc0 = c0, nj = j + 1;
