@@ -18,7 +18,7 @@ namespace ac {
 
 constexpr int LP6_SLICE_BYTES = 3 * 16 * 16 * 2;     // 1536
 constexpr long long LP6_GROUP_BYTES = (long long)LP_SLICES * LP6_SLICE_BYTES;   // 48 KB per 16-clip group and time step
-// NP = 2 (split16.h): two fp16 planes.  h lies in (-1, 1): it travels as 2 h = hi + lo (|hi| < 2 keeps bit 14 clear -- the
+// NP = 2 (split16.h): two fp16 planes.  h lies in [-1, 1]: it travels unscaled as hi + lo (|hi| <= 1 keeps bit 14 clear -- the
 // exchange's "has arrived" test works unchanged on fp16), the weight rows of the two matrices that share an accumulator
 // ([W_ih | W_hh] of a layer) carry ONE power-of-two scale per gate row, and the fused layer-0 input projection scales x[t] by
 // its clip's amax scale and rescales the projection to the recurrent product's units (exact: powers of two) before use.
@@ -113,10 +113,10 @@ __global__ __launch_bounds__(256) void lstm_persist6_kernel(const LstmPersist6Pa
 #pragma unroll
         for (int q = 0; q < 4; ++q) bq[q] = (layer ? p.bias1 : pp.bias0)[q * D + eu];
     }
-    float wiv[4] = {1.f, 1.f, 1.f, 1.f};                      // NP = 2: 2^-s of this thread's gate rows, times 1/2 for the 2 h planes
+    float wiv[4] = {1.f, 1.f, 1.f, 1.f};                      // NP = 2: 2^-s of this thread's gate rows, (h travels unscaled)
     if (NP == 2) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) wiv[q] = 0.5f * pp.winv[layer * 4 * D + q * D + eu];
+        for (int q = 0; q < 4; ++q) wiv[q] = pp.winv[layer * 4 * D + q * D + eu];
     }
     const int hpos = ec * 32 + ej * 2;                         // byte offset of (clip, unit) inside a plane of the slice block
 
@@ -190,13 +190,13 @@ __global__ __launch_bounds__(256) void lstm_persist6_kernel(const LstmPersist6Pa
                                                      xlive ? xoff + (t * D + (i >> 1) * 32 + (i & 1) * 4) * 4 : 0x7fff0000, 0, 0, 0);
     };
     // NP = 2: x[t] of clip li is scaled by its clip's 2^ex; the projection's rows (clips kq*4 + r) then go to the units of the
-    // recurrent product (h planes carry 2 h): * 2^(1 - ex)
+    // recurrent product (h travels unscaled): * 2^-ex
     float xsc = 1.f, xcr[4] = {1.f, 1.f, 1.f, 1.f};
     if (NP == 2 && fuse0) {
         const int cb = p.clip0 + g * 16, cl = p.clip0 + p.B - 1;
         xsc = s16_pow2(s16_exponent(*amax_at(pp.amax_x, cb + li <= cl ? cb + li : cl)));
 #pragma unroll
-        for (int r = 0; r < 4; ++r) xcr[r] = s16_pow2(1 - s16_exponent(*amax_at(pp.amax_x, cb + kq * 4 + r <= cl ? cb + kq * 4 + r : cl)));
+        for (int r = 0; r < 4; ++r) xcr[r] = s16_pow2(-s16_exponent(*amax_at(pp.amax_x, cb + kq * 4 + r <= cl ? cb + kq * 4 + r : cl)));
     }
     auto project0 = [&](int t) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // the pieces of x[t] have landed
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(256) void lstm_persist6_kernel(const LstmPersist6Pa
             if (nonfinite && live) atomicMin(pp.poison + erow, t);
             const float hp = nonfinite ? 0.f : hn;
             if (NP == 2) {
-                const float h2 = hp + hp;
+                const float h2 = hp;                         // UNSCALED: |h| <= 1 and 1.0 itself occurs (saturated gates); fp16(2.0) would have bit 14 set
                 const _Float16 hh = (_Float16)h2;
                 const _Float16 hl = (_Float16)(h2 - (float)hh);
                 char* dst = hmine + (long long)t * p.h_ts + goff + (long long)idx * SLICE_BYTES;

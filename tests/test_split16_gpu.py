@@ -76,6 +76,30 @@ def test_zero_and_vanishing_clips(enc):
     _against_oracle(enc, sig, "zero_tiny")
 
 
+def test_saturated_lstm(checkpoints):
+    """Gate biases of +30 drive i, g, o to 1.0 and c up by one per step: h becomes EXACTLY 1.0 after a few steps.  The exchange of
+    the persistent LSTM tells "arrived" from "not yet written" by bit 14 of every published fp16 term, so h must travel in a
+    form whose bit 14 is clear at 1.0 -- an early version published 2 h and would have timed out here."""
+    from audiocodecs_amd import Encodec
+    from oracle import encodec_oracle as O
+
+    cfg, sd = checkpoints("full", 0)
+    sd = {k: v.clone() for k, v in sd.items()}
+    D = 512
+    n = 0
+    for k in sd:
+        if ".lstm.bias_ih_l" in k:
+            sd[k][:] = 30.0              # i, f, g, o all saturated: c[t] = c[t-1] + 1, h = 1.0 exactly once tanh(c) rounds to 1
+            n += 1
+    assert n == 4
+    codec = Encodec(24000, num_codebooks=8, state_dict=sd).eval()
+    sig = noise(7106, 2, 16000)
+    W, W64 = O.fold_weight_norm(sd), O.fold_weight_norm(sd, torch.float64)
+    _against_oracle((cfg, sd, codec, W, W64), sig, "saturated_lstm")
+    nat = next(iter(codec._natives.values()))
+    assert nat.lib.ac_lstm_status(nat.h) >= 0, "persistent LSTM reported a failed launch"
+
+
 def test_three_bf16_plane_arithmetic_beside_it(enc, golden, checkpoints):
     import golden_cases
     from audiocodecs_amd import Encodec
