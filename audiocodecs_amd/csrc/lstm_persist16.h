@@ -17,8 +17,8 @@
 //     operand and has a whole step to arrive; the recurrent request itself is issued in the middle of the projection that
 //     follows the publish (the peers publish at about the same time), so its round trip runs under the projection's MFMAs; when
 //     it comes back incomplete, the step starts with the ordinary polling load.
-// h lies in [-1, 1] (1.0 itself occurs when gates saturate): it travels UNSCALED as hi + lo (|hi| <= 1 keeps bit 14 clear, the
-// exchange's "has arrived" test; lo is then a denormal for |h| < 0.25: 2^-25 absolute, far below the gates' fp32 accumulation); the rows of
+// h lies in [-1, 1]: it travels as 2 h = hi + lo with |hi| < 2 (bit 14 clear: the exchange's "has arrived" test).  1.0 itself occurs
+// when the gates saturate, and fp16(2.0) has bit 14 set: hi is capped at the largest fp16 below 2, lo takes the rest; the rows of
 // [W_ih | W_hh] of a layer share one power-of-two scale per gate row; the fused layer-0 projection scales x[t] by its clip's amax
 // scale and rescales the result to the recurrent product's units (exact).  A slice block is [2 planes][16 clips][16 units] fp16.
 #pragma once
@@ -26,6 +26,10 @@
 
 namespace ac {
 
+#ifndef LP16_HEXP
+#define LP16_HEXP 1                                  // h travels as 2^LP16_HEXP h (0: unscaled)
+#endif
+constexpr float LP16_HSCALE = LP16_HEXP ? 2.0f : 1.0f, LP16_HINV = LP16_HEXP ? 0.5f : 1.0f;
 constexpr int LP16_BATCH = 8;                        // steps of h0 per hand-over to layer 1
 
 // FUSE: compile-time copy of LstmPersist6Params::fuse_in (a run-time branch around the gin loads would make the compiler wait
@@ -104,9 +108,9 @@ __global__ __launch_bounds__(512) void lstm_persist16_kernel(const LstmPersist6P
 #pragma unroll
         for (int q = 0; q < 4; ++q) bq[q] = (layer ? p.bias1 : pp.bias0)[q * D + eu];
     }
-    float wiv[4];                                             // 2^-s of this thread's gate rows, (h travels unscaled)
+    float wiv[4];                                             // 2^-s of this thread's gate rows, (h travels as 2 h)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) wiv[q] = pp.winv[layer * 4 * D + q * D + eu];
+    for (int q = 0; q < 4; ++q) wiv[q] = LP16_HINV * pp.winv[layer * 4 * D + q * D + eu];
     const int hpos = ec * 32 + ej * 2;                         // byte offset of (clip, unit) inside a plane of the slice block
 
     // A operand: for k-step ks of this wave's K eighth (slices 4 wave .. 4 wave + 3), lane (clip li, kq) reads units 8 kq .. 8 kq + 7
@@ -171,13 +175,13 @@ __global__ __launch_bounds__(512) void lstm_persist16_kernel(const LstmPersist6P
                 xr[ks][hf] = bufload16(xrs, xlive ? xoff + (t * D + ks * 32 + hf * 4) * 4 : 0x7fff0000, 0);
     };
     // x[t] of clip li is scaled by its clip's 2^ex; the projection's rows (clips kq*4 + r) then go to the units of the recurrent
-    // product (h travels unscaled): * 2^-ex
+    // product (h travels as 2 h): * 2^-ex
     float xsc = 1.f, xcr[4] = {1.f, 1.f, 1.f, 1.f};
     if (fuse0) {
         const int cb = p.clip0 + g * 16, cl = p.clip0 + p.B - 1;
         xsc = s16_pow2(s16_exponent(*amax_at(pp.amax_x, cb + li <= cl ? cb + li : cl)));
 #pragma unroll
-        for (int r = 0; r < 4; ++r) xcr[r] = s16_pow2(-s16_exponent(*amax_at(pp.amax_x, cb + kq * 4 + r <= cl ? cb + kq * 4 + r : cl)));
+        for (int r = 0; r < 4; ++r) xcr[r] = s16_pow2(LP16_HEXP - s16_exponent(*amax_at(pp.amax_x, cb + kq * 4 + r <= cl ? cb + kq * 4 + r : cl)));
     }
     // layer 0: accP = W_ih0 * x[t] from xr; trec >= 0: the requests for the peers' h[trec] and for x[t + 1] go out after the first
     // k-step
@@ -293,8 +297,13 @@ __global__ __launch_bounds__(512) void lstm_persist16_kernel(const LstmPersist6P
             const bool nonfinite = !(fabsf(hn) < 2.0f);
             if (nonfinite && live) atomicMin(pp.poison + erow, t);
             const float hp = nonfinite ? 0.f : hn;
-            const float h2 = hp;                         // UNSCALED: |h| <= 1 and 1.0 itself occurs (saturated gates); fp16(2.0) would have bit 14 set
-            const _Float16 hh = (_Float16)h2;
+            // h travels as 2 h = hi + lo with |hi| < 2 (bit 14 clear).  1.0 itself occurs when the gates saturate and fp16(2.0) has
+            // bit 14 set: hi is capped at the largest fp16 below 2 and lo takes the rest (2.0 = 1.9990234375 + 2^-10 exactly; values
+            // that merely round up to 2.0 keep an error of 2^-21 of 2 h).  (Unscaled h would need no cap but makes lo a denormal
+            // for |h| < 0.25 and the kernel 5 % slower.)
+            const float h2 = LP16_HSCALE * hp;
+            _Float16 hh = (_Float16)h2;
+            if (LP16_HEXP && fabsf((float)hh) >= 2.0f) hh = (_Float16)copysignf(1.9990234375f, h2);
             const _Float16 hl = (_Float16)(h2 - (float)hh);
             char* dst = hmine + (long long)t * p.h_ts + goff + (long long)idx * SLICE_BYTES;
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)dst, 0, SLICE_BYTES, 0x00020000);
