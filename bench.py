@@ -349,8 +349,8 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": {"fp32_exact": "f32", "bf16": "bf16 operands / f32 accumulate in the tap-GEMMs (OPT-IN side mode, not the parity arithmetic); everything else f32-faithful"}.get(
-                mode_, "f32 (GEMM-shaped kernels: operands as two scaled fp16 planes, 3 partial products, fp32 accumulate -- split16.h; LSTM "
-                       "products: three bf16 planes, 6 partial products)" if mode_ == "fp32" else
+                mode_, "f32 (GEMM-shaped kernels and LSTM products: operands as two scaled fp16 planes, 3 partial products, fp32 accumulate -- split16.h)"
+                       if mode_ == "fp32" else
                        "f32 (GEMMs and LSTM products: operands split exactly into 3 bf16 terms, 6 partial products, fp32 accumulate)"),
             "data": f"synthetic (0.1*N(0,1) clips, seeded synthetic weights of the {label} architecture)",
             "config": {"workload": f"{label} {ncb} codebooks, encode+decode, {B} clips x {args.seconds:g} s per GPU, resident in HBM",

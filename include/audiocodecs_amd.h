@@ -21,10 +21,10 @@
  *  - a handle is not thread-safe; one handle per process/GPU like the reference's one codec/rank;
  *    the handle's device (ac_config.device) must be the current HIP device when its entry points run;
  *  - activations, weights and results are fp32, accumulation is fp32, tokens are int64 like the reference's.  The
- *    large GEMMs and the LSTM products run "split-operand" arithmetic on the bf16 matrix pipe: every fp32 operand is
- *    written exactly as three bf16 terms and 6 of the 9 exact partial products are accumulated in fp32 (error equal
- *    to fp32 arithmetic); the environment variable AC_GEMM=fp32 selects kernels with exact fp32
- *    products (v_mfma_f32_16x16x4_f32) instead.
+ *    large GEMMs, the fused residual blocks and the LSTM products run "split-operand" arithmetic on the fp16 matrix pipe:
+ *    every fp32 operand, scaled by a power of two, is written as two fp16 terms and 3 of the 4 exact partial products
+ *    are accumulated in fp32 (error equal to fp32 arithmetic; ac_set_precision lists the
+ *    alternatives: three bf16 terms / 6 products, exact fp32 products (v_mfma_f32_16x16x4_f32), opt-in bf16).
  */
 #ifndef AUDIOCODECS_AMD_H
 #define AUDIOCODECS_AMD_H
