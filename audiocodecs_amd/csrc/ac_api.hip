@@ -1031,7 +1031,9 @@ int run_tap(ac_handle* h, hipStream_t st, TapGemmParams& p) {
             // (split16: the 128-column arrangement runs three workgroups per CU and is 6 % faster per flop than before)
             const double s128 = p.winv ? 1.06 * fill(2.0 * wg256, 768.0) : 1.00 * fill(2.0 * wg256, 512.0);
             const double s256 = 1.10 * fill(wg256, 512.0);
-            const double s8 = (kk >= 2048 ? 1.12 : 0.95) * fill(wg256, 256.0);
+            // (split16: 1 x 8 waves no longer beat the three-workgroup 128-column arrangement per flop -- WavTokenizer's K = 2304 layers:
+            //  4.71 ms at 128 columns, 5.43 ms with 1 x 8 waves)
+            const double s8 = (kk >= 2048 ? (p.winv ? 1.00 : 1.12) : (p.winv ? 0.85 : 0.95)) * fill(wg256, 256.0);
             pick = s256 >= s128 && s256 >= s8 ? 1 : (s8 > s128 ? 2 : 0);
             static const char* force = std::getenv("AC_TAP_PICK");     // developer override: 0 / 1 / 2
             if (force && force[0] >= '0' && force[0] <= '2') pick = force[0] - '0';
