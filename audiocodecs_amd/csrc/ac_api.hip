@@ -765,7 +765,8 @@ struct Act {          // a channels-last activation view
     const float* p;
     long long bs, ts;
     int L, C;
-    const unsigned* amax = nullptr;   // split16.h: [B] largest-magnitude bits left by the producer (null: not reported)
+    const unsigned* amax = nullptr;   // split16.h: [B] largest-magnitude bits left by the producer (null: not reported).  A kernel that
+                                      //   rewrites the tensor in place invalidates it: the caller must reset it (mimi_encoder_fwd does)
     int amax_n = 0;                   //   number of clips the slot was written for (a view of another batch shape must not use it)
 };
 

@@ -15,12 +15,14 @@
 //   * activations: one scale per CLIP and tensor, from the tensor's largest magnitude ("amax", bits of |x| as an unsigned
 //     int -- ordered like the values, NaN above everything) which the PRODUCING kernel leaves in an amax slot by atomicMax
 //     (one per wave, skipped when the slot already holds more), or a bound derived from it (ELU never grows a magnitude;
-//     |conv(x)| <= |b| + ||w||_1 amax(x) inside the fused blocks; LSTM output <= 1 + amax(skip); codebook sums).
+//     |conv(x)| <= |b| + ||w||_1 amax(x) inside the fused blocks; LSTM output <= 1 + amax(skip); |re|, |im| <= 100 behind the
+//     clamped magnitude of WavTokenizer's head).
 //     Scaled magnitudes stay below 2^15, so elements down to 2^-16 of the clip's largest keep fp32-grade RELATIVE
 //     precision and everything smaller an absolute error of 2^-40 of the largest -- far below the rounding of the fp32
 //     accumulation it feeds.  inf / NaN elements do not enter the amax: they convert to fp16 inf / NaN and propagate, the
 //     clip's finite part keeps its scale.
-// A tensor whose producer does not report an amax gets one from amax_kernel (one extra read) -- never a guess.
+// A tensor whose producer does not report an amax (normalisation kernels, codebook sums) gets one from amax_kernel (one extra
+// read) -- never a guess; whoever rewrites a tensor in place drops its slot (Act::amax on the host side).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
