@@ -120,3 +120,32 @@ def test_three_bf16_plane_arithmetic_beside_it(enc, golden, checkpoints):
     assert bad == 0
     nat = next(iter(legacy._natives.values()))
     assert nat.lib.ac_lstm_status(nat.h) >= 0
+
+
+@pytest.mark.parametrize("name", ["dac", "mimi", "wavtokenizer"])
+def test_a_clip_alone_equals_the_clip_in_a_batch(name, dac_checkpoints, mimi_checkpoints, wavtok_checkpoints):
+    """Scales are per clip / per row, and row mode is never inferred from the batch shape: encoding and decoding one clip
+    gives bit-identical results whether it runs alone or between neighbours (a one-clip conv once took the row-mode path
+    that the same conv in a batch does not take)."""
+    from audiocodecs_amd import DAC, Mimi, WavTokenizer
+
+    if name == "dac":
+        cfg, sd = dac_checkpoints("full", 0)
+        codec = DAC(44100, 44100, num_codebooks=9, state_dict=sd, config=cfg).eval()
+        sig = noise(7110, 3, 30000)
+    elif name == "mimi":
+        cfg, sd = mimi_checkpoints("full", 0)
+        codec = Mimi(24000, num_codebooks=8, state_dict=sd, config=cfg).eval()
+        sig = noise(7111, 3, 36000)
+    else:
+        cfg, sd = wavtok_checkpoints("full", 0)
+        codec = WavTokenizer(24000, state_dict=sd, arch=cfg).eval()
+        sig = noise(7112, 3, 30000)
+    sig[1] *= 40.0                                   # a loud neighbour in the middle
+    sig = sig.cuda()
+    toks = codec.sig_to_toks(sig)
+    rec = codec.toks_to_sig(toks)
+    for b in range(3):
+        tb = codec.sig_to_toks(sig[b : b + 1])
+        assert torch.equal(tb, toks[b : b + 1]), f"{name}: tokens of clip {b} depend on its batch"
+        assert torch.equal(codec.toks_to_sig(tb), rec[b : b + 1]), f"{name}: decode of clip {b} depends on its batch"
