@@ -17,3 +17,7 @@ python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
 python tools/rocpd_stats.py $(find gpurun_out/prof_r2s -name "*.db" | head -1) > gpurun_out/r2s_kernel_stats.txt 2>&1; head -20 gpurun_out/r2s_kernel_stats.txt
 python tools/rocpd_stats.py $(find gpurun_out/prof_r2s_wt -name "*.db" | head -1) > gpurun_out/r2s_wavtok_kernel_stats.txt 2>&1
 python tools/collect_traffic.py $(find gpurun_out/pmc_r2s_fetch -name "*counter_collection.csv" | head -1) $(find gpurun_out/pmc_r2s_write -name "*counter_collection.csv" | head -1) > gpurun_out/r2s_traffic.json 2> gpurun_out/r2s_traffic.err; head -c 600 gpurun_out/r2s_traffic.json
+rocprofv3 --kernel-trace --stats -d gpurun_out/prof_r2s_mimi -o r2s_mimi -- python3 bench.py --codec mimi --batch 128 --steps 3 --warmup 1 --no-cpu-baseline --no-parity > /dev/null 2> /dev/null; echo "mimi prof rc $?"
+rocprofv3 --kernel-trace --stats -d gpurun_out/prof_r2s_dac -o r2s_dac -- python3 bench.py --codec dac --batch 256 --steps 1 --warmup 1 --no-cpu-baseline --no-parity > /dev/null 2> /dev/null; echo "dac prof rc $?"
+python tools/rocpd_stats.py $(find gpurun_out/prof_r2s_mimi -name "*.db" | head -1) > gpurun_out/r2s_mimi_kernel_stats.txt 2>&1
+python tools/rocpd_stats.py $(find gpurun_out/prof_r2s_dac -name "*.db" | head -1) > gpurun_out/r2s_dac_kernel_stats.txt 2>&1
