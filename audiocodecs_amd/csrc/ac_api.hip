@@ -2225,6 +2225,7 @@ static int dac_encode_impl(ac_handle* h, const float* sig, int B, int T, int K, 
         if (rc) return rc;
         float* z = z_out ? z_out + (size_t)b0 * N * H : p.act[NACT - 1];
         if (!z_out) p.used[NACT - 1] = true;
+        if ((rc = amax_begin(h, st, nb))) return rc;      // every chunk starts with fresh amax slots (no activation view crosses chunks)
         rc = dac_encoder_fwd(h, st, sig + (size_t)b0 * T, nb, T, z, p);
         if (rc) return rc;
         if (zlat_out) {
@@ -2361,6 +2362,7 @@ int ac_decode(ac_handle* h, const int64_t* toks, int B, int N, int K, float* sig
             rc = carve(h, dac_plan_ws(h, B, 0, N, false), ws, ws_bytes, &p);
             if (rc) return rc;
             float* zq = p.take();
+            if ((rc = amax_begin(h, st, nb))) return rc;  // every chunk starts with fresh amax slots
             rc = dac_from_codes(h, st, reinterpret_cast<const long long*>(toks) + (size_t)b0 * N * K, nb * N, K, zq);
             if (rc) return rc;
             capture(h, st, Act{zq, (long long)N * h->dac.H, h->dac.H, N, h->dac.H}, nb);
