@@ -26,6 +26,8 @@
 #include "rb_fused6.h"
 #include "thin_conv6.h"
 #include "rb_fused6_128.h"
+#include "enc_front.h"
+#include "dec_tail.h"
 #include "mimi.h"
 #include "dac.h"
 #include "wavtok.h"
@@ -163,6 +165,9 @@ struct ac_handle {
     std::vector<ResBlockPlan> dec_rb;
     // codebooks
     size_t cb_plain = 0, cb_packed = 0, cb_ee = 0;
+    // bounds of the fused thin-channel chains (enc_front.h): |stem out| <= sb0 + sb1 amax(sig); |block out| <= fb0 + fb1h H + fb1x X
+    struct ChainBounds { float sb0 = 0.f, sb1 = 0.f, fb0 = 0.f, fb1h = 0.f, fb1x = 0.f; bool ok = false; } enc_front, dec_tail;   // dec_tail: sb0 / sb1 are the transposed conv's
+    bool fuse_chains = true;        // AC_FUSE=0 at ac_finalize: the layers of the fused chains as separate kernels (A/B runs, cross-check tests)
     // test hook: copy every layer output (standard [B][L][C] layout) into a caller buffer
     float* dbg = nullptr;
     size_t dbg_cap = 0, dbg_used = 0;
@@ -621,6 +626,43 @@ struct Packer {
         pack6(rb.fused);
         rb6(rb, true);
         return true;
+    }
+    // enc_front.h: constants of the bounds that stand in for the amax of the tensors inside a fused chain
+    //   |stem(x)| <= sb0 + sb1 amax(x)            (largest |bias|, largest row 1-norm)
+    //   |block out| <= fb0 + fb1h bound(hidden) + fb1x bound(block in)
+    void chain_bounds(const PackedGemm& stem, const ResBlockPlan& rb, const PackedGemm& down, ac_handle::ChainBounds& cb) {
+        cb.ok = false;
+        if (!use16() || !rb.has6 || !rb.winv3_off || rb.C != 32 || stem.N != 32 || !h->t6inv_of.count(down.w_off)) return;
+        const int hid = rb.C / 2;
+        cb.sb0 = cb.sb1 = cb.fb0 = cb.fb1h = cb.fb1x = 0.f;
+        for (int n = 0; n < stem.N; ++n) {
+            double l1 = 0.0;
+            for (int k = 0; k < stem.Ktot; ++k) l1 += std::fabs((double)blob[stem.w_off + (size_t)n * stem.Ktot + k]);
+            cb.sb1 = std::max(cb.sb1, (float)(l1 * 1.000001));
+            cb.sb0 = std::max(cb.sb0, std::fabs(blob[stem.b_off + n]));
+        }
+        for (int n = 0; n < rb.C; ++n) {
+            double lh = 0.0, lx = 0.0;
+            for (int k = 0; k < hid; ++k) lh += std::fabs((double)blob[rb.fused.w_off + (size_t)n * rb.fused.Ktot + k]);
+            for (int k = hid; k < rb.fused.Ktot; ++k) lx += std::fabs((double)blob[rb.fused.w_off + (size_t)n * rb.fused.Ktot + k]);
+            cb.fb1h = std::max(cb.fb1h, (float)(lh * 1.000001));
+            cb.fb1x = std::max(cb.fb1x, (float)(lx * 1.000001));
+            cb.fb0 = std::max(cb.fb0, std::fabs(blob[rb.fused.b_off + n]));
+        }
+        cb.ok = true;
+    }
+    // dec_tail.h: |transposed conv out| <= sb0 + sb1 amax(in)
+    void tail_bounds(const PackedGemm& up, const ResBlockPlan& rb, const PackedGemm& head, ac_handle::ChainBounds& cb) {
+        cb.ok = false;
+        if (!use16() || !rb.has6 || !rb.winv3_off || rb.C != 32 || up.N != 64 || up.Ktot != 128 || !h->t6inv_of.count(up.w_off) || head.N != 1 || head.Ktot != 7 * 32) return;
+        cb.sb0 = cb.sb1 = 0.f;
+        for (int n = 0; n < up.N; ++n) {
+            double l1 = 0.0;
+            for (int k = 0; k < up.Ktot; ++k) l1 += std::fabs((double)blob[up.w_off + (size_t)n * up.Ktot + k]);
+            cb.sb1 = std::max(cb.sb1, (float)(l1 * 1.000001));
+            cb.sb0 = std::max(cb.sb0, std::fabs(blob[up.b_off + n]));
+        }
+        cb.ok = true;
     }
     bool lstm(const std::string& prefix, int D, int layers, LstmPlan& lp) {
         lp.D = D;
@@ -1423,6 +1465,114 @@ int head_fwd(ac_handle* h, hipStream_t st, const Act& x, int B, float* sig) {
     return thin_head(h, st, h->dec_head, h->cfg.num_filters, h->cfg.last_kernel_size, PAD_REFLECT, x, B, sig);
 }
 
+// ---- fused thin-channel head of the encoder (enc_front.h): stem -> ResBlock(32) -> ELU -> Conv1d(32, 64, k4, s2)
+bool enc_front_ok(const ac_handle* h, int T) {
+    const ac_config& c = h->cfg;
+    return h->fuse_chains && h->arch == ARCH_ENCODEC && !h->noncausal && h->split16 && !h->gemm_bf16 && !h->gemm_fp32 && h->enc_front.ok &&
+           c.num_filters == 32 && c.kernel_size == 7 && c.residual_kernel_size == 3 && c.compress == 2 && c.num_ratios >= 1 &&
+           c.upsampling_ratios[c.num_ratios - 1] == 2 && T >= 64 && (long long)T * 128 < 0x70000000LL;
+}
+
+int enc_front_fwd(ac_handle* h, hipStream_t st, const float* sig, const float* rel_len, int B, int T, float* y, float* dbg_x0, float* dbg_y1, Act2* out) {
+    const ResBlockPlan& rb = h->enc_rb[0];
+    const PackedGemm& gd = h->enc_down[0];
+    EncFrontParams p{};
+    p.sig = sig;
+    p.rel_len = rel_len;
+    p.w0 = h->blob + h->enc_stem.w_off;
+    p.b0 = h->blob + h->enc_stem.b_off;
+    p.w3f = reinterpret_cast<const __bf16*>(h->blob + rb.w3f_off);
+    p.wff = reinterpret_cast<const __bf16*>(h->blob + rb.wff_off);
+    p.wdf = reinterpret_cast<const __bf16*>(h->blob + h->t6_of[gd.w_off]);
+    p.b3 = h->blob + rb.c3.b_off;
+    p.winv3 = h->blob + rb.winv3_off;
+    p.bf = h->blob + rb.fused.b_off;
+    p.winvf = h->blob + rb.winvf_off;
+    p.bd = h->blob + gd.b_off;
+    p.winvd = h->blob + h->t6inv_of[gd.w_off];
+    p.y = y;
+    p.dbg_x0 = dbg_x0;
+    p.dbg_y1 = dbg_y1;
+    p.B = B;
+    p.T = T;
+    p.M = cdiv(T, 2);
+    const int nchunks = cdiv(T, EF_ROWS);
+    p.seg_chunks = std::max(8, cdiv(nchunks, std::max(1, 6144 / B)));     // ~6144 streams: three rounds of 2048 resident waves
+    if (const char* sc = std::getenv("AC_FRONT_SEG")) p.seg_chunks = std::max(1, std::atoi(sc));
+    p.segs_per_clip = cdiv(nchunks, p.seg_chunks);
+    // amax of the samples (one read of 4 B per sample; as 16-byte vectors where the clip pitch allows)
+    const bool v4 = T % 4 == 0 && aligned16(sig);
+    p.amax_sig = amax_of(h, st, sig, T, v4 ? 4 : 1, v4 ? T / 4 : T, v4 ? 4 : 1, B, nullptr);
+    if (!p.amax_sig) return fail(h, AC_ESTATE, "out of amax slots (split16.h)");
+    p.amax_out = amax_new(h);
+    p.sb0 = h->enc_front.sb0; p.sb1 = h->enc_front.sb1;
+    p.hb0 = rb.hb0; p.hb1 = rb.hb1;
+    p.fb0 = h->enc_front.fb0; p.fb1h = h->enc_front.fb1h; p.fb1x = h->enc_front.fb1x;
+    size_t lds = EF_LDS;
+    if (const char* lp = std::getenv("AC_FRONT_LDSPAD")) lds += (size_t)std::atoi(lp);     // developer: force one workgroup per CU
+    if (int rc = ensure_lds(h, reinterpret_cast<const void*>(enc_front_kernel), lds)) return rc;
+    const long long streams = (long long)B * p.segs_per_clip;
+    {
+        ProfScope ps(h, st, "enc_front_kernel", 2.0 * B * (double)T * (7.0 * 32 + 16.0 * 96 + 32.0 * 48 + 64.0 * 128 / 2),
+                     (double)B * T * 4.0 + (double)B * p.M * 256.0);
+        hipLaunchKernelGGL(enc_front_kernel, dim3((unsigned)cdiv((int)streams, EF_WAVES)), dim3(64 * EF_WAVES), lds, st, p);
+    }
+    HIPCHK(h, hipGetLastError());
+    out->raw = Act{y, (long long)p.M * 64, 64, p.M, 64, p.amax_out, B};
+    out->elu = Act{nullptr, (long long)p.M * 64, 64, p.M, 64, p.amax_out, B};
+    return AC_OK;
+}
+
+// ---- fused thin-channel tail of the decoder (dec_tail.h): ConvTranspose1d(64, 32, k4, s2) -> ResBlock(32) -> ELU -> Conv1d(32, 1, k7)
+bool dec_tail_ok(const ac_handle* h, const Act& xe) {
+    const ac_config& c = h->cfg;
+    return h->fuse_chains && h->arch == ARCH_ENCODEC && !h->noncausal && h->split16 && !h->gemm_bf16 && !h->gemm_fp32 && h->dec_tail.ok &&
+           c.num_filters == 32 && c.last_kernel_size == 7 && c.residual_kernel_size == 3 && c.compress == 2 && c.num_ratios >= 1 &&
+           c.upsampling_ratios[c.num_ratios - 1] == 2 && xe.p && xe.C == 64 && xe.ts == 64 && xe.bs == (long long)xe.L * 64 && aligned16(xe.p) &&
+           xe.L >= 32 && (long long)xe.L * 256 < 0x70000000LL;
+}
+
+int dec_tail_fwd(ac_handle* h, hipStream_t st, const Act& xe, int B, float* sig, float* dbg_u, float* dbg_v) {
+    const int last = h->cfg.num_ratios - 1;
+    const ResBlockPlan& rb = h->dec_rb[last];
+    const PackedGemm& gu = h->dec_up[last];
+    DecTailParams p{};
+    p.xe = xe.p;
+    p.wuf = reinterpret_cast<const __bf16*>(h->blob + h->t6_of[gu.w_off]);
+    p.w3f = reinterpret_cast<const __bf16*>(h->blob + rb.w3f_off);
+    p.wff = reinterpret_cast<const __bf16*>(h->blob + rb.wff_off);
+    p.bu = h->blob + gu.b_off;
+    p.winvu = h->blob + h->t6inv_of[gu.w_off];
+    p.b3 = h->blob + rb.c3.b_off;
+    p.winv3 = h->blob + rb.winv3_off;
+    p.bf = h->blob + rb.fused.b_off;
+    p.winvf = h->blob + rb.winvf_off;
+    p.wh = h->blob + h->dec_head.w_off;
+    p.bh = h->blob + h->dec_head.b_off;
+    p.sig = sig;
+    p.dbg_u = dbg_u;
+    p.dbg_v = dbg_v;
+    p.B = B;
+    p.L = xe.L;
+    const int nchunks = cdiv(xe.L, DT_ROWS);
+    p.seg_chunks = std::max(8, cdiv(nchunks, std::max(1, 6144 / B)));
+    if (const char* sc = std::getenv("AC_TAIL_SEG")) p.seg_chunks = std::max(1, std::atoi(sc));
+    p.segs_per_clip = cdiv(nchunks, p.seg_chunks);
+    p.amax_x = amax_of(h, st, xe.p, xe.bs, xe.ts, xe.L, xe.C, B, xe.amax_n == B ? xe.amax : nullptr);
+    if (!p.amax_x) return fail(h, AC_ESTATE, "out of amax slots (split16.h)");
+    p.ub0 = h->dec_tail.sb0; p.ub1 = h->dec_tail.sb1;
+    p.hb0 = rb.hb0; p.hb1 = rb.hb1;
+    if (int rc = ensure_lds(h, reinterpret_cast<const void*>(dec_tail_kernel), DT_LDS)) return rc;
+    const long long streams = (long long)B * p.segs_per_clip;
+    {
+        ProfScope ps(h, st, "dec_tail_kernel", 2.0 * B * (double)xe.L * (64.0 * 128 + 2.0 * (16.0 * 96 + 32.0 * 48 + 7.0 * 32)),
+                     (double)B * xe.L * 256.0 + (double)B * xe.L * 8.0);
+        hipLaunchKernelGGL(dec_tail_kernel, dim3((unsigned)cdiv((int)streams, 8)), dim3(512), DT_LDS, st, p);
+    }
+    HIPCHK(h, hipGetLastError());
+    return AC_OK;
+}
+
 void capture(ac_handle* h, hipStream_t st, const Act& a, int B) {
     if (!h->dbg) return;
     const size_t n = (size_t)B * a.L * a.C;
@@ -1809,6 +1959,21 @@ int encoder_fwd(ac_handle* h, hipStream_t st, const float* sig, const float* rel
         if (h->noncausal && h->gemm_fp32) return false;   // non-causal blocks are fused in split-operand arithmetic only
         return (C == 32 || C == 64 || (C == 128 && c.num_ratios > 2 && rb128_ok(h, h->enc_rb[2]))) && c.residual_kernel_size == 3 && c.compress == 2;
     };
+    int i0 = 0;
+    if (enc_front_ok(h, T)) {   // stem, first residual block and first down-sampler as one kernel (enc_front.h)
+        float* d0 = dbg ? ws.take() : nullptr;
+        float* d1 = dbg ? ws.take() : nullptr;
+        rc = enc_front_fwd(h, st, sig, rel_len, B, T, ws.take(), d0, d1, &x);
+        if (rc) return rc;
+        if (dbg) {   // the module outputs inside the chain, written by the same kernel while the test hook is armed
+            capture(h, st, Act{d0, (long long)T * 32, 32, T, 32}, B);
+            capture(h, st, Act{d1, (long long)T * 32, 32, T, 32}, B);
+            ws.give(d0);
+            ws.give(d1);
+        }
+        capture(h, st, x.raw, B);
+        i0 = 1;
+    } else {
     if (thin_ok(c, c.kernel_size))
         rc = stem_fwd(h, st, sig, rel_len, B, T, Out{ws.take(), rb_self_elu(c.num_filters) ? nullptr : ws.take()}, &x);
     else
@@ -1816,7 +1981,8 @@ int encoder_fwd(ac_handle* h, hipStream_t st, const float* sig, const float* rel
                       (long long)T * c.num_filters, c.num_filters, B, &x);
     if (rc) return rc;
     capture(h, st, x.raw, B);
-    for (int i = 0; i < c.num_ratios; ++i) {
+    }
+    for (int i = i0; i < c.num_ratios; ++i) {
         const int ratio = c.upsampling_ratios[c.num_ratios - 1 - i];
         float* hb = ws.take();
         rc = resblock_fwd(h, st, h->enc_rb[i], x, hb, Out{dbg ? ws.take() : nullptr, ws.take()}, B, &y);
@@ -1864,6 +2030,21 @@ int decoder_fwd(ac_handle* h, hipStream_t st, const long long* toks, int B, int 
     if (dbg) { capture(h, st, y.raw, B); ws.give(y.raw.p); y.raw.p = nullptr; }
     x = y;
     for (int i = 0; i < c.num_ratios; ++i) {
+        if (i == c.num_ratios - 1 && dec_tail_ok(h, x.elu)) {   // last up-sampler, last residual block and the head as one kernel (dec_tail.h)
+            const long long T2 = 2LL * x.elu.L;
+            float* d0 = dbg ? ws.take() : nullptr;
+            float* d1 = dbg ? ws.take() : nullptr;
+            rc = dec_tail_fwd(h, st, x.elu, B, sig, d0, d1);
+            if (rc) return rc;
+            if (dbg) {   // the module outputs inside the chain, written by the same kernel while the test hook is armed
+                capture(h, st, Act{d0, T2 * 32, 32, (int)T2, 32}, B);
+                capture(h, st, Act{d1, T2 * 32, 32, (int)T2, 32}, B);
+                ws.give(d0);
+                ws.give(d1);
+            }
+            ws.give(x);
+            return AC_OK;
+        }
         const int cup = h->dec_up[i].N / c.upsampling_ratios[i];
         const bool self_elu = (cup == 32 || cup == 64 || (cup == 128 && rb128_ok(h, h->dec_rb[i]))) && c.residual_kernel_size == 3 &&
                               c.compress == 2;   // rb_fused.h / rb_fused6*.h activate raw rows themselves
@@ -2102,6 +2283,8 @@ int ac_finalize(ac_handle* h) {
             pr = gm && std::strcmp(gm, "fp32") == 0 ? AC_PRECISION_FP32_EXACT : gm && std::strcmp(gm, "bf16") == 0 ? AC_PRECISION_BF16 :
                  gm && std::strcmp(gm, "bf16x3") == 0 ? AC_PRECISION_FP32_BF16X3 : AC_PRECISION_FP32;
         }
+        const char* fz = std::getenv("AC_FUSE");
+        h->fuse_chains = !(fz && fz[0] == '0');
         h->gemm_fp32 = pr == AC_PRECISION_FP32_EXACT;
         h->gemm_bf16 = pr == AC_PRECISION_BF16;
         h->split16 = pr == AC_PRECISION_FP32;
@@ -2144,6 +2327,7 @@ int ac_finalize(ac_handle* h) {
         }
         ok = ok && pk.lstm(a.enc_lstm, a.D, c.num_lstm_layers, h->enc_lstm);
         ok = ok && pk.conv(a.enc_final, h->enc_final);
+        if (ok) pk.chain_bounds(h->enc_stem, h->enc_rb[0], h->enc_down[0], h->enc_front);
     }
     if (h->has_dec) {
         ok = ok && pk.conv(a.dec_first, h->dec_first);
@@ -2153,6 +2337,7 @@ int ac_finalize(ac_handle* h) {
             ok = ok && pk.resblock(a.dec_rb3[i], a.dec_rb1[i], a.dec_rbs[i], h->dec_rb[i]);
         }
         ok = ok && pk.conv(a.dec_head, h->dec_head);
+        if (ok) pk.tail_bounds(h->dec_up[c.num_ratios - 1], h->dec_rb[c.num_ratios - 1], h->dec_head, h->dec_tail);
     }
     if (!ok) return pk.rc;
     // codebooks: plain [K][C][H], MFMA B-fragment order, squared norms

@@ -15,6 +15,13 @@ inside the timed step.  Rank 0 prints ONE JSON line (contract in the task statem
                   kernels, bounded by the 157.3 TF fp32 MFMA peak) or HBM (8 TB/s)
   cpu_baseline -- the CPU oracle (torch-CPU restatement of the reference) timed on this host's
                   cores on a bounded sample of the same workload.  Baseline only.
+and, at N = 1, outside the timed region (all skipped by --no-parity):
+  parity                 -- token exact-match and decode RMS error on the reference-generated fixture
+  exact_fp32_ms_per_step -- the same step with every product an IEEE fp32 product (precision="fp32_exact"), so the
+                            split16 figure never travels without its exact-product twin
+  other_configs          -- BASELINE.json configs 3-5 at their per-GPU sizes (DAC 256 x 10 s, Mimi 128 x 10 s,
+                            WavTokenizer 64 x 10 s): value, ms_per_step and parity gate of a short (1 + 3 step) run each
+Nothing inside an `if rank == 0` block issues a collective (tests/test_bench_contract.py checks the source for it).
 """
 import argparse
 import json
@@ -156,6 +163,20 @@ def parity_gate(codec_name, codec):
     }
 
 
+def mfma16_terms(kernel_name, mode):
+    """16-bit MFMA partial products a kernel executes per fp32 product it stands for (0: not on the 16-bit matrix pipe)."""
+    split = kernel_name.startswith(("tap_gemm6", "lstm_persist6", "lstm_persist16", "rb_fused6", "rb128_fused6", "thin_conv6"))
+    if kernel_name.startswith(("enc_front", "dec_tail", "enc_mid", "dec_mid", "lstm_persist16")):
+        return SPLIT16_TERMS
+    if not split:
+        return 0
+    if kernel_name.rstrip().endswith(", 1>"):
+        return 1
+    if kernel_name.rstrip().endswith(", 2>"):
+        return SPLIT16_TERMS
+    return SPLIT_TERMS if mode != "bf16" else 1
+
+
 def measured_traffic(kernel_name, unit, codec="encodec", batch=64):
     """HBM bytes per launch of `kernel_name` from the committed PMC summary (rocprofv3 --pmc FETCH_SIZE /
     WRITE_SIZE in separate passes, gfx950 FETCH x2 correction: tools/collect_traffic.py).  bench.py cannot
@@ -182,6 +203,71 @@ def measured_traffic(kernel_name, unit, codec="encodec", batch=64):
     return None
 
 
+CODEC_LABEL = {"mimi": "Mimi-24k", "dac": "DAC-44.1k", "encodec": "EnCodec-24k", "wavtokenizer": "WavTokenizer-24k-40tok"}
+CODEC_NCB = {"dac": 9, "wavtokenizer": 1, "mimi": 8, "encodec": 8}
+
+
+def build_codec(name, precision=None):
+    """(codec, cfg, state dict) of one of the four wrappers on seeded synthetic weights of the full architecture."""
+    from audiocodecs_amd import DAC, Encodec, Mimi, WavTokenizer, checkpoint
+    from audiocodecs_amd.config import DAC_44KHZ, ENCODEC_24KHZ, MIMI_24KHZ, WAVTOK_40
+
+    cfg = {"mimi": MIMI_24KHZ, "dac": DAC_44KHZ, "encodec": ENCODEC_24KHZ, "wavtokenizer": WAVTOK_40}[name]
+    if name == "mimi":
+        sd = checkpoint.synthetic_mimi_state_dict(cfg, seed=0)
+        codec = Mimi(cfg.sampling_rate, num_codebooks=8, state_dict=sd, precision=precision).eval()
+    elif name == "dac":
+        sd = checkpoint.synthetic_dac_state_dict(cfg, seed=0)
+        codec = DAC(cfg.sampling_rate, cfg.sampling_rate, num_codebooks=9, state_dict=sd, config=cfg, precision=precision).eval()
+    elif name == "wavtokenizer":
+        sd = checkpoint.synthetic_wavtok_state_dict(cfg, seed=0)
+        codec = WavTokenizer(cfg.sampling_rate, state_dict=sd, arch=cfg, precision=precision).eval()
+    else:
+        sd = checkpoint.synthetic_state_dict(cfg, seed=0)
+        codec = Encodec(cfg.sampling_rate, num_codebooks=8, state_dict=sd, precision=precision).eval()
+    return codec, cfg, sd
+
+
+def drop_codec(codec):
+    """Release a codec's device memory (weights + workspace) before the next one is built."""
+    import gc
+
+    for nat in list(getattr(codec, "_natives", {}).values()):
+        nat.ws = None
+        if getattr(nat, "h", None):
+            nat.lib.ac_destroy(nat.h)
+            nat.h = None
+    codec._natives.clear()
+    gc.collect()
+    torch.cuda.empty_cache()
+
+
+def short_run(name, batch, seconds, steps, warmup, precision=None):
+    """One of the other BASELINE.json configs as a short driver-timed run of the same step (encode + decode of `batch` clips
+    resident in HBM), with its parity gate: value, ms_per_step and the gate travel in the headline JSON line (`other_configs`)."""
+    from audiocodecs_amd import prng
+
+    codec, cfg, sd = build_codec(name, precision)
+    T = int(round(seconds * cfg.sampling_rate))
+    sig = torch.from_numpy((prng.normal(123, f"bench.sig.{name}", (batch, T)) * 0.1).astype(np.float32)).cuda()
+    with torch.no_grad():
+        for _ in range(warmup):
+            codec.toks_to_sig(codec.sig_to_toks(sig))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            codec.toks_to_sig(codec.sig_to_toks(sig))
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        gate = parity_gate(name, codec)
+    del sig
+    drop_codec(codec)
+    audio_s = batch * T / cfg.sampling_rate * steps
+    return {"workload": f"{CODEC_LABEL[name]} {CODEC_NCB[name]} codebooks, encode+decode, {batch} clips x {seconds:g} s on 1 GPU, resident in HBM",
+            "value": round(audio_s / dt, 1), "unit": "audio-s/s", "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps, "warmup": warmup,
+            "parity": gate}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -196,7 +282,9 @@ def main():
                     help="arithmetic of the GEMM-shaped kernels: default = fp32 fidelity (split-operand; the parity arithmetic, what `value` is "
                          "quoted for); bf16 = OPT-IN reduced precision, a reported side mode with its own parity figures")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-parity", action="store_true", help="skip the parity gates (profiling passes: keeps the kernel trace to the timed workload)")
+    ap.add_argument("--no-parity", action="store_true", help="skip the parity gates and every other untimed extra (profiling passes: keeps the kernel trace to the timed workload)")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the short runs of BASELINE.json configs 3-5 (DAC, Mimi, WavTokenizer) that travel in the same JSON line")
+    ap.add_argument("--no-exact", action="store_true", help="skip the exact-fp32-product twin of the headline figure")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -215,27 +303,13 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    from audiocodecs_amd import DAC, Encodec, Mimi, WavTokenizer, checkpoint, prng
-    from audiocodecs_amd.config import DAC_44KHZ, ENCODEC_24KHZ, MIMI_24KHZ, WAVTOK_40
+    from audiocodecs_amd import prng
     from audiocodecs_amd.sharding import gather_tokens
 
     mimi = args.codec != "encodec"   # "not the headline codec": whole-path fractions from the kernels' own counts
-    cfg = {"mimi": MIMI_24KHZ, "dac": DAC_44KHZ, "encodec": ENCODEC_24KHZ, "wavtokenizer": WAVTOK_40}[args.codec]
-    label = {"mimi": "Mimi-24k", "dac": "DAC-44.1k", "encodec": "EnCodec-24k", "wavtokenizer": "WavTokenizer-24k-40tok"}[args.codec]
-    ncb = {"dac": 9, "wavtokenizer": 1}.get(args.codec, 8)
+    label, ncb = CODEC_LABEL[args.codec], CODEC_NCB[args.codec]
+    codec, cfg, sd = build_codec(args.codec, args.precision)
     B, T = args.batch, int(round(args.seconds * cfg.sampling_rate))
-    if args.codec == "mimi":
-        sd = checkpoint.synthetic_mimi_state_dict(cfg, seed=0)
-        codec = Mimi(cfg.sampling_rate, num_codebooks=8, state_dict=sd, precision=args.precision).eval()
-    elif args.codec == "dac":
-        sd = checkpoint.synthetic_dac_state_dict(cfg, seed=0)
-        codec = DAC(cfg.sampling_rate, cfg.sampling_rate, num_codebooks=9, state_dict=sd, config=cfg, precision=args.precision).eval()
-    elif args.codec == "wavtokenizer":
-        sd = checkpoint.synthetic_wavtok_state_dict(cfg, seed=0)
-        codec = WavTokenizer(cfg.sampling_rate, state_dict=sd, arch=cfg, precision=args.precision).eval()
-    else:
-        sd = checkpoint.synthetic_state_dict(cfg, seed=0)
-        codec = Encodec(cfg.sampling_rate, num_codebooks=8, state_dict=sd, precision=args.precision).eval()
     # sig = 0.1*N(0,1), repo PRNG seed 123; each rank draws its own shard
     sig_cpu = torch.from_numpy((prng.normal(123, f"bench.sig.rank{rank}", (B, T)) * 0.1).astype(np.float32))
     sig = sig_cpu.cuda()
@@ -245,6 +319,9 @@ def main():
         if dist is not None:
             gather_tokens(toks, force=True)
         return codec.toks_to_sig(toks)
+
+    def local_step():   # the same work without the collective: for rank-local diagnostics outside the timed region
+        return codec.toks_to_sig(codec.sig_to_toks(sig))
 
     def fence():
         if dist is not None:
@@ -273,7 +350,7 @@ def main():
         dt, dt_plain = tt.tolist()
 
     audio_s = world * B * T / cfg.sampling_rate * args.steps
-    mode_ = args.precision or {"fp32": "fp32_exact", "bf16": "bf16"}.get(os.environ.get("AC_GEMM", ""), "fp32")
+    mode_ = args.precision or {"fp32": "fp32_exact", "bf16": "bf16", "bf16x3": "fp32_bf16x3"}.get(os.environ.get("AC_GEMM", ""), "fp32")
     if rank == 0:
         ms = dt / args.steps * 1e3
         stats.sort(key=lambda s: -s[2])
@@ -292,7 +369,7 @@ def main():
             name = members[0][0]
         avg_us = tot_ms / launches * 1e3
         ai = flops / max(nbytes, 1.0)
-        split_kernel = name.startswith(("tap_gemm6", "lstm_persist6", "rb_fused6", "rb128_fused6", "thin_conv6"))
+        split_kernel = name.startswith(("tap_gemm6", "lstm_persist6", "rb_fused6", "rb128_fused6", "thin_conv6", "enc_front", "dec_tail", "enc_mid", "dec_mid"))
         if name.startswith("tap_gemm6") and mode_ == "bf16":
             tf = flops / (tot_ms * 1e-3) / 1e12
             roof = {"bound": "mfma", "achieved": round(tf, 1), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "pipe": "bf16 MFMA, one product per operand pair"}
@@ -300,7 +377,7 @@ def main():
             # split-operand kernels (tap_gemm6.h arithmetic): every fp32 product is 6 bf16 MFMA partial products, so the kernel's
             # roofline is the dense bf16 MFMA peak; `achieved` counts the bf16 flops it actually executes
             eq = flops / (tot_ms * 1e-3) / 1e12
-            s16 = all(m_[0].rstrip().endswith(", 2>") for m_ in members)     # split16.h instantiations (template argument NP = 2)
+            s16 = all(m_[0].rstrip().endswith(", 2>") or m_[0].startswith(("enc_front", "dec_tail", "enc_mid", "dec_mid")) for m_ in members)     # split16.h kernels (template argument NP = 2; the fused chains exist in that arithmetic only)
             terms, cap = (SPLIT16_TERMS, SUSTAINED_F16_MFMA_TFLOPS) if s16 else (SPLIT_TERMS, SUSTAINED_BF16_MFMA_TFLOPS)
             roof = {"bound": "mfma", "achieved": round(terms * eq, 1), "peak": PEAK_F16_MFMA_TFLOPS if s16 else PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "pipe": (f"fp16 MFMA, {terms} partial products per fp32 product (two fp16 planes per operand, split16.h)" if s16 else
@@ -358,9 +435,14 @@ def main():
             "rtf": round(dt / audio_s, 7),
             "x_realtime_per_gpu": round(audio_s / dt / world, 1),
             "whole_path": {
-                # EnCodec: SURVEY.md §8(d) per-audio-second figures; Mimi: the kernels' own algorithmic counts
-                "mfma_fp32_frac": round((sum(s[3] for s in stats) if mimi else FLOP_PER_AUDIO_S * audio_s / world) / dt / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4),
+                # (a) HBM: layer-boundary bytes of the UNFUSED layer stack (117.6 MB per audio-second for EnCodec; the
+                #     kernels' own algorithmic counts for the other codecs) per second against 8 TB/s -- fused chains move fewer bytes
+                #     than this model, so the fraction measures time, not traffic;
+                # (b) matrix pipe: the 16-bit MFMA flops the split-operand kernels EXECUTE (3 partial products per fp32 product in
+                #     split16 arithmetic, 6 with three bf16 planes, 1 in the opt-in bf16 mode) per second against the 2.5 PF dense peak.
                 "hbm_layer_boundary_frac": round((sum(s[4] for s in stats) if mimi else LAYER_BYTES_PER_AUDIO_S * audio_s / world) / dt / (PEAK_HBM_GBS * 1e9), 4),
+                "executed_mfma16_tflops": round(sum(s[3] * mfma16_terms(s[0], mode_) for s in stats) / dt / 1e12, 1),
+                "executed_mfma16_frac": round(sum(s[3] * mfma16_terms(s[0], mode_) for s in stats) / dt / (PEAK_F16_MFMA_TFLOPS * 1e12), 4),
                 "ms_per_step_without_kernel_events": round(dt_plain / args.steps * 1e3, 3),
             },
             "roofline": roof,
@@ -370,20 +452,49 @@ def main():
                 for s in stats
             ],
         }
+        extras = not args.no_parity
         with torch.no_grad():
-            try:   # shader clock under the tap-GEMMs (power cap), sampled in 2 extra steps outside the timed region
-                import ctypes as _C
-                nat = next(iter(codec._natives.values()))
-                mhz = _C.c_double(0.0)
-                nat.lib.ac_debug_clock(nat.h, 1, _C.byref(mhz))
-                step(); step()
-                nat.lib.ac_debug_clock(nat.h, 0, _C.byref(mhz))
-                out["roofline"]["tap_gemm6_shader_clock_mhz"] = round(mhz.value, 0)
-            except Exception as e:  # diagnostics only
-                out["roofline"]["tap_gemm6_shader_clock_mhz"] = None
-            out["parity"] = None if args.no_parity else parity_gate(args.codec, codec)
+            if extras:
+                try:   # shader clock under the tap-GEMMs (power cap): 2 collective-free steps outside the timed region (rank 0 only)
+                    import ctypes as _C
+                    nat = next(iter(codec._natives.values()))
+                    mhz = _C.c_double(0.0)
+                    nat.lib.ac_debug_clock(nat.h, 1, _C.byref(mhz))
+                    local_step(); local_step()
+                    nat.lib.ac_debug_clock(nat.h, 0, _C.byref(mhz))
+                    out["roofline"]["tap_gemm6_shader_clock_mhz"] = round(mhz.value, 0)
+                except Exception:  # diagnostics only
+                    out["roofline"]["tap_gemm6_shader_clock_mhz"] = None
+            out["parity"] = parity_gate(args.codec, codec) if extras else None
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.codec, cfg, sd, sig_cpu, ncb)
+        if world == 1 and extras and mode_ == "fp32" and not args.no_exact:
+            # the split16 figure always travels with its exact-product twin: the same step with every product an IEEE fp32 product
+            # (precision="fp32_exact": tap_gemm4 / rb_fused / lstm_persist kernels), 1 warm-up + 3 steps outside the timed region
+            try:
+                drop_codec(codec)
+                ex, _, _ = build_codec(args.codec, "fp32_exact")
+                with torch.no_grad():
+                    ex.toks_to_sig(ex.sig_to_toks(sig))
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(3):
+                        ex.toks_to_sig(ex.sig_to_toks(sig))
+                    torch.cuda.synchronize()
+                    out["exact_fp32_ms_per_step"] = round((time.perf_counter() - t0) / 3 * 1e3, 3)
+                    out["exact_fp32_parity"] = parity_gate(args.codec, ex)
+                drop_codec(ex)
+            except Exception as e:
+                out["exact_fp32_ms_per_step"] = None
+                out["exact_fp32_error"] = repr(e)[:200]
+        if world == 1 and extras and args.codec == "encodec" and not args.no_other_configs:
+            # BASELINE.json configs 3-5 at their per-GPU sizes: short runs of the same step, driver-visible in this line
+            out["other_configs"] = {}
+            for nm, bt, st_ in (("dac", 256, 3), ("mimi", 128, 3), ("wavtokenizer", 64, 3)):
+                try:
+                    out["other_configs"][nm] = short_run(nm, bt, 10.0, st_, 1, args.precision)
+                except Exception as e:
+                    out["other_configs"][nm] = {"error": repr(e)[:300]}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
