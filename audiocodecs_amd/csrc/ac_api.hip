@@ -190,6 +190,10 @@ struct ac_handle {
     // row mode (linear layers over merged row matrices): a ring of per-row words
     unsigned* row_buf = nullptr;
     size_t row_cap = 0, row_next = 0;
+    // the only pool the handle owns: a few KB allocated at ac_finalize for ac_embs_projected (Mimi), the one launching entry
+    // point without a workspace argument
+    void* own_pool = nullptr;
+    size_t own_pool_rows = 0;
     int precision = -1;             // ac_set_precision; -1: take AC_GEMM from the environment
     // persistent LSTM (lstm_persist.h): control words, device shape, opt-out (AC_LSTM=step)
     unsigned* lp_ctl = nullptr;
@@ -851,19 +855,32 @@ struct ProfScope {
     }
 };
 
-constexpr int AMAX_SLOTS = 4096;
-
-// start of a pass over B clips: all slots back to zero
-int amax_begin(ac_handle* h, hipStream_t st, int B) {
-    if (!(h->split16 || h->gemm_bf16) || h->gemm_fp32) return AC_OK;
-    if (B > h->amax_B) {
-        if (h->amax_buf) { HIPCHK(h, hipStreamSynchronize(st)); HIPCHK(h, hipFree(h->amax_buf)); h->amax_buf = nullptr; }
-        h->amax_B = std::max(B, 64);
-        HIPCHK(h, hipMalloc(&h->amax_buf, (size_t)AMAX_SLOTS * h->amax_B * AMAX_STRIDE * 4));
-        h->amax_next = AMAX_SLOTS;
-    }
-    if (h->amax_next) HIPCHK(h, hipMemsetAsync(h->amax_buf, 0, (size_t)std::min(h->amax_next, AMAX_SLOTS) * h->amax_B * AMAX_STRIDE * 4, st));
+// split16.h bookkeeping lives in the CALLER's workspace (include/audiocodecs_amd.h: "caller owns all device memory of a call"):
+//   amax slots  [AMAX_SLOTS][pool_B clips][AMAX_STRIDE words], handed out in launch order
+//   row ring    eight granules of `rows` words (row mode of the linear layers over merged token matrices)
+// carve() binds the pool of the workspace at hand to the handle for the duration of the call; no entry point allocates,
+// frees or synchronises.  AMAX_SLOTS bounds the producers of one pass (EnCodec ~30, WavTokenizer ~140, Mimi ~220, DAC ~110 per chunk).
+constexpr int AMAX_SLOTS = 512;
+inline size_t pool_bytes(int pool_B, size_t rows) {
+    return (size_t)AMAX_SLOTS * std::max(pool_B, 1) * AMAX_STRIDE * 4 + 8 * align_up(std::max<size_t>(rows, 64), 64) * 4 + 256;
+}
+// bind a pool (device memory of pool_bytes(pool_B, rows) bytes, 256-byte aligned; null: no pool -- entry points that launch
+// nothing in split-operand arithmetic)
+void pool_bind(ac_handle* h, void* mem, int pool_B, size_t rows) {
+    h->amax_buf = reinterpret_cast<unsigned*>(mem);
+    h->amax_B = mem ? std::max(pool_B, 1) : 0;
     h->amax_next = 0;
+    h->row_buf = mem ? h->amax_buf + (size_t)AMAX_SLOTS * h->amax_B * AMAX_STRIDE : nullptr;
+    h->row_cap = mem ? 8 * align_up(std::max<size_t>(rows, 64), 64) : 0;
+    h->row_next = 0;
+}
+
+// start of a pass over B clips: all slots of the bound pool back to zero (one memset of AMAX_SLOTS x B lines on the caller's stream)
+int amax_begin(ac_handle* h, hipStream_t st, int B) {
+    h->amax_next = 0;
+    if (!(h->split16 || h->gemm_bf16) || h->gemm_fp32 || !h->amax_buf) return AC_OK;
+    if (B > h->amax_B) return fail(h, AC_ENOMEM, "workspace pool holds amax slots for %d clips, the pass has %d", h->amax_B, B);
+    HIPCHK(h, hipMemsetAsync(h->amax_buf, 0, (size_t)AMAX_SLOTS * h->amax_B * AMAX_STRIDE * 4, st));
     return AC_OK;
 }
 // a fresh slot for a producer's output (null when the arithmetic does not use them)
@@ -874,8 +891,9 @@ unsigned* amax_new(ac_handle* h) {
 // the amax of a tensor a consumer is about to split: the producer's, or one more read of the tensor
 const unsigned* amax_of(ac_handle* h, hipStream_t st, const float* x, long long bs, long long ts, int L, int C, int B, const unsigned* known) {
     if (known) return known;
+    if (B > h->amax_B) return nullptr;
     unsigned* slot = amax_new(h);
-    if (!slot || B > h->amax_B) return nullptr;
+    if (!slot) return nullptr;
     const long long n = (long long)L * C;
     const int gx = (int)std::max<long long>(1, std::min<long long>((n / 4 + 256 * 8 - 1) / (256 * 8), std::max(4, 8192 / std::max(1, B))));   // >= 8 vectors per thread, <= 8192 workgroups
     ProfScope ps(h, st, "amax_kernel", 0.0, (double)B * n * 4.0);
@@ -883,15 +901,11 @@ const unsigned* amax_of(ac_handle* h, hipStream_t st, const float* x, long long 
     return slot;
 }
 
-// `rows` words of the row ring (split16.h row mode); zeroed when a kernel is going to atomicMax into them
+// `rows` words of the row ring (split16.h row mode); zeroed when a kernel is going to atomicMax into them.  Null when the
+// bound pool's ring is too small for `rows` (the workspace planners size it for the widest row matrix of the pass)
 unsigned* rowmax_new(ac_handle* h, hipStream_t st, long long rows, bool zero) {
-    const size_t need = ((size_t)rows + 63) / 64 * 64;      // allocations are 64-word granules; the ring holds eight of them
-    if (need * 8 > h->row_cap) {             // grows before any word of this size class has been handed out
-        if (h->row_buf) { if (hipStreamSynchronize(st) != hipSuccess) return nullptr; (void)hipFree(h->row_buf); h->row_buf = nullptr; }
-        h->row_cap = need * 8;
-        if (hipMalloc(&h->row_buf, h->row_cap * 4) != hipSuccess) { h->row_cap = 0; return nullptr; }
-        h->row_next = 0;
-    }
+    const size_t need = ((size_t)rows + 63) / 64 * 64;      // allocations are 64-word granules; the ring holds eight of the largest
+    if (!h->row_buf || need > h->row_cap) return nullptr;
     if (h->row_next + need > h->row_cap) h->row_next = 0;
     unsigned* r = h->row_buf + h->row_next;
     h->row_next += need;
@@ -1024,7 +1038,7 @@ int run_tap(ac_handle* h, hipStream_t st, TapGemmParams& p) {
             TapSeg& sg = p.seg[0];
             if (!(sg.amax && sg.amax_n == -p.M)) {
                 unsigned* rm = rowmax_new(h, st, p.M, false);
-                if (!rm) return fail(h, AC_EHIP, "row-amax ring allocation failed");
+                if (!rm) return fail(h, AC_ENOMEM, "the workspace pool's row ring is too small for %d rows", p.M);
                 ProfScope ps(h, st, "rowmax_kernel", 0.0, (double)p.M * sg.cin * 4.0);
                 hipLaunchKernelGGL(rowmax_kernel, dim3((unsigned)cdiv(p.M, 4)), dim3(256), 0, st, sg.x, sg.ts, (long long)p.M, sg.cin, rm);
                 sg.amax = rm;
@@ -1033,7 +1047,7 @@ int run_tap(ac_handle* h, hipStream_t st, TapGemmParams& p) {
             p.winv = h->blob + iv->second;
             if (want_rows) {              // the caller asked for the output's row words: a fresh, zeroed array
                 p.amax_out_rows = rowmax_new(h, st, p.M, true);
-                if (!p.amax_out_rows) return fail(h, AC_EHIP, "row-amax ring allocation failed");
+                if (!p.amax_out_rows) return fail(h, AC_ENOMEM, "the workspace pool's row ring is too small for %d rows", p.M);
             }
         } else if (iv != h->winv_of.end()) {     // split16.h: every operand tensor needs its amax; the output reports its own
             for (int i = 0; i < p.nseg; ++i) {
@@ -1590,7 +1604,12 @@ int lstm_fwd(ac_handle* h, hipStream_t st, const LstmPlan& lp, const Act& x, con
     const int D = lp.D, T = x.L, L = lp.layers;
     if (D % 64 != 0 || D > 512) return fail(h, AC_EINVAL, "LSTM width %d unsupported (need 64, 128, 256 or 512)", D);
     if (L < 1 || L > 2) return fail(h, AC_EINVAL, "%d LSTM layers unsupported (1 or 2)", L);
-    const bool persist = lp.has_persist && h->lp_ctl && h->num_cus == 256 && !h->lstm_step_only && x.ts == D;
+    // Under stream capture the per-step kernels run: the persistent kernel assigns roles from the XCD its workgroups land on and
+    // needs all 256 of them co-resident from the start; a cooperative launch guarantees that, its replay from a hipGraph does not
+    // (observed: 7 of 8 replayed launches without 32 workgroups on every XCD -- detected by the kernel, outputs NaN, status raised).
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(st, &cap);
+    const bool persist = lp.has_persist && h->lp_ctl && h->num_cus == 256 && !h->lstm_step_only && x.ts == D && cap == hipStreamCaptureStatusNone;
     static const bool fuse_env = !(std::getenv("AC_LSTM_FUSE_IN") && std::getenv("AC_LSTM_FUSE_IN")[0] == '0');
     const bool fuse_in = persist && !h->gemm_fp32 && fuse_env && aligned16(x.p) && x.bs % 4 == 0;   // lstm_persist6.h computes W_ih0 * x[t] itself
     // layer-0 input projection for all t: gin[t][b][4D]
@@ -1842,8 +1861,16 @@ constexpr int NACT = 6;   // rotating activation buffers: x.raw, x.elu, hidden, 
 struct Workspace {
     size_t act_floats = 0;     // each of the NACT rotating activation buffers
     size_t gin = 0, hseq = 0, c = 0;
+    int pool_B = 0;            // split16.h pool (amax slots for pool_B clips + row ring for pool_rows rows), at the head of the workspace
+    size_t pool_rows = 0;
     size_t total_bytes = 0;
 };
+// every planner ends here: the pool is part of what ac_*_workspace_bytes reports
+inline void add_pool(Workspace& w, int pool_B, size_t rows) {
+    w.pool_B = pool_B;
+    w.pool_rows = rows;
+    w.total_bytes += pool_bytes(pool_B, rows);
+}
 
 Workspace plan_ws(const ac_handle* h, int B, int T_in /*samples, encoder*/, int N_frames /*decoder*/, bool enc) {
     const ac_config& c = h->cfg;
@@ -1877,6 +1904,7 @@ Workspace plan_ws(const ac_handle* h, int B, int T_in /*samples, encoder*/, int 
     w.gin = std::max(align_up((size_t)N * B * 4 * h->D, 64), w.hseq);          // gin1 doubles as layer 0's local h copy on the persistent path
     w.c = align_up((size_t)2 * B * h->D, 64);
     w.total_bytes = (NACT * w.act_floats + 2 * w.gin + 2 * w.hseq + w.c) * sizeof(float) + 256;
+    add_pool(w, B, 0);
     return w;
 }
 
@@ -1899,7 +1927,9 @@ struct WsPtrs {
 int carve(ac_handle* h, const Workspace& w, void* ws, size_t ws_bytes, WsPtrs* o) {
     if (!ws) return fail(h, AC_EINVAL, "workspace pointer is null");
     if (ws_bytes < w.total_bytes) return fail(h, AC_ENOMEM, "workspace too small: %zu < %zu bytes", ws_bytes, w.total_bytes);
-    float* p = reinterpret_cast<float*>(align_up(reinterpret_cast<uintptr_t>(ws), 256));
+    char* base = reinterpret_cast<char*>(align_up(reinterpret_cast<uintptr_t>(ws), 256));
+    pool_bind(h, base, w.pool_B, w.pool_rows);
+    float* p = reinterpret_cast<float*>(base + align_up(pool_bytes(w.pool_B, w.pool_rows), 256));
     for (int i = 0; i < NACT; ++i) { o->act[i] = p; o->used[i] = false; p += w.act_floats; }
     o->lstm.gin = p; p += w.gin;
     o->lstm.gin1 = p; p += w.gin;
@@ -2257,6 +2287,10 @@ static int upload_blob(ac_handle* h, Packer& pk, int device) {
         if (!ok) { (void)hipGetLastError(); h->lstm_step_only = true; }
         HIPCHK(h, hipMemset(h->lp_ctl, 0, LP_CTL_WORDS * sizeof(unsigned)));
     }
+    if (h->arch == ARCH_MIMI) {
+        h->own_pool_rows = (size_t)h->mcfg.codebook_size;
+        HIPCHK(h, hipMalloc(&h->own_pool, pool_bytes(1, h->own_pool_rows)));
+    }
     h->blob_floats = pk.blob.size();
     HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&h->blob), h->blob_floats * sizeof(float)));
     HIPCHK(h, hipMemcpy(h->blob, pk.blob.data(), h->blob_floats * sizeof(float), hipMemcpyHostToDevice));
@@ -2436,13 +2470,20 @@ size_t ac_decode_workspace_bytes(const ac_handle* h, int B, int N) {
 }
 size_t ac_quantizer_workspace_bytes(const ac_handle* h, int B, int N) {
     if (!h || B < 1 || N < 1 || h->arch != ARCH_MIMI) return 0;
-    return (size_t)B * N * 2 * h->mcfg.codebook_dim * sizeof(float) + 256;
+    return align_up((size_t)B * N * 2 * h->mcfg.codebook_dim * sizeof(float) + 256, 256) + pool_bytes(1, (size_t)B * N) + 256;
+}
+
+// Mimi's quantizer entry points: scratch = [projection | split16 pool (row ring for the B*N frames)]
+static float* quantizer_scratch(ac_handle* h, void* ws, int B, int N) {
+    char* base = reinterpret_cast<char*>(align_up(reinterpret_cast<uintptr_t>(ws), 256));
+    const size_t proj = align_up((size_t)B * N * 2 * h->mcfg.codebook_dim * sizeof(float), 256);
+    pool_bind(h, base + proj, 1, (size_t)B * N);
+    return reinterpret_cast<float*>(base);
 }
 
 int ac_encode_feats(ac_handle* h, const float* sig, const float* rel_len, int B, int T, float* feats, void* ws, size_t ws_bytes, void* stream) {
     int rc = check_ready(h);
     if (rc) return rc;
-    if ((rc = amax_begin(h, (hipStream_t)stream, B))) return rc;
     if (!sig || !feats || B < 1 || T < 1) return fail(h, AC_EINVAL, "ac_encode_feats: bad argument (B=%d, T=%d)", B, T);
     if ((rc = check_len(h, T))) return rc;
     if (!h->has_enc) return fail(h, AC_ESTATE, "ac_encode_feats: the handle was loaded without encoder weights (mode=\"decode\")");
@@ -2450,6 +2491,7 @@ int ac_encode_feats(ac_handle* h, const float* sig, const float* rel_len, int B,
     WsPtrs p;
     rc = carve(h, any_plan_ws(h, B, T, 0, true), ws, ws_bytes, &p);
     if (rc) return rc;
+    if ((rc = amax_begin(h, (hipStream_t)stream, B))) return rc;
     if (h->arch == ARCH_MIMI) return mimi_encoder_fwd(h, (hipStream_t)stream, sig, B, T, feats, p);   // no sample mask in Mimi ([HF] mimi :1245-1247)
     return encoder_fwd(h, (hipStream_t)stream, sig, rel_len, B, T, feats, p);
 }
@@ -2457,7 +2499,6 @@ int ac_encode_feats(ac_handle* h, const float* sig, const float* rel_len, int B,
 int ac_encode(ac_handle* h, const float* sig, const float* rel_len, int B, int T, int K, int64_t* toks, void* ws, size_t ws_bytes, void* stream) {
     int rc = check_ready(h);
     if (rc) return rc;
-    if ((rc = amax_begin(h, (hipStream_t)stream, B))) return rc;
     if (!sig || !toks || B < 1 || T < 1) return fail(h, AC_EINVAL, "ac_encode: bad argument (B=%d, T=%d)", B, T);
     if (K < 1 || K > num_q(h)) return fail(h, AC_EINVAL, "ac_encode: K=%d outside [1, %d]", K, num_q(h));
     if ((rc = check_len(h, T))) return rc;
@@ -2468,6 +2509,7 @@ int ac_encode(ac_handle* h, const float* sig, const float* rel_len, int B, int T
     rc = carve(h, any_plan_ws(h, B, T, 0, true), ws, ws_bytes, &p);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
+    if ((rc = amax_begin(h, st, B))) return rc;
     const int N = ac_num_frames(h, T);
     if (h->arch == ARCH_MIMI) {
         const ac_mimi_config& c = h->mcfg;
@@ -2490,13 +2532,14 @@ int ac_encode(ac_handle* h, const float* sig, const float* rel_len, int B, int T
 int ac_quantize_ws(ac_handle* h, const float* feats, int B, int N, int K, int64_t* toks, void* ws, size_t ws_bytes, void* stream) {
     int rc = check_ready(h);
     if (rc) return rc;
-    if ((rc = amax_begin(h, (hipStream_t)stream, B))) return rc;
     if (!feats || !toks || B < 1 || N < 1 || K < 1 || K > num_q(h)) return fail(h, AC_EINVAL, "ac_quantize: bad argument");
+    pool_bind(h, nullptr, 0, 0);      // (EnCodec / DAC: the codebook search runs outside split-operand arithmetic)
     if (h->arch == ARCH_DAC) return dac_vq_encode(h, (hipStream_t)stream, feats, B * N, K, reinterpret_cast<long long*>(toks), nullptr);
     if (h->arch == ARCH_MIMI) {
         const ac_mimi_config& c = h->mcfg;
         if (!ws || ws_bytes < ac_quantizer_workspace_bytes(h, B, N)) return fail(h, AC_ENOMEM, "ac_quantize: workspace missing or too small");
-        float* proj = reinterpret_cast<float*>(align_up(reinterpret_cast<uintptr_t>(ws), 256));
+        float* proj = quantizer_scratch(h, ws, B, N);
+        if ((rc = amax_begin(h, (hipStream_t)stream, 1))) return rc;
         rc = mimi_linear(h, (hipStream_t)stream, h->mimi.in_proj, feats, (long long)B * N, c.hidden_size, c.hidden_size, 0, proj, 2 * c.codebook_dim);
         if (rc) return rc;
         return mimi_rvq_encode(h, (hipStream_t)stream, proj, B * N, K, reinterpret_cast<long long*>(toks));
@@ -2512,12 +2555,13 @@ int ac_quantize(ac_handle* h, const float* feats, int B, int N, int K, int64_t* 
 int ac_dequantize_ws(ac_handle* h, const int64_t* toks, int B, int N, int K, float* qfeats, void* ws, size_t ws_bytes, void* stream) {
     int rc = check_ready(h);
     if (rc) return rc;
-    if ((rc = amax_begin(h, (hipStream_t)stream, B))) return rc;
     if (!qfeats || !toks || B < 1 || N < 1 || K < 1 || K > num_q(h)) return fail(h, AC_EINVAL, "ac_dequantize: bad argument");
+    pool_bind(h, nullptr, 0, 0);
     if (h->arch == ARCH_DAC) return dac_from_codes(h, (hipStream_t)stream, reinterpret_cast<const long long*>(toks), B * N, K, qfeats);
     if (h->arch == ARCH_MIMI) {
         if (!ws || ws_bytes < ac_quantizer_workspace_bytes(h, B, N)) return fail(h, AC_ENOMEM, "ac_dequantize: workspace missing or too small");
-        float* qsum = reinterpret_cast<float*>(align_up(reinterpret_cast<uintptr_t>(ws), 256));
+        float* qsum = quantizer_scratch(h, ws, B, N);
+        if ((rc = amax_begin(h, (hipStream_t)stream, 1))) return rc;
         return mimi_rvq_decode(h, (hipStream_t)stream, reinterpret_cast<const long long*>(toks), B * N, K, qsum, qfeats);
     }
     return rvq_decode_fwd(h, (hipStream_t)stream, reinterpret_cast<const long long*>(toks), B * N, K, qfeats);
@@ -2531,7 +2575,6 @@ int ac_dequantize(ac_handle* h, const int64_t* toks, int B, int N, int K, float*
 int ac_decode(ac_handle* h, const int64_t* toks, int B, int N, int K, float* sig, void* ws, size_t ws_bytes, void* stream) {
     int rc = check_ready(h);
     if (rc) return rc;
-    if ((rc = amax_begin(h, (hipStream_t)stream, B))) return rc;
     if (!sig || !toks || B < 1 || N < 1) return fail(h, AC_EINVAL, "ac_decode: bad argument (B=%d, N=%d)", B, N);
     if (K < 1 || K > num_q(h)) return fail(h, AC_EINVAL, "ac_decode: K=%d outside [1, %d]", K, num_q(h));
     if ((rc = check_len(h, ac_num_samples(h, N)))) return rc;
@@ -2559,6 +2602,7 @@ int ac_decode(ac_handle* h, const int64_t* toks, int B, int N, int K, float* sig
     WsPtrs p;
     rc = carve(h, any_plan_ws(h, B, 0, N, false), ws, ws_bytes, &p);
     if (rc) return rc;
+    if ((rc = amax_begin(h, (hipStream_t)stream, B))) return rc;
     if (h->arch == ARCH_WAVTOK) {
         hipStream_t st = (hipStream_t)stream;
         float* zq = p.take();   // codes_to_features: the single codebook's vectors [B*N][dimension]
@@ -2583,7 +2627,6 @@ int ac_decode(ac_handle* h, const int64_t* toks, int B, int N, int K, float* sig
 int ac_decode_feats(ac_handle* h, const float* feats, int B, int N, float* sig, void* ws, size_t ws_bytes, void* stream) {
     int rc = check_ready(h);
     if (rc) return rc;
-    if ((rc = amax_begin(h, (hipStream_t)stream, B))) return rc;
     if (h->arch != ARCH_WAVTOK) return fail(h, AC_EINVAL, "ac_decode_feats: WavTokenizer handles only (the other wrappers do not implement _feats_to_sig)");
     if (!feats || !sig || B < 1 || N < 1) return fail(h, AC_EINVAL, "ac_decode_feats: bad argument (B=%d, N=%d)", B, N);
     if ((rc = check_len(h, ac_num_samples(h, N)))) return rc;
@@ -2591,13 +2634,13 @@ int ac_decode_feats(ac_handle* h, const float* feats, int B, int N, float* sig, 
     WsPtrs p;
     rc = carve(h, wavtok_plan_ws(h, B, 0, N, false), ws, ws_bytes, &p);
     if (rc) return rc;
+    if ((rc = amax_begin(h, (hipStream_t)stream, B))) return rc;
     return wavtok_decoder_fwd(h, (hipStream_t)stream, feats, B, N, sig, p);
 }
 
 int ac_embs(ac_handle* h, int K, float* embs, void* stream) {
     int rc = check_ready(h);
     if (rc) return rc;
-    if ((rc = amax_begin(h, (hipStream_t)stream, 1))) return rc;
     if (!embs || K < 1 || K > num_q(h)) return fail(h, AC_EINVAL, "ac_embs: bad argument");
     size_t n, off;
     if (h->arch == ARCH_MIMI) { n = (size_t)K * h->mcfg.codebook_size * h->mcfg.codebook_dim; off = h->mimi.cb_plain; }
@@ -2610,7 +2653,6 @@ int ac_embs(ac_handle* h, int K, float* embs, void* stream) {
 int ac_embs_projected(ac_handle* h, int K, float* embs, void* stream) {
     int rc = check_ready(h);
     if (rc) return rc;
-    if ((rc = amax_begin(h, (hipStream_t)stream, 1))) return rc;
     if (h->arch == ARCH_DAC) {   // out_proj_k(codebook_k) + bias, tabulated at ac_finalize (dac.py:68-90)
         if (!embs || K < 1 || K > h->dcfg.n_codebooks) return fail(h, AC_EINVAL, "ac_embs_projected: bad argument");
         const size_t n = (size_t)K * h->dcfg.codebook_size * h->dac.H;
@@ -2620,6 +2662,9 @@ int ac_embs_projected(ac_handle* h, int K, float* embs, void* stream) {
     if (h->arch != ARCH_MIMI) return fail(h, AC_EINVAL, "ac_embs_projected: EnCodec has no output projection");
     const ac_mimi_config& c = h->mcfg;
     if (!embs || K < 1 || K > c.num_quantizers) return fail(h, AC_EINVAL, "ac_embs_projected: bad argument");
+    // the one launching entry point without a workspace argument: its few KB of pool were allocated at ac_finalize
+    pool_bind(h, h->own_pool, 1, h->own_pool_rows);
+    if ((rc = amax_begin(h, (hipStream_t)stream, 1))) return rc;
     for (int q = 0; q < K; ++q) {
         const int part = q < c.num_semantic_quantizers ? 0 : 1;
         rc = mimi_linear(h, (hipStream_t)stream, h->mimi.out_proj, h->blob + h->mimi.cb_plain + (size_t)q * c.codebook_size * c.codebook_dim,
@@ -2633,7 +2678,6 @@ int ac_embs_projected(ac_handle* h, int K, float* embs, void* stream) {
 int ac_encode_quantized(ac_handle* h, const float* sig, int B, int T, int K, int64_t* toks, float* qfeats, void* ws, size_t ws_bytes, void* stream) {
     int rc = check_ready(h);
     if (rc) return rc;
-    if ((rc = amax_begin(h, (hipStream_t)stream, B))) return rc;
     if (h->arch != ARCH_DAC) return fail(h, AC_EINVAL, "ac_encode_quantized: DAC handles only (others: ac_encode + ac_dequantize_ws)");
     if (!sig || !toks || !qfeats || B < 1 || T < 1 || K < 1 || K > num_q(h)) return fail(h, AC_EINVAL, "ac_encode_quantized: bad argument");
     if ((rc = check_len(h, T))) return rc;
@@ -2643,7 +2687,6 @@ int ac_encode_quantized(ac_handle* h, const float* sig, int B, int T, int K, int
 int ac_encode_feats_latent(ac_handle* h, const float* sig, int B, int T, float* feats_latent, void* ws, size_t ws_bytes, void* stream) {
     int rc = check_ready(h);
     if (rc) return rc;
-    if ((rc = amax_begin(h, (hipStream_t)stream, B))) return rc;
     if (h->arch != ARCH_DAC) return fail(h, AC_EINVAL, "ac_encode_feats_latent: DAC handles only");
     if (!sig || !feats_latent || B < 1 || T < 1) return fail(h, AC_EINVAL, "ac_encode_feats_latent: bad argument");
     if ((rc = check_len(h, T))) return rc;
@@ -2751,8 +2794,7 @@ void ac_destroy(ac_handle* h) {
     if (!h) return;
     if (h->blob) (void)hipFree(h->blob);
     if (h->lp_ctl) (void)hipFree(h->lp_ctl);
-    if (h->amax_buf) (void)hipFree(h->amax_buf);
-    if (h->row_buf) (void)hipFree(h->row_buf);
+    if (h->own_pool) (void)hipFree(h->own_pool);
     if (h->sticky) (void)hipHostFree(h->sticky);
     if (h->clk_dev) (void)hipFree(h->clk_dev);
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);

@@ -168,6 +168,7 @@ Workspace dac_plan_ws(const ac_handle* h, int B, long long T_in, long long N_fra
     const int Bc = dac_chunk_clips(h, B, T_in, N_frames, enc);
     w.act_floats = align_up(dac_act_floats(h, T_in, N_frames, enc) * Bc, 64);
     w.total_bytes = NACT * w.act_floats * sizeof(float) + 256;
+    add_pool(w, Bc, 0);                   // amax slots for one chunk of clips (every chunk starts a fresh pass)
     return w;
 }
 

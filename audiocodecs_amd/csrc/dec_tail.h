@@ -11,8 +11,9 @@
 //   stage B   v = [W1 | Ws] * [h | u] + (b1 + bs);  ELU(v) kept in fp32 in the slab Ve (6 rows of halo carried over)
 //   head      sig[t] = bh + sum_j sum_c wh[j][c] ELU(v)[t-6+j][c]   fp32 FMAs, lane = (sample, channel half), halves added
 // Clip start: reflect padding of the k3 conv (ue[-i] = ue[i]) and of the head (ve[-i] = ve[i]) by row copies; a segment
-// inside a clip runs one warm-up chunk without output.  Stage U's and B's weights in registers (160 VGPRs), stage A's
-// fragment image and the head's weights in LDS shared by the workgroup's 8 waves.
+// inside a clip runs one warm-up chunk without output.  Stage U's weights in registers (128 VGPRs); stage A's and B's fragment
+// images and the head's weights in LDS shared by the workgroup's 8 waves (no spill: a kernel with scratch cannot be replayed
+// safely from a hipGraph once the runtime has resized its scratch buffer).
 // split16 scales from BOUNDS (enc_front.h): U = ub0 + ub1 amax(xe) for ELU(u);  min(U, hb0 + hb1 U) for [h | u].
 #pragma once
 #include <hip/hip_runtime.h>
@@ -49,11 +50,13 @@ constexpr int DT_VP = 36;                                                       
 constexpr int DT_VE_HALO_BYTES = 6 * DT_VP * 4;                                  // 864
 constexpr int DT_X_BYTES = 6144;                                                // Xs (5440) / Hs (6144) / Ve rows 6..37 (4608) share this region
 constexpr int DT_UEP = 40, DT_UE_PLANE = 34 * DT_UEP;                            // Ue: rows 0,1 halo, 2..33 this chunk
-constexpr int DT_QP = 48, DT_Q_PLANE = 32 * DT_QP;                               // Ur, Hs
+constexpr int DT_QP = 48, DT_Q_PLANE = 32 * DT_QP;                               // Hs: 96-byte rows
+constexpr int DT_URP = 40, DT_UR_PLANE = 32 * DT_URP;                            // Ur: 80-byte rows (the LDS budget pays for stage B's weights)
 constexpr int DT_XPREV_BYTES = 2 * DT_XSP * 2;                                   // the chunk's last input row, both planes: the next chunk's xe[m0-1]
-constexpr int DT_WAVE_BYTES = DT_VE_HALO_BYTES + DT_X_BYTES + 2 * DT_UE_PLANE * 2 + 2 * DT_Q_PLANE * 2 + DT_XPREV_BYTES;
+constexpr int DT_WAVE_BYTES = DT_VE_HALO_BYTES + DT_X_BYTES + 2 * DT_UE_PLANE * 2 + 2 * DT_UR_PLANE * 2 + DT_XPREV_BYTES;
 constexpr int DT_CONST_FLOATS = 512;
-constexpr int DT_SHARED_BYTES = DT_CONST_FLOATS * 4 + EF_W3_HALFS * 2;
+constexpr int DT_WF_HALFS = 2 * 2 * 2 * 512;                                     // stage B's fragment image [2 n-tiles][2 k-steps][2 planes][64][8]
+constexpr int DT_SHARED_BYTES = DT_CONST_FLOATS * 4 + (EF_W3_HALFS + DT_WF_HALFS) * 2;
 constexpr size_t DT_LDS = (size_t)DT_SHARED_BYTES + 8 * (size_t)DT_WAVE_BYTES;
 static_assert(DT_WAVE_BYTES % 16 == 0 && DT_VE_HALO_BYTES % 16 == 0 && 2 * DT_XS_PLANE * 2 <= DT_X_BYTES && 2 * DT_Q_PLANE * 2 <= DT_X_BYTES &&
               32 * DT_VP * 4 <= DT_X_BYTES, "slab layout");
@@ -82,8 +85,11 @@ __global__ __launch_bounds__(512, 2) void dec_tail_kernel(const DecTailParams p)
         smem[e] = v;
     }
     const _Float16* W3s = reinterpret_cast<const _Float16*>(smem + DT_CONST_FLOATS);
+    const _Float16* WFs = W3s + EF_W3_HALFS;
     for (int e = tid; e < EF_W3_HALFS / 8; e += 512)
         *reinterpret_cast<f16x8*>(reinterpret_cast<_Float16*>(smem + DT_CONST_FLOATS) + e * 8) = *reinterpret_cast<const f16x8*>(p.w3f + (long long)e * 8);
+    for (int e = tid; e < DT_WF_HALFS / 8; e += 512)
+        *reinterpret_cast<f16x8*>(reinterpret_cast<_Float16*>(smem + DT_CONST_FLOATS) + EF_W3_HALFS + e * 8) = *reinterpret_cast<const f16x8*>(p.wff + (long long)e * 8);
     __syncthreads();
 
     char* wbase = reinterpret_cast<char*>(smem) + DT_SHARED_BYTES + wave * DT_WAVE_BYTES;
@@ -91,8 +97,8 @@ __global__ __launch_bounds__(512, 2) void dec_tail_kernel(const DecTailParams p)
     _Float16* Xs = reinterpret_cast<_Float16*>(wbase + DT_VE_HALO_BYTES);              // [2][17][80]
     _Float16* Hs = Xs;                                                                  // [2][32][48]  (Xs is dead by then)
     _Float16* Ue = reinterpret_cast<_Float16*>(wbase + DT_VE_HALO_BYTES + DT_X_BYTES);  // [2][34][40]
-    _Float16* Ur = Ue + 2 * DT_UE_PLANE;                                                // [2][32][48]
-    _Float16* Xprev = Ur + 2 * DT_Q_PLANE;                                              // [2][80]
+    _Float16* Ur = Ue + 2 * DT_UE_PLANE;                                                // [2][32][40]
+    _Float16* Xprev = Ur + 2 * DT_UR_PLANE;                                              // [2][80]
 
     const int sid = blockIdx.x * 8 + wave;
     if (sid >= p.B * p.segs_per_clip) return;
@@ -103,13 +109,7 @@ __global__ __launch_bounds__(512, 2) void dec_tail_kernel(const DecTailParams p)
     if (c_first >= c_last) return;
     const int T = 2 * p.L;
 
-    f16x8 wf[2][2][2], wu[4][4][2];
-#pragma unroll
-    for (int c = 0; c < 2; ++c)
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int pl = 0; pl < 2; ++pl) wf[ks][c][pl] = *reinterpret_cast<const f16x8*>(p.wff + ((long long)((c * 2 + ks) * 2 + pl) * 64 + lane) * 8);
+    f16x8 wu[4][4][2];
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(512, 2) void dec_tail_kernel(const DecTailParams p)
                 const int rho = 2 * li + (c >> 1), co = 16 * (c & 1) + 4 * kq;      // output row of the chunk, first channel
                 if (p.dbg_u && emit && t0 + rho < T) *reinterpret_cast<f32x4*>(p.dbg_u + (ob + t0 + rho) * 32 + co) = v;
                 split16_store4(elu4(v) * su, Ue, DT_UE_PLANE, (2 + rho) * DT_UEP + co);
-                split16_store4(v * sb, Ur, DT_Q_PLANE, rho * DT_QP + co);
+                split16_store4(v * sb, Ur, DT_UR_PLANE, rho * DT_URP + co);
             }
         }
         if (lane < 32) *reinterpret_cast<f16x4_t*>(Xprev + (lane >> 4) * DT_XSP + (lane & 15) * 4) = *reinterpret_cast<const f16x4_t*>(Xs + (lane >> 4) * DT_XS_PLANE + 16 * DT_XSP + (lane & 15) * 4);
@@ -233,27 +233,34 @@ __global__ __launch_bounds__(512, 2) void dec_tail_kernel(const DecTailParams p)
                 f16x8 xh[2], xl[2];
 #pragma unroll
                 for (int a = 0; a < 2; ++a) {
-                    const int o = (a * 16 + li) * DT_QP + 8 * kq;
                     if (ks == 0) {            // k = 0..15 hidden, 16..31 K padding (zero weight columns): lanes kq >= 2 supply zeros
+                        const int o = (a * 16 + li) * DT_QP + 8 * kq;
                         xh[a] = kq < 2 ? *reinterpret_cast<const f16x8*>(Hs + o) : z8;
                         xl[a] = kq < 2 ? *reinterpret_cast<const f16x8*>(Hs + DT_Q_PLANE + o) : z8;
                     } else {
+                        const int o = (a * 16 + li) * DT_URP + 8 * kq;
                         xh[a] = *reinterpret_cast<const f16x8*>(Ur + o);
-                        xl[a] = *reinterpret_cast<const f16x8*>(Ur + DT_Q_PLANE + o);
+                        xl[a] = *reinterpret_cast<const f16x8*>(Ur + DT_UR_PLANE + o);
                     }
+                }
+                f16x8 wfh[2], wfl[2];
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    wfh[c] = *reinterpret_cast<const f16x8*>(WFs + (((c * 2 + ks) * 2 + 0) * 64 + lane) * 8);
+                    wfl[c] = *reinterpret_cast<const f16x8*>(WFs + (((c * 2 + ks) * 2 + 1) * 64 + lane) * 8);
                 }
 #pragma unroll
                 for (int a = 0; a < 2; ++a)
 #pragma unroll
-                    for (int c = 0; c < 2; ++c) acc[a][c] = ef_mfma(wf[ks][c][1], xh[a], acc[a][c]);
+                    for (int c = 0; c < 2; ++c) acc[a][c] = ef_mfma(wfl[c], xh[a], acc[a][c]);
 #pragma unroll
                 for (int a = 0; a < 2; ++a)
 #pragma unroll
-                    for (int c = 0; c < 2; ++c) acc[a][c] = ef_mfma(wf[ks][c][0], xl[a], acc[a][c]);
+                    for (int c = 0; c < 2; ++c) acc[a][c] = ef_mfma(wfh[c], xl[a], acc[a][c]);
 #pragma unroll
                 for (int a = 0; a < 2; ++a)
 #pragma unroll
-                    for (int c = 0; c < 2; ++c) acc[a][c] = ef_mfma(wf[ks][c][0], xh[a], acc[a][c]);
+                    for (int c = 0; c < 2; ++c) acc[a][c] = ef_mfma(wfh[c], xh[a], acc[a][c]);
             }
             DT_FENCE();
 #pragma unroll

@@ -328,6 +328,7 @@ Workspace mimi_plan_ws(const ac_handle* h, int B, int T_in, int N_frames, bool e
     mx = std::max(mx, (size_t)T25 * widest);
     w.act_floats = align_up(mx * B, 64);
     w.total_bytes = NACT * w.act_floats * sizeof(float) + 256;
+    add_pool(w, B, (size_t)B * T25);      // row mode of the transformers' linear layers: one word per token row
     return w;
 }
 

@@ -354,5 +354,6 @@ Workspace wavtok_plan_ws(const ac_handle* h, int B, int T_in, int N_frames, bool
     w.act_floats = align_up((size_t)B * N_frames * widest, 64);
     w.c = align_up((size_t)B * c.num_groups * 2, 64);
     w.total_bytes = (NACT * w.act_floats + 2 * w.gin + 2 * w.hseq + w.c) * sizeof(float) + 256;
+    add_pool(w, B, (size_t)B * N_frames); // row mode of the backbone's linear layers
     return w;
 }

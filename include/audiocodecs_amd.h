@@ -16,6 +16,13 @@
  *  - all work is enqueued on the caller's `stream` (a hipStream_t passed as void*); no entry point
  *    synchronises the device, so the caller's own fences (torch.cuda.synchronize in
  *    downstream/test_sr.py:58,84) time the real work;
+ *  - no compute entry point allocates or frees device memory: every byte a call needs beyond the handle's weights
+ *    (activations, LSTM state, and the split-operand bookkeeping -- per-clip amax slots and the per-row ring) is carved
+ *    from the caller's workspace, whose size ac_encode_workspace_bytes / ac_decode_workspace_bytes /
+ *    ac_quantizer_workspace_bytes report for the call's (B, T | N); B may grow or shrink from call to call without any
+ *    hipMalloc / hipFree / stream synchronisation inside the library (tests/test_workspace_contract_gpu.py).  The handle
+ *    owns only what ac_finalize allocates once: the packed weights, the persistent LSTM's control words, a pinned status
+ *    word, and (Mimi) a few KB of pool for ac_embs_projected, the one launching entry point without a workspace argument;
  *  - return 0 on success, a negative AC_E* code on failure; never throws across the ABI;
  *    ac_last_error() returns a human-readable message for the last failure on that handle;
  *  - a handle is not thread-safe; one handle per process/GPU like the reference's one codec/rank;
