@@ -118,7 +118,11 @@ class WavTokenizer(Codec):
         self.precision = _native.check_precision(precision)   # see Encodec: None / "fp32" (parity arithmetic), "fp32_exact", "bf16" (opt-in)
         if state_dict is None:
             state_dict = self._fetch_pretrained(source, checkpoint)
-        sd = {k: v for k, v in state_dict.items() if not k.startswith("feature_extractor.encodec.decoder.")}  # never used for inference
+        # Upstream's from_pretrained0802 keeps the generator only; a Lightning checkpoint also carries the discriminators and the
+        # loss modules (hundreds of MB that would be copied to the host twice per handle just to be dropped), and the encodec
+        # DECODER inside the feature extractor is never used for inference
+        keep = ("feature_extractor.encodec.encoder.", "feature_extractor.encodec.quantizer.", "backbone.", "head.")
+        sd = {k: v for k, v in state_dict.items() if k.startswith(keep)}
         # wavtokenizer.py:80-84: the half the mode never runs is dropped (here: never packed or uploaded)
         if mode == "encode":
             sd = {k: v for k, v in sd.items() if not (k.startswith("backbone.") or k.startswith("head."))}
