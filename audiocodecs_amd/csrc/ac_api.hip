@@ -2716,6 +2716,32 @@ int ac_debug_split_row(const float* w, int n, uint16_t* hi, uint16_t* lo) {
     return s;
 }
 
+int ac_debug_bounds(const ac_handle* h, float* out, int cap) {
+    // Layout (EnCodec handles; 0 where a half was not loaded):
+    //   [0..6]   enc_front.h: sb0 sb1 | hb0 hb1 | fb0 fb1h fb1x        |x0| <= sb0 + sb1 amax(sig); |h| <= hb0 + hb1 X0; |y1| <= fb0 + fb1h H + fb1x X0
+    //   [7..10]  dec_tail.h:  ub0 ub1 | hb0 hb1                        |u| <= ub0 + ub1 amax(xe);   |h| <= hb0 + hb1 U
+    //   [11 + 2i], [12 + 2i]  hb0, hb1 of encoder residual block i, then of decoder residual block i (AC_MAX_RATIOS each):
+    //            |hidden| <= hb0 + hb1 amax(block input)  (rb_fused6.h / rb_fused6_128.h)
+    if (!h || !out || !h->finalized || h->arch != ARCH_ENCODEC) return AC_EINVAL;
+    const int n = 11 + 4 * AC_MAX_RATIOS;
+    if (cap < n) return AC_EINVAL;
+    for (int i = 0; i < n; ++i) out[i] = 0.f;
+    const int last = h->cfg.num_ratios - 1;
+    if (h->enc_front.ok) {
+        const float v[7] = {h->enc_front.sb0, h->enc_front.sb1, h->enc_rb[0].hb0, h->enc_rb[0].hb1, h->enc_front.fb0, h->enc_front.fb1h, h->enc_front.fb1x};
+        for (int i = 0; i < 7; ++i) out[i] = v[i];
+    }
+    if (h->dec_tail.ok) {
+        const float v[4] = {h->dec_tail.sb0, h->dec_tail.sb1, h->dec_rb[last].hb0, h->dec_rb[last].hb1};
+        for (int i = 0; i < 4; ++i) out[7 + i] = v[i];
+    }
+    for (int i = 0; i < h->cfg.num_ratios; ++i) {
+        if (h->has_enc && h->enc_rb[i].has6) { out[11 + 2 * i] = h->enc_rb[i].hb0; out[12 + 2 * i] = h->enc_rb[i].hb1; }
+        if (h->has_dec && h->dec_rb[i].has6) { out[11 + 2 * AC_MAX_RATIOS + 2 * i] = h->dec_rb[i].hb0; out[12 + 2 * AC_MAX_RATIOS + 2 * i] = h->dec_rb[i].hb1; }
+    }
+    return n;
+}
+
 int ac_debug_clock(ac_handle* h, int enable, double* shader_mhz) {
     if (!h || !h->finalized) return AC_EINVAL;
     if (shader_mhz) *shader_mhz = 0.0;

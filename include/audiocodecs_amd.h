@@ -331,6 +331,12 @@ int ac_profile_end(ac_handle* h, ac_kernel_stat* out, int cap);
 int ac_debug_capture(ac_handle* h, float* buf_dev, size_t cap_floats);
 size_t ac_debug_captured(const ac_handle* h);
 
+/* Test hook: the constants of the BOUNDS that stand in for an amax where a tensor exists only inside a fused kernel
+ * (csrc/enc_front.h, dec_tail.h, rb_fused6.h): a split16 scale derived from a bound 2^w too large costs w of the 16 bits of
+ * range split16 keeps below a tensor's largest element (csrc/split16.h); tests/test_split16_gpu.py measures w on speech-like
+ * data.  Writes 11 + 4 * AC_MAX_RATIOS floats (layout at the definition, csrc/ac_api.hip) and returns that count. */
+int ac_debug_bounds(const ac_handle* h, float* out, int cap);
+
 /* Diagnostics (SYNCHRONISES): shader clock the tap_gemm6 workgroups ran at since the last call -- every workgroup reads
  * s_memtime (shader clock) and s_memrealtime (100 MHz) at its start and end; *shader_mhz = 100 * sum / sum (0 when nothing ran).
  * enable != 0 arms the sampling for the following calls, 0 disarms it.  The matrix pipe on this chip is power-capped: the

@@ -149,3 +149,91 @@ def test_a_clip_alone_equals_the_clip_in_a_batch(name, dac_checkpoints, mimi_che
         tb = codec.sig_to_toks(sig[b : b + 1])
         assert torch.equal(tb, toks[b : b + 1]), f"{name}: tokens of clip {b} depend on its batch"
         assert torch.equal(codec.toks_to_sig(tb), rec[b : b + 1]), f"{name}: decode of clip {b} depends on its batch"
+
+
+def _speech_like_batch():
+    """Segments of the reference's example.wav (16 kHz speech fed as 24 kHz samples: the spectrum shifts, the dynamics stay) at
+    levels from -40 dBFS to full scale, with what real recordings add: a DC offset, isolated full-scale clicks, a hard-clipped
+    segment, digital silence in the middle of a clip, and a clip that fades in from nothing."""
+    from golden_cases import read_example_wav
+
+    wav = read_example_wav(GOLDEN_DIR)[0]
+    T = 36000
+    starts = [20000, 60000, 100000, 140000, 180000, 210000]
+    clips = [wav[s : s + T].clone() for s in starts]
+    peak = [float(c.abs().max()) for c in clips]
+    clips[0] = clips[0] / peak[0]                                 # 0 dBFS
+    clips[1] = clips[1] / peak[1] * 10 ** (-40 / 20)              # -40 dBFS
+    clips[2] = clips[2] / peak[2] * 0.1 + 0.05                    # -20 dBFS riding on a DC offset
+    clips[3] = clips[3] / peak[3] * 0.02
+    clips[3][5000] = 1.0                                          # clicks 34 dB above the speech around them
+    clips[3][5001] = -1.0
+    clips[3][23456] = 0.9
+    clips[4] = (clips[4] / peak[4] * 4.0).clamp(-1.0, 1.0)        # hard clipping
+    clips[4][12000:20000] = 0.0                                   # digital silence inside the clip
+    clips[5] = clips[5] / peak[5] * torch.linspace(0.0, 1.0, T) ** 4
+    return torch.stack(clips)
+
+
+def test_speech_like_batch_tokens_and_bound_waste(enc):
+    """(a) the usual parity policy on data with the dynamics of real recordings (tokens exact outside fp64 near-ties, waveform
+    within 1e-5 of the signal's scale); (b) every split16 scale that comes from a BOUND instead of a measured amax (the tensors
+    that exist only inside a fused kernel) wastes less than 2^10 of range: bound / true amax, the true amax taken from the
+    oracle's module outputs per clip.  split16 keeps fp32-grade relative precision 16 bits below a tensor's largest element
+    (split16.h), so 10 wasted bits still leave every element down to 2^-6 of the largest exact to fp32 rounding and the rest
+    with an absolute error of 2^-30 of the largest."""
+    import ctypes as C
+    import math
+
+    import torch.nn.functional as F
+    from oracle import encodec_oracle as O
+
+    cfg, sd, codec, W, W64 = enc
+    sig = _speech_like_batch()
+    toks, rec = _against_oracle(enc, sig, "speech_like")
+    nat = next(iter(codec._natives.values()))
+    buf = (C.c_float * 64)()
+    n = nat.lib.ac_debug_bounds(nat.h, buf, 64)
+    assert n == 11 + 4 * 8
+    b = [float(v) for v in buf[:n]]
+    assert b[1] > 0 and b[8] > 0, "the fused chains are what runs on this handle"
+    taps, dtaps = {}, {}
+    with torch.no_grad():
+        O.masked_embeddings(cfg, W, sig, None, taps=taps)
+        O.toks_to_sig(cfg, W, toks.cpu(), taps=dtaps)
+
+        def amax(t):                     # per clip
+            return t.abs().flatten(1).max(dim=1).values.double()
+
+        def hidden(x, p):                # ELU(conv_k3(ELU(x))) of the residual block with prefix p
+            return F.elu(O.conv1d_causal(F.elu(x), W[p + ".block.1.conv.weight"], W[p + ".block.1.conv.bias"]))
+
+        waste = {}
+        # encoder front: bounds chained from amax(sig)
+        a_sig = amax(sig)
+        X0 = b[0] + b[1] * a_sig
+        H = b[2] + b[3] * X0
+        Y1 = b[4] + b[5] * H + b[6] * X0
+        waste["enc_front.x0"] = X0 / amax(taps["enc0"])
+        waste["enc_front.hidden"] = H / amax(hidden(taps["enc0"], "encoder.layers.1"))
+        waste["enc_front.y1"] = Y1 / amax(taps["enc1"])
+        # separate residual blocks: hidden bound from the exact amax of the block input
+        for i, (tin, layer) in enumerate((("enc3", 4), ("enc6", 7), ("enc9", 10)), start=1):
+            if b[12 + 2 * i] > 0:
+                waste[f"enc_rb{i}.hidden"] = (b[11 + 2 * i] + b[12 + 2 * i] * amax(taps[tin])) / amax(hidden(taps[tin], f"encoder.layers.{layer}"))
+        for i, (tin, layer) in enumerate((("dec3", 4), ("dec6", 7), ("dec9", 10))):
+            if b[12 + 16 + 2 * i] > 0:
+                waste[f"dec_rb{i}.hidden"] = (b[11 + 16 + 2 * i] + b[12 + 16 + 2 * i] * amax(dtaps[tin])) / amax(hidden(dtaps[tin], f"decoder.layers.{layer}"))
+        # decoder tail: bounds chained from the exact amax of ELU(block output)
+        xe = F.elu(dtaps["dec10"])
+        U = b[7] + b[8] * amax(xe)
+        waste["dec_tail.u"] = U / amax(dtaps["dec12"])
+        waste["dec_tail.hidden"] = (b[9] + b[10] * U) / amax(hidden(dtaps["dec12"], "decoder.layers.13"))
+        # LSTM output: |lstm(x) + x| <= 1 + amax(x)
+        waste["enc_lstm.out"] = (1.0 + amax(taps["enc12"])) / amax(taps["enc13"])
+        waste["dec_lstm.out"] = (1.0 + amax(dtaps["dec0"])) / amax(dtaps["dec1"])
+    worst = {k: float(v.max()) for k, v in waste.items()}
+    parity_record.record("encodec", "split16_speech_like", bound_waste_bits={k: round(math.log2(max(v, 1e-30)), 2) for k, v in worst.items()})
+    for k, v in waste.items():
+        assert bool((v >= 1.0 - 1e-6).all()), (k, v)              # a bound below the true maximum would overflow the fp16 planes
+        assert worst[k] < 2.0 ** 10, (k, math.log2(worst[k]))
