@@ -163,7 +163,7 @@ __global__ __launch_bounds__(512, 2) void dec_tail_kernel(const DecTailParams p)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int e = lane + 64 * i;
-            split16_store4(rx[i] * sxs, Xs, DT_XS_PLANE, (1 + (e >> 4)) * DT_XSP + 4 * (e & 15));
+            split16_store4s(rx[i], sxs, Xs, DT_XS_PLANE, (1 + (e >> 4)) * DT_XSP + 4 * (e & 15));
         }
         if (lane < 32) copy_row(Ue, DT_UE_PLANE, DT_UEP, lane >> 4, 32 + (lane >> 4), lane & 15);
 
@@ -189,8 +189,8 @@ __global__ __launch_bounds__(512, 2) void dec_tail_kernel(const DecTailParams p)
                 const f32x4 v = ef_fma4(acc[c], iuv, buv);
                 const int rho = 2 * li + (c >> 1), co = 16 * (c & 1) + 4 * kq;      // output row of the chunk, first channel
                 if (p.dbg_u && emit && t0 + rho < T) *reinterpret_cast<f32x4*>(p.dbg_u + (ob + t0 + rho) * 32 + co) = v;
-                split16_store4(elu4(v) * su, Ue, DT_UE_PLANE, (2 + rho) * DT_UEP + co);
-                split16_store4(v * sb, Ur, DT_UR_PLANE, rho * DT_URP + co);
+                split16_store4s(elu4(v), su, Ue, DT_UE_PLANE, (2 + rho) * DT_UEP + co);
+                split16_store4s(v, sb, Ur, DT_UR_PLANE, rho * DT_URP + co);
             }
         }
         if (lane < 32) *reinterpret_cast<f16x4_t*>(Xprev + (lane >> 4) * DT_XSP + (lane & 15) * 4) = *reinterpret_cast<const f16x4_t*>(Xs + (lane >> 4) * DT_XS_PLANE + 16 * DT_XSP + (lane & 15) * 4);
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(512, 2) void dec_tail_kernel(const DecTailParams p)
             const f32x4 i3v = *reinterpret_cast<const f32x4*>(smem + DT_I3 + 4 * kq) * iu;
 #pragma unroll
             for (int a = 0; a < 2; ++a)
-                split16_store4(elu4(ef_fma4(aH[a] + aL[a], i3v, b3v)) * sb, Hs, DT_Q_PLANE, (a * 16 + li) * DT_QP + 4 * kq);
+                split16_store4s(elu4(ef_fma4(aH[a] + aL[a], i3v, b3v)), sb, Hs, DT_Q_PLANE, (a * 16 + li) * DT_QP + 4 * kq);
         }
         // ---- stage B: v = [W1 | Ws] * [hidden | u] + bf; ELU(v) -> Ve rows 6..37 in fp32 (over Hs: all its reads are issued first)
         {

@@ -7,14 +7,14 @@
 // Structure: one WAVE = one stream.  A wave walks a segment of one clip in chunks of 32 input samples and carries every
 // intermediate in its own LDS slab; no workgroup barrier in the loop, no cross-wave traffic:
 //   stem      x0 = b0 + W0 * sig[t-6 .. t]                       fp32 FMAs (bias first, taps ascending: stem_kernel's order);
-//             ELU(x0) and x0 are split (split16.h) into the slabs Xe (34 rows: 2 rows of causal halo, recomputed) and Xr
+//             ELU(x0) and x0 are split (split16.h) into the slabs Xe (34 rows: 2 rows of causal halo carried over) and Xr
 //   stage A   h  = ELU(W3 * Xe[t-2 .. t] + b3)                   3 k-steps, v_mfma_f32_16x16x32_f16, 3 partial products
 //   stage B   y1 = [W1 | Ws] * [h | x0] + (b1 + bs)              2 k-steps; ELU(y1) split into the slab Y1e (aliases Xe)
 //   stage C   y  = Wd * Y1e[2m-2 .. 2m+1] + bd                   4 k-steps, 16 output rows per chunk -> HBM (raw) + amax
-// The two rows of Y1e halo the strided conv needs are the last two rows of the previous chunk (kept in the slab), so
-// nothing but the stem's halo is recomputed; a segment that starts inside a clip runs ONE warm-up chunk without output.
-// Clip edges follow [HF]:157-176: reflect padding on the left of every conv (stem rows are computed at the reflected
-// time, Y1e rows copied), one reflected step on the right of the strided conv when T is odd, length mask on the samples.
+// The halo rows of Xe and Y1e are the last two rows of the previous chunk (kept in the slab), so nothing is recomputed
+// inside a stream; a segment that starts inside a clip runs ONE warm-up chunk without output.
+// Clip edges follow [HF]:157-176: reflect padding on the left of every conv (the sample window for the stem, row copies for
+// Xe and Y1e), one reflected step on the right of the strided conv when T is odd, length mask on the samples.
 // The weights of stages B and C (rb_fused6.h / thin_conv6.h fragment images) live in registers (160 VGPRs), stage A's are read from
 // LDS per chunk; two waves per SIMD.
 //
@@ -179,36 +179,34 @@ __global__ __launch_bounds__(64 * EF_WAVES, 2) void enc_front_kernel(const EncFr
     for (; ch < c_last; ++ch) {
         const int t0 = ch * EF_ROWS;
         const bool emit = ch >= c_first;
-        // Y1e halo = the previous chunk's last two rows (stale bytes in the first chunk of a stream: fixed below at a clip
-        // start, never emitted in a warm-up chunk)
+        // Halos = the previous chunk's last two rows: Y1e rows 32, 33 -> 0, 1 and Xe rows 34, 35 -> 2, 3 (Y1e, written over
+        // Xe rows 2..33, leaves them alone).  Stale bytes in the first chunk of a stream: fixed below at a clip start, and in a
+        // warm-up chunk they reach only rows whose results nothing reads.
         if (lane < 32) copy_row(R1, EF_R1_PLANE, EF_XP, lane >> 4, 32 + (lane >> 4), lane & 15);
+        else copy_row(R1, EF_R1_PLANE, EF_XP, 2 + ((lane - 32) >> 4), 34 + ((lane - 32) >> 4), lane & 15);
         if (lane < EF_SIGW) sg[lane] = sv;
         if (ch + 1 < c_last) sv = fetch_sig(t0 + EF_ROWS);   // in flight during the chunk
 
-        // ---- stem: slab row r <-> time t0 - 2 + r (34 rows), lane item = (row, 4 channels)
+        // ---- stem: 32 rows (times t0 .. t0 + 31 -> Xe rows 4..35, Xr rows 0..31), lane item = (row, 4 channels)
 #pragma unroll
-        for (int it = 0; it < 5; ++it) {
+        for (int it = 0; it < 4; ++it) {
             const int e = lane + 64 * it;
-            const int r = e >> 3, g = e & 7;
+            const int r = e >> 3, g = e & 7;                 // row of the chunk, channel group
             asm volatile("" ::: "memory");      // the stem weights are re-read per item: 32 fewer registers held beside the matrix weights
-            if (it < 4 || r < 34) {
-                const int tau = t0 - 2 + r;
-                const int wi = (tau < 0 ? -tau : tau) - t0 + 2;          // window index of tap 0 (reflected row at a clip start)
-                f32x4 acc = *reinterpret_cast<const f32x4*>(smem + EF_B0 + 4 * g);
+            f32x4 acc = *reinterpret_cast<const f32x4*>(smem + EF_B0 + 4 * g);
 #pragma unroll
-                for (int j = 0; j < 7; ++j) {
-                    const float xv = sg[wi + j];
-                    const f32x4 w = *reinterpret_cast<const f32x4*>(smem + EF_W0 + j * 32 + 4 * g);
-                    acc.x = fmaf(w.x, xv, acc.x); acc.y = fmaf(w.y, xv, acc.y);
-                    acc.z = fmaf(w.z, xv, acc.z); acc.w = fmaf(w.w, xv, acc.w);
-                }
-                split16_store4(elu4(acc) * sx, R1, EF_R1_PLANE, (2 + r) * EF_XP + 4 * g);
-                if (r >= 2) {
-                    split16_store4(acc * sb, Xr, EF_Q_PLANE, (r - 2) * EF_QP + 4 * g);
-                    if (p.dbg_x0 && emit && tau < p.T) *reinterpret_cast<f32x4*>(p.dbg_x0 + ((long long)b * p.T + tau) * 32 + 4 * g) = acc;
-                }
+            for (int j = 0; j < 7; ++j) {
+                const float xv = sg[r + 2 + j];              // sample t0 + r - 6 + j  (window index 0 <-> t0 - 8)
+                const f32x4 w = *reinterpret_cast<const f32x4*>(smem + EF_W0 + j * 32 + 4 * g);
+                acc.x = fmaf(w.x, xv, acc.x); acc.y = fmaf(w.y, xv, acc.y);
+                acc.z = fmaf(w.z, xv, acc.z); acc.w = fmaf(w.w, xv, acc.w);
             }
+            split16_store4s(elu4(acc), sx, R1, EF_R1_PLANE, (4 + r) * EF_XP + 4 * g);
+            split16_store4s(acc, sb, Xr, EF_Q_PLANE, r * EF_QP + 4 * g);
+            if (p.dbg_x0 && emit && t0 + r < p.T) *reinterpret_cast<f32x4*>(p.dbg_x0 + ((long long)b * p.T + t0 + r) * 32 + 4 * g) = acc;
         }
+        // reflect padding of the k3 conv at the clip start ([HF]:157-176): x0e[-1] = x0e[1], x0e[-2] = x0e[2]  (rows 3, 2 <- 5, 6)
+        if (t0 == 0 && lane < 32) copy_row(R1, EF_R1_PLANE, EF_XP, 2 + (lane >> 4), 6 - (lane >> 4), lane & 15);
 
         // ---- stage A: hidden = ELU(W3 * Xe + b3), 32 rows x 16 channels
         {
@@ -235,7 +233,7 @@ __global__ __launch_bounds__(64 * EF_WAVES, 2) void enc_front_kernel(const EncFr
             const f32x4 i3v = *reinterpret_cast<const f32x4*>(smem + EF_I3 + 4 * kq) * ix;
 #pragma unroll
             for (int a = 0; a < 2; ++a)
-                split16_store4(elu4(ef_fma4(aH[a] + aL[a], i3v, b3v)) * sb, Hs, EF_Q_PLANE, (a * 16 + li) * EF_QP + 4 * kq);
+                split16_store4s(elu4(ef_fma4(aH[a] + aL[a], i3v, b3v)), sb, Hs, EF_Q_PLANE, (a * 16 + li) * EF_QP + 4 * kq);
         }
 
         // ---- stage B: y1 = [W1 | Ws] * [hidden | x0] + bf; ELU(y1) -> Y1e rows 2..33 (over Xe: stage A is done with it)
@@ -273,7 +271,7 @@ __global__ __launch_bounds__(64 * EF_WAVES, 2) void enc_front_kernel(const EncFr
                     const f32x4 v = ef_fma4(acc[a][c], ifv, bfv);
                     const int t = t0 + a * 16 + li;
                     if (p.dbg_y1 && emit && t < p.T) *reinterpret_cast<f32x4*>(p.dbg_y1 + ((long long)b * p.T + t) * 32 + 16 * c + 4 * kq) = v;
-                    split16_store4(elu4(v) * sy, R1, EF_R1_PLANE, (2 + a * 16 + li) * EF_XP + 16 * c + 4 * kq);
+                    split16_store4s(elu4(v), sy, R1, EF_R1_PLANE, (2 + a * 16 + li) * EF_XP + 16 * c + 4 * kq);
                 }
             }
         }

@@ -90,7 +90,7 @@ __device__ __forceinline__ void split3(float v, unsigned& h, unsigned& m, unsign
 template <int NP = 3>
 __device__ __forceinline__ void split_store4(const f32x4 v, __bf16* p0, int plane, int o, float scale = 1.f) {
     if (NP == 2) {   // split16.h
-        split16_store4(v * scale, p0, plane, o);
+        split16_store4s(v, scale, p0, plane, o);
         return;
     }
     if (NP == 1) {

@@ -53,10 +53,11 @@ constexpr int AMAX_STRIDE = 32;
 __host__ __device__ __forceinline__ unsigned* amax_at(unsigned* slot, int b) { return slot + (long long)b * AMAX_STRIDE; }
 __host__ __device__ __forceinline__ const unsigned* amax_at(const unsigned* slot, int b) { return slot + (long long)b * AMAX_STRIDE; }
 
-// |v| bits into a running maximum
+// |v| bits into a running maximum: the largest FINITE magnitude -- inf / NaN elements stay what they are in fp16 and do not
+// enter the scale (v_cmp_class + v_cndmask |v| + v_max_u32: three instructions per value)
 __device__ __forceinline__ void amax_acc(unsigned& mx, float v) {
-    const unsigned b = __float_as_uint(v) & 0x7fffffffu;
-    mx = (b > mx && b < 0x7f800000u) ? b : mx;     // the largest FINITE magnitude: inf / NaN elements stay what they are in fp16
+    const unsigned b = __builtin_amdgcn_classf(v, 0x1F8) ? __float_as_uint(__builtin_fabsf(v)) : 0u;     // 0x1F8: +-normal, +-subnormal, +-0
+    mx = b > mx ? b : mx;
 }
 __device__ __forceinline__ void amax_acc4(unsigned& mx, const s16_f32x4 v) {
     amax_acc(mx, v.x); amax_acc(mx, v.y); amax_acc(mx, v.z); amax_acc(mx, v.w);
@@ -71,11 +72,16 @@ __device__ __forceinline__ void amax_flush(unsigned mx, unsigned* slot) {
     if ((threadIdx.x & 63) == 0 && mx > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, mx);
 }
 
-// 4 scaled fp32 values -> hi / lo fp16 planes, 8 bytes each at element offset `o` (planes `plane` elements apart)
-__device__ __forceinline__ void split16_store4(const s16_f32x4 v, void* p0, int plane, int o) {
-    const f16x4_t hi = __builtin_convertvector(v, f16x4_t);
-    const s16_f32x4 r = v - __builtin_convertvector(hi, s16_f32x4);
-    const f16x4_t lo = __builtin_convertvector(r, f16x4_t);
+// 4 fp32 values x scale -> hi / lo fp16 planes, 8 bytes each at element offset `o` (planes `plane` elements apart):
+//   hi = fp16(v s),  lo = fp16(fma(v, s, -hi))   -- v_fma_mixlo/mixhi_f16 does the fma on the fp16 `hi` and the rounding of the
+// result in ONE instruction: two instructions per value in all (v_pk_mul, v_cvt_pk, 2 x v_fma_mix per pair)
+__device__ __forceinline__ void split16_store4s(const s16_f32x4 v, const float s, void* p0, int plane, int o) {
+    const f16x4_t hi = __builtin_convertvector(v * s, f16x4_t);
+    f16x4_t lo;
+    lo.x = (_Float16)__builtin_fmaf(v.x, s, -(float)hi.x);
+    lo.y = (_Float16)__builtin_fmaf(v.y, s, -(float)hi.y);
+    lo.z = (_Float16)__builtin_fmaf(v.z, s, -(float)hi.z);
+    lo.w = (_Float16)__builtin_fmaf(v.w, s, -(float)hi.w);
     *reinterpret_cast<f16x4_t*>(reinterpret_cast<_Float16*>(p0) + o) = hi;
     *reinterpret_cast<f16x4_t*>(reinterpret_cast<_Float16*>(p0) + plane + o) = lo;
 }

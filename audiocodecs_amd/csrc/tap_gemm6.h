@@ -205,7 +205,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (tap6_occupancy<WGM, WGN, WMT, WN, 
                     continue;
                 }
                 if (NP == 2) {   // split16.h: scaled value = hi + lo in fp16
-                    split16_store4(v * a_rsc[i], dst, PLANE, a_lds[i]);
+                    split16_store4s(v, a_rsc[i], dst, PLANE, a_lds[i]);
                     continue;
                 }
                 unsigned h[4], m[4], l[4];
