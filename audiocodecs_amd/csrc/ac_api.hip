@@ -18,6 +18,7 @@
 #include "lstm_persist6.h"
 #include "lstm_persist16.h"
 #include "rvq.h"
+#include "rvq16.h"
 #include "tap_gemm.h"
 #include "tap_gemm4.h"
 #include "tap_gemm6.h"
@@ -165,6 +166,7 @@ struct ac_handle {
     std::vector<ResBlockPlan> dec_rb;
     // codebooks
     size_t cb_plain = 0, cb_packed = 0, cb_ee = 0;
+    size_t cb16 = 0, cb16_inv = 0;   // rvq16.h: split16 images of the codebooks + their 2^-s (0: not packed -- other arithmetic or shape)
     // bounds of the fused thin-channel chains (enc_front.h): |stem out| <= sb0 + sb1 amax(sig); |block out| <= fb0 + fb1h H + fb1x X
     struct ChainBounds { float sb0 = 0.f, sb1 = 0.f, fb0 = 0.f, fb1h = 0.f, fb1x = 0.f; bool ok = false; } enc_front, dec_tail;   // dec_tail: sb0 / sb1 are the transposed conv's
     bool fuse_chains = true;        // AC_FUSE=0 at ac_finalize: the layers of the fused chains as separate kernels (A/B runs, cross-check tests)
@@ -1812,6 +1814,19 @@ int rvq_encode_fwd(ac_handle* h, hipStream_t st, const float* feats, int F, int 
     // frames per wave: 48 once there are enough frames to fill every SIMD (1024) with one wave
     const int MS = (HV <= 8 && F >= 1024 * 32) ? 3 : 1;
     const dim3 grid(cdiv(F, 16 * MS)), block(64);
+    static const bool exact_env = std::getenv("AC_RVQ") && std::strcmp(std::getenv("AC_RVQ"), "fp32") == 0;   // developer A/B switch
+    if (h->cb16 && HV == 8 && !exact_env) {   // split16 products on the fp16 matrix pipe (rvq16.h)
+        RvqEnc16Params q{};
+        q.base = p;
+        q.epk16 = reinterpret_cast<const _Float16*>(h->blob + h->cb16);
+        q.einv = h->blob + h->cb16_inv;
+        ProfScope ps(h, st, "rvq_encode16_kernel", 2.0 * F * (double)p.C * p.H * K,
+                     (double)F * p.H * 4 + (double)F * K * 8 + (double)K * p.C * p.H * 4);
+        if (MS == 3) hipLaunchKernelGGL((rvq_encode16_kernel<8, 3, false>), grid, block, 0, st, q);
+        else hipLaunchKernelGGL((rvq_encode16_kernel<8, 1, false>), grid, block, 0, st, q);
+        HIPCHK(h, hipGetLastError());
+        return AC_OK;
+    }
     ProfScope ps(h, st, "rvq_encode_kernel", 2.0 * F * (double)p.C * p.H * K,
                  (double)F * p.H * 4 + (double)F * K * 8 + (double)K * p.C * p.H * 4);
 #define RVQ_CASE(HV_, MS_) hipLaunchKernelGGL((rvq_encode_kernel<HV_, MS_, false>), grid, block, 0, st, p)
@@ -2395,6 +2410,32 @@ int ac_finalize(ac_handle* h) {
                     for (int u = 0; u < 4; ++u)
                         pk.blob[h->cb_packed + (size_t)q * C * H + (((size_t)ct * HV + v) * 64 + lane) * 4 + u] =
                             (*e)[(size_t)(ct * 16 + (lane & 15)) * H + v * 16 + 4 * (lane >> 4) + u];
+    }
+    if (pk.use16() && H % 32 == 0 && H / 16 == 8) {
+        // rvq16.h: split16 image of every table, one power-of-two scale per table, halves in the lanes' own dim order:
+        //   [q][code tile 16][k-step s of 32][plane 2][lane (j, kq)][e 8]  <->  dim 16 (2s + e/4) + 4 kq + e%4 of code 16 ct + j
+        const int KS = H / 32;
+        h->cb16 = pk.reserve((size_t)Q * C * H);                  // 2 planes x 2 bytes = 4 bytes per element
+        h->cb16_inv = pk.reserve((size_t)Q);
+        std::vector<uint16_t> img((size_t)Q * C * H * 2);
+        for (int q = 0; q < Q; ++q) {
+            const float* e = &pk.blob[h->cb_plain + (size_t)q * C * H];
+            const int se = Packer::row_scale(e, (size_t)C * H);
+            pk.blob[h->cb16_inv + q] = s16_pow2(-se);
+            for (int ct = 0; ct < C / 16; ++ct)
+                for (int s = 0; s < KS; ++s)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int e8 = 0; e8 < 8; ++e8) {
+                            const int j = lane & 15, kq = lane >> 4;
+                            const int dim = 16 * (2 * s + e8 / 4) + 4 * kq + e8 % 4;
+                            uint16_t t[3];
+                            Packer::split16h(e[(size_t)(ct * 16 + j) * H + dim], se, t);
+                            const size_t base = ((((size_t)q * (C / 16) + ct) * KS + s) * 2) * 512 + (size_t)lane * 8 + e8;
+                            img[base] = t[0];
+                            img[base + 512] = t[1];
+                        }
+        }
+        std::memcpy(&pk.blob[h->cb16], img.data(), img.size() * 2);
     }
     return upload_blob(h, pk, c.device);
 }

@@ -1,0 +1,177 @@
+// rvq16: the codebook search of rvq.h (same residual layout, same distance form, same first-index argmax, same fp32 residual
+// update) with the 2 x.E^T products in split16 arithmetic (split16.h) on the fp16 matrix pipe instead of exact fp32 products on
+// v_mfma_f32_16x16x4_f32: the search was bound by the fp32 matrix pipe (0.98 ms of the 19 ms step at 0.66 of its 157 TF); three
+// fp16 partial products per fp32 product run 16 / 3 times faster.
+//   * residual rows: one power-of-two scale per FRAME from the row's largest magnitude, recomputed every stage (the residual
+//     shrinks by stages); hi / lo planes built in registers in the order the lane already holds its values -- the k order of a
+//     dot product is free as long as both operands use the same one, so the codebook image is packed in THAT order offline:
+//         k-step s of 32, half e of lane (j, kq)  <->  dim 16 (2s + e/4) + 4 kq + e%4
+//   * codebook stage k: one scale for the whole [C][H] table (code vectors of one table have comparable magnitudes; elements
+//     16 bits below the table's largest keep fp32-grade relative precision, split16.h), image
+//         epk16[K][C/16 code tiles][H/32 k-steps][2 planes][64 lanes][8 fp16]
+//   * dist = -((|x|^2 - 2 dot) + |e|^2) with |x|^2 and |e|^2 exact fp32 as before; dot = acc * 2^-(sx + se) is exact scaling.
+// One wave owns 16 MS frames; MS = 3 at the benchmark size: 1000 waves for 1024 SIMDs, 382 registers, and a code tile fetched
+// from L2 (8 KB) feeds 36 MFMAs (the CU's 64 B/clk L1 path is the next bound: 57 B/clk).
+// The error of a dot product equals that of an fp32 FMA chain (split16.h); the token policy (exact outside fp64 near-ties of
+// 1e-4 relative margin) holds unchanged (tests/test_gpu_parity.py, test_gpu_fullsize.py).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "rvq.h"
+#include "split16.h"
+
+namespace ac {
+
+struct RvqEnc16Params {
+    RvqEncParams base;
+    const _Float16* epk16;   // split16 images of the codebooks (layout above)
+    const float* einv;       // [K] 2^-se of each table's image
+};
+
+template <int HV, int MS, bool CDIST>
+__global__ __launch_bounds__(64) void rvq_encode16_kernel(const RvqEnc16Params q) {
+    static_assert(HV % 2 == 0, "k-steps of 32 dims");
+    constexpr int KS = HV / 2;
+    const RvqEncParams& p = q.base;
+    const int lane = threadIdx.x & 63;
+    const int li = lane & 15, kq = lane >> 4;
+    const int f0 = blockIdx.x * (16 * MS);
+    const int H = p.H;
+
+    f32x4 res[MS][HV];
+#pragma unroll
+    for (int m = 0; m < MS; ++m) {
+        const int frow = f0 + m * 16 + li;
+#pragma unroll
+        for (int v = 0; v < HV; ++v)
+            res[m][v] = frow < p.F ? *reinterpret_cast<const f32x4*>(p.x + (long long)frow * p.xs + v * 16 + 4 * kq)
+                                   : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    const int ctiles = p.C / 16;
+    for (int k = 0; k < p.K; ++k) {
+        float xxr[MS][4], m2s[MS][4];        // per accumulator row: |x|^2 and -2 * 2^-(sx + se)
+        f16x8 xh[MS][KS], xl[MS][KS];
+        const float einv = q.einv[k];
+#pragma unroll
+        for (int m = 0; m < MS; ++m) {
+            float xx = 0.f;
+            unsigned am = 0;
+#pragma unroll
+            for (int v = 0; v < HV; ++v) {
+                xx = fmaf(res[m][v].x, res[m][v].x, xx); xx = fmaf(res[m][v].y, res[m][v].y, xx);
+                xx = fmaf(res[m][v].z, res[m][v].z, xx); xx = fmaf(res[m][v].w, res[m][v].w, xx);
+                amax_acc4(am, res[m][v]);
+            }
+            xx += __shfl_xor(xx, 16);
+            xx += __shfl_xor(xx, 32);
+            unsigned t = (unsigned)__shfl_xor((int)am, 16);
+            am = t > am ? t : am;
+            t = (unsigned)__shfl_xor((int)am, 32);
+            am = t > am ? t : am;                              // the frame's largest finite magnitude, in all four of its lanes
+            const int ex = s16_exponent(am);
+            const float sx = s16_pow2(ex);
+            const float mine = -2.0f * s16_pow2(-ex) * einv;   // exact: powers of two
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                xxr[m][r] = __shfl(xx, kq * 4 + r);
+                m2s[m][r] = __shfl(mine, kq * 4 + r);
+            }
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const f32x4 a = res[m][2 * s], b = res[m][2 * s + 1];
+                const float v8[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const _Float16 h = (_Float16)(v8[e] * sx);
+                    xh[m][s][e] = h;
+                    xl[m][s][e] = (_Float16)__builtin_fmaf(v8[e], sx, -(float)h);
+                }
+            }
+        }
+        float best[MS][4];
+        int bidx[MS][4];
+#pragma unroll
+        for (int m = 0; m < MS; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { best[m][r] = -3.0e38f; bidx[m][r] = 0; }
+        const _Float16* ep = q.epk16 + (long long)k * p.C * H * 2 + lane * 8;
+        const float* eek = p.ee + (long long)k * p.C;
+        auto load_tile = [&](int ct, f16x8 (&bh)[KS], f16x8 (&bl)[KS], float& eev) {
+            const _Float16* et = ep + (long long)ct * KS * 1024;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                bh[s] = *reinterpret_cast<const f16x8*>(et + (s * 2 + 0) * 512);
+                bl[s] = *reinterpret_cast<const f16x8*>(et + (s * 2 + 1) * 512);
+            }
+            eev = eek[ct * 16 + li];
+        };
+        auto run_tile = [&](int ct, const f16x8 (&bh)[KS], const f16x8 (&bl)[KS], float eev) {
+            f32x4 acc[MS];
+#pragma unroll
+            for (int m = 0; m < MS; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+#pragma unroll
+                for (int m = 0; m < MS; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl[m][s], bh[s], acc[m], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < MS; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh[m][s], bl[s], acc[m], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < MS; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh[m][s], bh[s], acc[m], 0, 0, 0);
+            }
+            const int code = ct * 16 + li;
+#pragma unroll
+            for (int m = 0; m < MS; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    // dist = -((xx - 2*dot) + ee) in the reference's order; -2 dot = acc * m2s is an exact scaling of the accumulator
+                    float d = __fmaf_rn(acc[m][r], m2s[m][r], xxr[m][r]) + eev;
+                    d = CDIST ? -sqrtf(fmaxf(d, 1e-30f)) : -d;
+                    if (d > best[m][r]) { best[m][r] = d; bidx[m][r] = code; }
+                }
+        };
+        f16x8 bh0[KS], bl0[KS], bh1[KS], bl1[KS];
+        float ee0, ee1 = 0.f;
+        load_tile(0, bh0, bl0, ee0);
+        for (int ct = 0; ct < ctiles; ct += 2) {
+            load_tile(ct + 1, bh1, bl1, ee1);
+            run_tile(ct, bh0, bl0, ee0);
+            if (ct + 2 < ctiles) load_tile(ct + 2, bh0, bl0, ee0);
+            run_tile(ct + 1, bh1, bl1, ee1);
+        }
+#pragma unroll
+        for (int m = 0; m < MS; ++m) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                for (int sh = 1; sh < 16; sh <<= 1) {
+                    const float ob = __shfl_xor(best[m][r], sh);
+                    const int oi = __shfl_xor(bidx[m][r], sh);
+                    if (ob > best[m][r] || (ob == best[m][r] && oi < bidx[m][r])) { best[m][r] = ob; bidx[m][r] = oi; }
+                }
+            }
+            if (li == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int f = f0 + m * 16 + kq * 4 + r;
+                    if (f < p.F) p.toks[(long long)f * p.tK + p.tk0 + k] = (long long)bidx[m][r];
+                }
+            }
+            int myidx = 0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int v = __shfl(bidx[m][r], (li >> 2) * 16);
+                if ((li & 3) == r) myidx = v;
+            }
+            if (k + 1 < p.K) {
+                const float* qv_ = p.e + ((long long)k * p.C + myidx) * H + 4 * kq;
+#pragma unroll
+                for (int v = 0; v < HV; ++v) {
+                    const f32x4 qv = *reinterpret_cast<const f32x4*>(qv_ + v * 16);
+                    res[m][v].x -= qv.x; res[m][v].y -= qv.y; res[m][v].z -= qv.z; res[m][v].w -= qv.w;
+                }
+            }
+        }
+    }
+}
+
+}  // namespace ac
