@@ -1,13 +1,22 @@
 #!/bin/bash
 # Build libaudiocodecs_amd.so for gfx950 (MI355X) in-tree.  Usage: build.sh [extra hipcc flags]
-set -euo pipefail
-here="$(cd "$(dirname "$0")" && pwd)"
-out="$here/../libaudiocodecs_amd.so"
-HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+# Five translation units (core.h has the map), compiled in parallel, linked into one shared library.
 # -fno-slp-vectorize: the SLP vectoriser turns the stem's scalar fp32 FMAs (enc_front.h) into v_pk_fma_f32 with op_sel
 # broadcasts, and THAT code returned wrong values in lanes 48..63 of one FMA group per ~100 chunks whenever a second wave shared the
 # SIMD (run-to-run different; never with one wave per SIMD, never without the packed FMAs -- profiles/r3_pk_fma_hazard.md).
 # The flag costs the other kernels nothing measurable (19.2 -> 19.5 ms per step, inside the box-to-box spread).
-"$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -fPIC -shared -Wall -Wno-unused-function \
-    -I"$here/../../include" "$@" -o "$out" "$here/ac_api.hip"
+set -euo pipefail
+here="$(cd "$(dirname "$0")" && pwd)"
+out="$here/../libaudiocodecs_amd.so"
+obj="$here/build"
+HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -fPIC -Wall -Wno-unused-function -I"$here/../../include" "$@")
+mkdir -p "$obj"
+pids=()
+for tu in core mimi_path dac_path wavtok_path ac_api; do
+    "$HIPCC" "${FLAGS[@]}" -c "$here/$tu.hip" -o "$obj/$tu.o" &
+    pids+=($!)
+done
+for p in "${pids[@]}"; do wait "$p"; done
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$out" "$obj"/core.o "$obj"/mimi_path.o "$obj"/dac_path.o "$obj"/wavtok_path.o "$obj"/ac_api.o
 echo "built $out"

@@ -1,5 +1,5 @@
 // DAC: model plan, weight packing and the launch sequences of encode / decode.
-// Included by ac_api.hip inside its anonymous namespace.  Algorithm: descript-audio-codec 1.0.0
+// One translation unit of the library (core.h has the map): owns the DAC kernels of dac.h and ac_dac_create.  Algorithm: descript-audio-codec 1.0.0
 // (dac/model/dac.py, dac/nn/layers.py, dac/nn/quantize.py) as /root/reference/audiocodecs/dac.py calls it;
 // that package is not on disk, line cites below are to the same-architecture [HF] transformers
 // models/dac/modeling_dac.py (PARITY UNPINNED w.r.t. the reference, oracle/dac_oracle.py header).
@@ -12,7 +12,12 @@
 // Every conv is the tap-GEMM again: symmetric zero padding is the segment's `pad`, dilation reloads the A slab
 // per tap, Snake (per-channel alpha of the CONSUMING layer) is the activated flavour written by the producer's
 // epilogue, the padded transposed conv writes shifted rows with a range mask.
-#pragma once
+#include "core.h"
+#include "dac.h"
+
+namespace acimpl {
+
+static_assert(DAC_D == DAC_CODE_DIM, "core.h mirrors dac.h");
 
 struct SnakeP {
     const float* a = nullptr;
@@ -308,7 +313,7 @@ int dac_from_codes(ac_handle* h, hipStream_t st, const long long* toks, int F, i
     const long long cnt = (long long)F * (m.H / 4);
     p.bad = h->sticky_dev ? h->sticky_dev + ST_BAD_TOKEN : nullptr;
     ProfScope ps(h, st, "rvq_decode_kernel", (double)F * m.H * K, (double)F * K * 8 + (double)F * m.H * 4 * (K + 1));
-    hipLaunchKernelGGL(rvq_decode_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, p);
+    rvq_decode_launch(st, p, (unsigned)((cnt + 255) / 256));
     HIPCHK(h, hipGetLastError());
     return AC_OK;
 }
@@ -426,5 +431,43 @@ int dac_finalize(ac_handle* h, Packer& pk) {
     m.in_proj0.has_bias = true;
     m.in_proj0.w_off = m.win;
     m.in_proj0.b_off = m.bin;
+    return AC_OK;
+}
+
+// in_proj of the first codebook alone (dac.py:103-112, _sig_to_feats with latent=True)
+int dac_latent_proj(ac_handle* h, hipStream_t st, const float* z, int N, int nb, float* zlat) {
+    const int H = h->dac.H;
+    Act za{z, (long long)N * H, H, N, H};
+    return dac_conv(h, st, h->dac.in_proj0, za, 1, 1, 1, 0, Out{zlat, nullptr}, SnakeP{}, nb, nullptr);
+}
+
+}  // namespace acimpl
+
+extern "C" int ac_dac_create(const ac_dac_config* cfg, ac_handle** out) {
+    if (!cfg || !out) return AC_EINVAL;
+    *out = nullptr;
+    if (cfg->struct_size != (int32_t)sizeof(ac_dac_config)) return AC_EINVAL;
+    const ac_dac_config& c = *cfg;
+    if (c.num_ratios < 1 || c.num_ratios > AC_MAX_RATIOS || c.encoder_hidden_size < 1 || c.decoder_hidden_size < (1 << c.num_ratios) ||
+        c.decoder_hidden_size % (1 << c.num_ratios) || c.n_codebooks < 1 || c.codebook_size % 64 || c.codebook_size < 64 ||
+        c.codebook_dim != DAC_D || c.num_dilations < 1 || c.num_dilations > AC_MAX_DILATIONS)
+        return AC_EINVAL;
+    const int H = c.encoder_hidden_size << c.num_ratios;
+    if (H % 64 || H > 1024) return AC_EINVAL;
+    for (int i = 0; i < c.num_dilations; ++i)
+        if (c.dilations[i] < 1 || 6 * c.dilations[i] > GEN_EXTRA) return AC_EINVAL;
+    for (int i = 0; i < c.num_ratios; ++i)
+        if (c.downsampling_ratios[i] < 1 || c.upsampling_ratios[i] < 1) return AC_EINVAL;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= c.device || c.device < 0) return AC_ENODEV;
+    ac_handle* h = new (std::nothrow) ac_handle();
+    if (!h) return AC_ENOMEM;
+    h->arch = ARCH_DAC;
+    h->dcfg = c;
+    h->hop = 1;
+    for (int i = 0; i < c.num_ratios; ++i) h->hop *= c.downsampling_ratios[i];
+    h->D = H;
+    h->dac.H = H;
+    *out = h;
     return AC_OK;
 }

@@ -20,12 +20,12 @@
 // Layer 1 multiplies W_ih1 with h0[t+1] (layer 0 runs ahead) right after publishing h1[t], i.e. while its peers'
 // slices travel: the input projection hides behind the exchange latency and needs no gin buffer.
 #pragma once
+#include "lstm_consts.h"
 #include <hip/hip_runtime.h>
 #include "lstm.h"
 
 namespace ac {
 
-constexpr int LP_D = 512, LP_SLICES = 32, LP_FLAG_STRIDE = 32;   // one 128-byte line per flag
 
 struct LstmPersistParams {
     const float* gin0;     // [T][Ball][4D] layer-0 pre-activations (x W_ih0^T + b_ih0 + b_hh0), clip row stride 4D
@@ -64,9 +64,6 @@ __global__ __launch_bounds__(256) void lstm_persist_probe_kernel(unsigned* hist)
     if (threadIdx.x == 0) atomicAdd(&hist[lp_xcc_id() & 15], 1u);
 }
 
-// Sticky status words of a handle (host-pinned, device-mapped: the host reads them without synchronising; they are
-// never cleared by a launch).  Written by lstm_tail_kernel / rvq_decode_kernel.
-enum { ST_LSTM_TIMEOUT = 0, ST_LSTM_PLACEMENT = 1, ST_BAD_TOKEN = 2, ST_NONFINITE_CLIPS = 3, ST_WORDS = 4 };
 constexpr int LP_NEVER = 0x7f7f7f7f;   // poison fill (hipMemsetAsync byte 0x7f): "this clip never went non-finite"
 
 struct LstmTailParams {

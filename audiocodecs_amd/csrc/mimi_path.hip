@@ -1,5 +1,5 @@
 // Mimi: model plan, weight packing and the launch sequences of encode / decode.
-// Included by ac_api.hip inside its anonymous namespace (uses its Packer, run_tap, Act/Out, ProfScope ...).
+// One translation unit of the library (core.h has the map): owns the Mimi kernels of mimi.h and ac_mimi_create.
 //
 //   encode ([HF] mimi :1237-1259): SEANet encoder (:444-492) -> 8-layer causal transformer (:782-928) ->
 //           stride-2 replicate-padded conv (:1195-1208) -> split RVQ (:1084-1127)
@@ -8,20 +8,13 @@
 // Data layout: channels-last fp32 as for EnCodec; the transformer works on the [B*T][hidden] token matrix
 // (the same memory), so encoder conv -> transformer -> down-sampler need no transposes (the reference
 // transposes twice per transformer, :1248-1257).
-#pragma once
+#include "core.h"
+#include "mimi.h"
+
+namespace acimpl {
 
 constexpr int MIMI_ROPE_T = 8192;   // positions tabulated (327 s at 25 Hz; HF max_position_embeddings = 8000)
 
-struct Epi {
-    const float* scale = nullptr;
-    const float* res = nullptr;
-    long long res_bs = 0, res_rs = 0;
-    int gelu = 0;
-    // split16.h row mode (mimi_linear): per-row amax words of the input when the producing linear layer left them, and
-    // where to return the output's (null: not wanted)
-    const unsigned* rowmax_in = nullptr;
-    const unsigned** rowmax_out = nullptr;
-};
 
 // conv (stride 1 or k = 2*stride) with the given padding rule, output contiguous [B][M][N]
 int mimi_conv(ac_handle* h, hipStream_t st, const PackedGemm& g, const Act& x, int k, int s, int pad, Out out, int B, Act2* y,
@@ -55,43 +48,6 @@ int mimi_conv(ac_handle* h, hipStream_t st, const PackedGemm& g, const Act& x, i
     return rc;
 }
 
-// y[rows][N] = epi(x[rows][cin-slice] * W^T): a 1-tap GEMM over the merged token matrix.  `x_pitch` is the row
-// pitch of x, `kofs`/`Ktot` select a column block of a wider packed weight.  Rows are chunked so that one
-// launch's operands stay below the 2 GB range of a buffer descriptor.
-int mimi_linear(ac_handle* h, hipStream_t st, const PackedGemm& g, const float* x, long long rows, int cin, int x_pitch, int kofs,
-                float* y, int y_pitch, const Epi& epi = Epi{}) {
-    const long long widest = std::max<long long>(std::max(x_pitch, y_pitch), g.N);
-    long long chunk = ((1LL << 31) / 4 - 4096) / widest / 128 * 128;
-    if (chunk < 128) return fail(h, AC_EINVAL, "linear layer too wide for the tap-GEMM (%lld)", widest);
-    for (long long r0 = 0; r0 < rows; r0 += chunk) {
-        const long long n = std::min(chunk, rows - r0);
-        TapGemmParams p{};
-        p.nseg = 1;
-        Act xa{x + r0 * x_pitch, 0, x_pitch, (int)n, cin};
-        const bool one = r0 == 0 && n == rows;     // row words are chained between launches that cover the whole matrix
-        if (one && epi.rowmax_in) { xa.amax = epi.rowmax_in; xa.amax_n = -(int)n; }
-        p.seg[0] = make_seg(xa, 1, 1, PAD_ZERO, 0, kofs, nullptr);
-        if (one && epi.rowmax_out) p.amax_out_rows = reinterpret_cast<unsigned*>(1);   // request; run_tap allocates
-        p.amax_rows = 1;                           // split16.h row mode: every row scales by its own amax
-        p.w = h->blob + g.w_off;
-        p.bias = g.has_bias ? h->blob + g.b_off : nullptr;
-        p.y = y + r0 * y_pitch;
-        p.y_bs = 0;
-        p.y_rs = y_pitch;
-        p.B = 1;
-        p.M = (int)n;
-        p.N = g.N;
-        p.Ktot = g.Ktot;
-        p.scale = epi.scale;
-        p.res = epi.res ? epi.res + r0 * epi.res_rs : nullptr;
-        p.res_bs = 0;
-        p.res_rs = epi.res_rs;
-        p.gelu = epi.gelu;
-        if (int rc = run_tap(h, st, p)) return rc;
-        if (epi.rowmax_out) *epi.rowmax_out = one ? p.amax_out_rows : nullptr;
-    }
-    return AC_OK;
-}
 
 // ResBlock with identity shortcut: y = x + conv_k1(ELU(conv_k3(ELU(x))))
 int mimi_resblock(ac_handle* h, hipStream_t st, const ResBlockPlan& rb, const Act2& x, float* hbuf, Out out, int B, Act2* y) {
@@ -100,7 +56,7 @@ int mimi_resblock(ac_handle* h, hipStream_t st, const ResBlockPlan& rb, const Ac
     if (rb128_ok(h, rb) && c.residual_kernel_size == 3 && c.compress == 2 && x.raw.ts == 128 && x.raw.bs == bs && aligned16(x.raw.p) &&
         bs * 4 < 0x70000000LL) {
         const unsigned* am = nullptr;
-        int rc = launch_rb128_fused6<false>(h, st, rb, x, out, B, PAD_ZERO, &am);
+        int rc = rb128_identity_fwd(h, st, rb, x, out, B, &am);
         if (rc) return rc;
         HIPCHK(h, hipGetLastError());
         y->raw = Act{out.raw, bs, rb.C, x.raw.L, rb.C, am, B};
@@ -110,8 +66,7 @@ int mimi_resblock(ac_handle* h, hipStream_t st, const ResBlockPlan& rb, const Ac
     if (rb.C == 64 && c.residual_kernel_size == 3 && c.compress == 2 && x.raw.ts == rb.C && x.raw.bs == bs && aligned16(x.raw.p) &&
         (!x.elu.p || (x.elu.ts == rb.C && x.elu.bs == bs && aligned16(x.elu.p)))) {
         const unsigned* am = nullptr;
-        int rc = rb.has6 && !h->gemm_fp32 ? launch_rb_fused6<64, false>(h, st, rb, x, out, B, PAD_ZERO, &am)
-                                          : launch_rb_fused<64, 64, 2, false>(h, st, rb, x, out, B, PAD_ZERO);
+        int rc = rb64_identity_fwd(h, st, rb, x, out, B, &am);
         if (rc) return rc;
         HIPCHK(h, hipGetLastError());
         y->raw = Act{out.raw, bs, rb.C, x.raw.L, rb.C, am, B};
@@ -230,16 +185,8 @@ int mimi_rvq_encode(ac_handle* h, hipStream_t st, const float* proj /*[F][2*Dq]*
         p.K = n;
         p.tK = K;
         p.tk0 = k0;
-        const dim3 grid(cdiv(F, 16)), block(64);
         ProfScope ps(h, st, "rvq_encode_kernel", 2.0 * F * (double)C * Dq * n, (double)F * Dq * 4 + (double)F * n * 8 + (double)n * C * Dq * 4);
-        switch (Dq / 16) {
-            case 1: hipLaunchKernelGGL((rvq_encode_kernel<1, 1, true>), grid, block, 0, st, p); break;
-            case 2: hipLaunchKernelGGL((rvq_encode_kernel<2, 1, true>), grid, block, 0, st, p); break;
-            case 4: hipLaunchKernelGGL((rvq_encode_kernel<4, 1, true>), grid, block, 0, st, p); break;
-            case 8: hipLaunchKernelGGL((rvq_encode_kernel<8, 1, true>), grid, block, 0, st, p); break;
-            case 16: hipLaunchKernelGGL((rvq_encode_kernel<16, 1, true>), grid, block, 0, st, p); break;
-            default: return fail(h, AC_EINVAL, "codebook_dim %d unsupported by the RVQ kernel (need 16*{1,2,4,8,16})", Dq);
-        }
+        if (int rc = rvq_encode_cdist_launch(h, st, p, (unsigned)cdiv(F, 16))) return rc;
         HIPCHK(h, hipGetLastError());
     }
     return AC_OK;
@@ -267,7 +214,7 @@ int mimi_rvq_decode(ac_handle* h, hipStream_t st, const long long* toks, int F, 
         const long long cnt = (long long)F * (Dq / 4);
         p.bad = h->sticky_dev ? h->sticky_dev + ST_BAD_TOKEN : nullptr;
         ProfScope ps(h, st, "rvq_decode_kernel", (double)F * Dq * n, (double)F * n * 8 + (double)F * Dq * 4 * (n + 1));
-        hipLaunchKernelGGL(rvq_decode_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, p);
+        rvq_decode_launch(st, p, (unsigned)((cnt + 255) / 256));
         HIPCHK(h, hipGetLastError());
     }
     // one GEMM over the K-concatenation [q_s | q_a] (only the semantic columns when K <= num_semantic_quantizers)
@@ -596,5 +543,35 @@ int mimi_finalize(ac_handle* h, Packer& pk) {
                         pk.blob[m.cb_packed + (size_t)q * C * Dq + (((size_t)ct * HV + v) * 64 + lane) * 4 + u] =
                             e[(size_t)(ct * 16 + (lane & 15)) * Dq + v * 16 + 4 * (lane >> 4) + u];
     }
+    return AC_OK;
+}
+
+}  // namespace acimpl
+
+extern "C" int ac_mimi_create(const ac_mimi_config* cfg, ac_handle** out) {
+    if (!cfg || !out) return AC_EINVAL;
+    *out = nullptr;
+    if (cfg->struct_size != (int32_t)sizeof(ac_mimi_config)) return AC_EINVAL;
+    const ac_mimi_config& c = *cfg;
+    if (c.num_ratios < 1 || c.num_ratios > AC_MAX_RATIOS || c.num_filters < 1 || c.hidden_size < 16 || c.hidden_size % 16 ||
+        c.hidden_size > 64 * LN_MAXV || c.compress < 1 || c.codebook_size % 32 || c.codebook_size < 32 || c.codebook_dim < 16 ||
+        c.codebook_dim % 16 || c.codebook_dim > 256 || c.num_quantizers < 1 || c.num_semantic_quantizers < 1 ||
+        c.num_semantic_quantizers > c.num_quantizers || c.kernel_size < 1 || c.kernel_size > 8 || c.last_kernel_size < 1 ||
+        c.last_kernel_size > 8 || c.residual_kernel_size < 1 || c.residual_kernel_size > 8 || c.num_hidden_layers < 0 ||
+        c.num_attention_heads < 1 || (c.head_dim != 16 && c.head_dim != 32 && c.head_dim != 64) || c.intermediate_size < 16 ||
+        c.intermediate_size % 4 || c.sliding_window < 1 || c.resample_stride < 1 || c.resample_stride > 4 || !(c.norm_eps > 0.f) ||
+        !(c.rope_theta > 0.f))
+        return AC_EINVAL;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= c.device || c.device < 0) return AC_ENODEV;
+    ac_handle* h = new (std::nothrow) ac_handle();
+    if (!h) return AC_ENOMEM;
+    h->arch = ARCH_MIMI;
+    h->mcfg = c;
+    h->hop = c.resample_stride;
+    for (int i = 0; i < c.num_ratios; ++i) h->hop *= c.upsampling_ratios[i];
+    h->D = c.num_filters << c.num_ratios;
+    h->mimi.D = h->D;
+    *out = h;
     return AC_OK;
 }

@@ -12,19 +12,10 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "tap_gemm.h"
+#include "rvq_types.h"
 
 namespace ac {
 
-struct RvqEncParams {
-    const float* x;      // [F][H] frames (channels-last encoder output), F = B*N
-    const float* epk;    // packed codebooks: [K][C/16 code tiles][H/16 ksteps][64 lanes][4]
-    const float* e;      // plain codebooks [K][C][H] (for the residual update)
-    const float* ee;     // [K][C] squared norms of the code vectors
-    long long* toks;     // [F][tK]: stage k of this launch writes column tk0 + k
-    int F, H, C, K;
-    int xs;              // row pitch of x (floats)
-    int tK, tk0;
-};
 
 // CDIST = false: EnCodec's expanded form above.  CDIST = true: Mimi, [HF] mimi :985-990
 //     idx = argmin(cdist(x, E, p=2))  with cdist's matmul form  sqrt(clamp_min(|x|^2 - 2 x.E^T + |E|^2, 1e-30)):
@@ -151,15 +142,6 @@ __global__ __launch_bounds__(64) void rvq_encode_kernel(const RvqEncParams p) {
     }
 }
 
-struct RvqDecParams {
-    const long long* toks;  // [F][tK]: stage k reads column tk0 + k
-    const float* e;         // [K][C][H] codebooks of the stages summed here
-    float* out;             // [F][H]
-    int F, H, C, K;
-    int tK, tk0;
-    int os;                 // row pitch of out (floats)
-    unsigned* bad;          // sticky counter (host-mapped) raised when an id is outside [0, C); may be null
-};
 
 __global__ __launch_bounds__(256) void rvq_decode_kernel(const RvqDecParams p) {
     const int hv = p.H / 4;

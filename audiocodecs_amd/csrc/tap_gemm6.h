@@ -344,6 +344,44 @@ __global__ __launch_bounds__(64 * WGM * WGN, (tap6_occupancy<WGM, WGN, WMT, WN, 
         }
     }
 
+    // ---- direct epilogue (split16, plain conv outputs): value r of a 32 x 32 accumulator tile is row 8 (r / 4) + 4 kh + r % 4,
+    // column lane & 31 -- for a fixed r the 64 lanes hold two rows x 32 consecutive channels, i.e. two 128-byte segments: stored as
+    // they are with one 4-byte buffer store per value (row offset in the scalar offset, rows past the clip fall outside the
+    // descriptor's range).  No LDS, no barrier: the staged epilogue below cost 24 % of the kernel (profiles/r2_tapgemm_variants.md).
+    if (NP == 2 && p.epi_direct) {
+        const long long yoff = (long long)b * p.y_bs;
+        const int rs4 = (int)p.y_rs * 4, out_bytes = p.M * rs4;
+        const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)(p.y ? p.y + yoff : nullptr), 0, p.y ? out_bytes : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t re = __builtin_amdgcn_make_buffer_rsrc((void*)(p.y_elu ? p.y_elu + yoff : nullptr), 0, p.y_elu ? out_bytes : 0, 0x00020000);
+        const bool full = m0 + BM <= p.M;
+        unsigned omax = 0;
+#pragma unroll
+        for (int c = 0; c < WN; ++c) {
+            const int ng = n0 + (wn * WN + c) * 32 + i32;
+            const float bv = p.bias ? p.bias[ng] : 0.f;
+            const float iv = a_inv * p.winv[ng];
+#pragma unroll
+            for (int a = 0; a < WMT; ++a) {
+                const int mrow = m0 + (wm * WMT + a) * 32 + 4 * kh;
+                const int voff = mrow * rs4 + ng * 4;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int dr = 8 * (r / 4) + (r % 4);
+                    const float v = __fmaf_rn(acc[a][c][r], iv, bv);
+                    if (p.amax_out && (full || mrow + dr < p.M)) amax_acc(omax, v);
+                    if (p.y) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ry, voff, dr * rs4, 0);
+                    if (p.y_elu) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(elu1(v)), re, voff, dr * rs4, 0);
+                }
+            }
+        }
+        if (p.amax_out) amax_flush(omax, amax_at(p.amax_out, b));
+        if (p.clk && tid == 0) {
+            atomicAdd(&p.clk[0], (unsigned long long)(__builtin_amdgcn_s_memtime() - clk_t0));
+            atomicAdd(&p.clk[1], (unsigned long long)(__builtin_amdgcn_s_memrealtime() - clk_r0));
+        }
+        return;
+    }
+
     // ---- epilogue through LDS (as tap_gemm4), one chunk per wave column tile c: [BM][32 * WGN] staged at a time, so the
     // staging tile never exceeds the main loop's LDS (a 128 x 256 tile keeps two workgroups per CU).  C layout of 32x32:
     // column = lane & 31, row = 8*(r/4) + 4*kh + r%4.  Staging column q <-> global column n0 + (q/32)*32*WN + 32*c + q%32.

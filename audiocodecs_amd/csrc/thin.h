@@ -37,7 +37,6 @@ __device__ __forceinline__ int reflect_src(int i, int T, int Lp, int pad) {
 }
 
 constexpr int STEM_TT = 2048;   // time steps per workgroup
-constexpr int THIN_MAXK = 8;
 
 // F must be a multiple of 4 (<= 128): thread = (time step, 4 channels); k <= 8.
 __global__ __launch_bounds__(256) void stem_kernel(const ThinParams p) {

@@ -1,5 +1,5 @@
 // WavTokenizer (BASELINE.json configs[4]): model plan, weight packing and the launch sequence of
-// the decoder.  Included by ac_api.hip inside its anonymous namespace.  PARITY UNPINNED: the reference's backend package is
+// the decoder.  One translation unit of the library (core.h has the map): owns the kernels of wavtok.h and ac_wavtok_create.  PARITY UNPINNED: the reference's backend package is
 // not on disk (oracle/wavtokenizer_oracle.py restates it and cites the wrapper's call sites).
 //
 //   encode (wavtokenizer.py:92-96):  SEANet encoder -- the EnCodec encoder of ac_api.hip with centred (non-causal) reflect
@@ -12,7 +12,10 @@
 //   inverse rFFT x window x overlap-add = ONE 4-tap GEMM: output row m = the `hop` samples [m*hop, (m+1)*hop) of the
 //   overlap-add buffer, tap j = frame m + j - 3, weight[n][j][2c | 2c+1] = (a_c / nfft) * (cos | -sin)(2 pi c pos / nfft) *
 //   window[pos], pos = (3 - j)*hop + n;  the "same" trim of (nfft - hop)/2 samples is the GEMM's output offset.
-#pragma once
+#include "core.h"
+#include "wavtok.h"
+
+namespace acimpl {
 
 // one fp32 vector of the checkpoint -> blob
 bool wt_vec(Packer& pk, const std::string& name, size_t n, size_t& off, size_t row = 0) {
@@ -315,7 +318,7 @@ int wavtok_decoder_fwd(ac_handle* h, hipStream_t st, const float* feats, int B, 
             unsigned bits;
             std::memcpy(&bits, &bound, 4);
             if (B <= h->amax_B) {
-                hipLaunchKernelGGL(amax_fill_kernel, dim3(cdiv(B, 64)), dim3(64), 0, st, slot, bits, B);
+                amax_fill_launch(st, slot, bits, B);
                 ua.amax = slot;
                 ua.amax_n = B;
             }
@@ -356,4 +359,55 @@ Workspace wavtok_plan_ws(const ac_handle* h, int B, int T_in, int N_frames, bool
     w.total_bytes = (NACT * w.act_floats + 2 * w.gin + 2 * w.hseq + w.c) * sizeof(float) + 256;
     add_pool(w, B, (size_t)B * N_frames); // row mode of the backbone's linear layers
     return w;
+}
+
+}  // namespace acimpl
+
+extern "C" int ac_wavtok_create(const ac_wavtok_config* cfg, ac_handle** out) {
+    if (!cfg || !out) return AC_EINVAL;
+    *out = nullptr;
+    if (cfg->struct_size != (int32_t)sizeof(ac_wavtok_config)) return AC_EINVAL;
+    const ac_wavtok_config& c = *cfg;
+    if (c.num_ratios < 1 || c.num_ratios > AC_MAX_RATIOS || c.num_filters < 1 || c.dimension < 16 || c.dimension % 16 || c.dimension > 512 ||
+        c.compress < 1 || c.num_lstm_layers < 1 || c.num_lstm_layers > 2 || c.codebook_size % 32 || c.codebook_size < 32 ||
+        c.kernel_size < 1 || c.kernel_size > 8 || c.last_kernel_size < 1 || c.last_kernel_size > 8 || c.residual_kernel_size < 1 ||
+        c.residual_kernel_size > 8 || (c.backbone_dim != 256 && c.backbone_dim != 768) || c.intermediate_dim < 16 || c.intermediate_dim % 4 ||
+        c.num_layers < 0 || c.adanorm_num_embeddings < 1 || c.bandwidth_id < 0 || c.bandwidth_id >= c.adanorm_num_embeddings ||
+        c.num_groups < GN_GPW || c.num_groups % GN_GPW || c.backbone_dim % c.num_groups || (c.backbone_dim / c.num_groups * GN_GPW) % 4 ||
+        c.backbone_dim / c.num_groups * GN_GPW > 1024 || c.n_fft < 4 || c.n_fft % 2)
+        return AC_EINVAL;
+    int hop = 1;
+    for (int i = 0; i < c.num_ratios; ++i) {
+        if (c.ratios[i] < 1) return AC_EINVAL;
+        hop *= c.ratios[i];
+    }
+    // the inverse STFT is a GEMM over n_fft / hop whole frames per output row; "same" padding trims (n_fft - hop) / 2
+    if (c.n_fft % hop || c.n_fft / hop < 1 || c.n_fft / hop > 8 || hop % 4 || ((c.n_fft - hop) / 2) % 4 || (c.n_fft - hop) % 2) return AC_EINVAL;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= c.device || c.device < 0) return AC_ENODEV;
+    ac_handle* h = new (std::nothrow) ac_handle();
+    if (!h) return AC_ENOMEM;
+    h->arch = ARCH_WAVTOK;
+    h->wcfg = c;
+    h->noncausal = true;
+    // the SEANet encoder is the EnCodec encoder plan with centred padding: describe it in h->cfg
+    ac_config& e = h->cfg;
+    e.struct_size = (int32_t)sizeof(ac_config);
+    e.sampling_rate = c.sampling_rate;
+    e.num_filters = c.num_filters;
+    e.hidden_size = c.dimension;
+    e.num_ratios = c.num_ratios;
+    for (int i = 0; i < c.num_ratios; ++i) e.upsampling_ratios[i] = c.ratios[i];
+    e.kernel_size = c.kernel_size;
+    e.last_kernel_size = c.last_kernel_size;
+    e.residual_kernel_size = c.residual_kernel_size;
+    e.compress = c.compress;
+    e.num_lstm_layers = c.num_lstm_layers;
+    e.codebook_size = c.codebook_size;
+    e.num_quantizers = 1;
+    e.device = c.device;
+    h->hop = hop;
+    h->D = c.num_filters << c.num_ratios;
+    *out = h;
+    return AC_OK;
 }
