@@ -162,6 +162,7 @@ EXPORTS = {
     "ac_profile_end": (_i, [_vp, C.POINTER(AcKernelStat), _i]),
     "ac_debug_clock": (_i, [_vp, _i, C.POINTER(C.c_double)]),
     "ac_debug_bounds": (_i, [_vp, C.POINTER(C.c_float), _i]),
+    "ac_debug_trace": (_i, [_vp, C.POINTER(C.c_ulonglong), _i]),
     "ac_debug_split_row": (_i, [_vp, _i, _vp, _vp]),
     "ac_debug_capture": (_i, [_vp, _vp, _sz]),
     "ac_debug_captured": (_sz, [_vp]),

@@ -540,13 +540,22 @@ int ac_debug_clock(ac_handle* h, int enable, double* shader_mhz) {
         HIPCHK(h, hipMemset(h->clk_dev, 0, sizeof v));
     }
     if (enable && !h->clk_dev) {
-        HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&h->clk_dev), 16));
-        HIPCHK(h, hipMemset(h->clk_dev, 0, 16));
+        HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&h->clk_dev), 16 + 8 * (16 + 8 * 16 * 8)));   // (+ the stage stamps of a T6_TRACE build)
+        HIPCHK(h, hipMemset(h->clk_dev, 0, 16 + 8 * (16 + 8 * 16 * 8)));
     } else if (!enable && h->clk_dev) {
         (void)hipFree(h->clk_dev);
         h->clk_dev = nullptr;
     }
     return AC_OK;
+}
+
+int ac_debug_trace(ac_handle* h, unsigned long long* out, int words) {   // developer (T6_TRACE builds): the stage stamps behind the clock words
+    if (!h || !h->clk_dev || !out || words < 1) return AC_EINVAL;
+    HIPCHK(h, hipDeviceSynchronize());
+    const int n = std::min(words, 16 + 8 * 16 * 8);
+    HIPCHK(h, hipMemcpy(out, h->clk_dev, (size_t)n * 8, hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemset(h->clk_dev + 4, 0, (size_t)(12 + 8 * 16 * 8) * 8));
+    return n;
 }
 
 int ac_debug_capture(ac_handle* h, float* buf_dev, size_t cap_floats) {

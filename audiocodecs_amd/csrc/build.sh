@@ -7,8 +7,8 @@
 # The flag costs the other kernels nothing measurable (19.2 -> 19.5 ms per step, inside the box-to-box spread).
 set -euo pipefail
 here="$(cd "$(dirname "$0")" && pwd)"
-out="$here/../libaudiocodecs_amd.so"
-obj="$here/build"
+out="${AC_OUT:-$here/../libaudiocodecs_amd.so}"     # AC_OUT / AC_OBJ: developer builds beside the product (timing variants)
+obj="${AC_OBJ:-$here/build}"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -fPIC -Wall -Wno-unused-function -I"$here/../../include" "$@")
 mkdir -p "$obj"

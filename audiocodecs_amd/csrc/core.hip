@@ -270,6 +270,10 @@ int run_tap(ac_handle* h, hipStream_t st, TapGemmParams& p) {
     p.amax_rows = 0;
     if (w6) {
         p.clk = h->clk_dev;
+        if (const char* ts = std::getenv("AC_TRACE_SHAPE")) {      // developer (T6_TRACE builds): clock / stamps of ONE layer shape "M,N,K"
+            int tm = 0, tn = 0, tk = 0;
+            if (std::sscanf(ts, "%d,%d,%d", &tm, &tn, &tk) == 3 && !(tm == p.M && tn == p.N && tk == (int)kk)) p.clk = nullptr;
+        }
         auto iv = h->winv_of.find((size_t)(p.w - h->blob));
         // (row mode only on the caller's request -- the linear layers over merged token matrices: a conv that merely happens to
         // run with one clip must scale like the same conv in a batch, or a clip's result would depend on the batch size)
@@ -303,6 +307,7 @@ int run_tap(ac_handle* h, hipStream_t st, TapGemmParams& p) {
             p.epi_direct = !staged_env && !h->gemm_bf16 && !p.gelu && !p.scale && !p.res && !p.tanh_out && !p.alpha && p.y_off == 0 && p.y_len == 0 &&
                            (p.n_valid == 0 || p.n_valid == p.N) && p.N % 128 == 0 && (long long)p.M * p.y_rs * 4 < 0x7fffffffLL && p.y_rs * 4 < (1 << 20);
         }
+        { static const int stag = std::getenv("AC_TAP_STAGGER") ? std::atoi(std::getenv("AC_TAP_STAGGER")) : 0; p.stagger = stag; }
 #define TAP6_LAUNCH(WGM, WGN, WMT, WN, NP)                                                                              \
     do {                                                                                                                \
         if ((rc = ensure_lds(h, reinterpret_cast<const void*>(tap_gemm6_kernel<WGM, WGN, WMT, WN, NP>), Cfg6::lds_for(NP)))) return rc; \

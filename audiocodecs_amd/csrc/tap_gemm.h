@@ -92,6 +92,7 @@ struct TapGemmParams {
     unsigned* amax_out_rows;
     int epi_direct;     // tap_gemm6, split16: the epilogue stores straight from the accumulators (no LDS staging, no barriers): a lane's
                         // 32 x 32 tile column is one output channel, so a 4-byte store instruction covers two rows x 128 contiguous bytes
+    int stagger;        // experiment (AC_TAP_STAGGER cycles): the first resident workgroups start after a pseudo-random share of it
     unsigned long long* clk;   // diagnostics (ac_debug_clock): [0] += shader-clock ticks, [1] += 100 MHz real-time ticks of
                                // every workgroup of a tap_gemm6 launch; null = off
 };

@@ -19,6 +19,7 @@
 #pragma once
 #include "tap_gemm4.h"
 #include "split16.h"
+#include <type_traits>
 
 namespace ac {
 
@@ -73,6 +74,11 @@ __global__ __launch_bounds__(64 * WGM * WGN, (tap6_occupancy<WGM, WGN, WMT, WN, 
     constexpr int BM = Cfg::BM, BN = Cfg::BN, NT = Cfg::NT, A_SLOTS = Cfg::A_SLOTS, PLANE = Cfg::PLANE;
     unsigned long long clk_t0 = 0, clk_r0 = 0;
     if (p.clk) { clk_t0 = __builtin_amdgcn_s_memtime(); clk_r0 = __builtin_amdgcn_s_memrealtime(); }
+    if (p.stagger && (int)blockIdx.x < 256 * tap6_occupancy<WGM, WGN, WMT, WN, NP>()) {
+        const unsigned long long wait = (unsigned long long)((blockIdx.x * 0x9E3779B1u) >> 24) * (unsigned)p.stagger >> 8;
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        while (__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(32);
+    }
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __bf16* As0 = reinterpret_cast<__bf16*>(smem);            // [2 buffers][NPL planes][A_ROWS][T6_PITCH]
     constexpr int NPL = NP == 2 ? 2 : 3;
@@ -91,6 +97,12 @@ __global__ __launch_bounds__(64 * WGM * WGN, (tap6_occupancy<WGM, WGN, WMT, WN, 
     const int mt = id % p.mtiles;
     const int b = id / p.mtiles;
     const int m0 = mt * BM, n0 = nt * BN;
+#ifdef T6_TRACE   // developer build: phase stamps of wave 1 of one workgroup (p.clk[4..15]), stage stamps below
+    const bool t6_ph = p.clk && blockIdx.x == gridDim.x / 2 + 1 && tid == 64;
+#define T6_PHASE(k) do { if (t6_ph) p.clk[4 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+    if (t6_ph) p.clk[4] = clk_t0;
+    T6_PHASE(1);
+#endif
 
     f32x16 acc[WMT][WN];
 #pragma unroll
@@ -171,16 +183,22 @@ __global__ __launch_bounds__(64 * WGM * WGN, (tap6_occupancy<WGM, WGN, WMT, WN, 
         }
     }
     f32x4 ra[A_SLOTS];
-    auto load_a = [&](int s_, int c_, int j_) {
-        if (seg_interior) {
-            const int soff = c_ * 4 + (seg_reload ? j_ * seg_tapoff : 0);
+    // Exactly A_SLOTS buffer loads, whatever the stage needs (see `stage` below for why the COUNT must not depend on the path):
+    //   interior tile : the per-slot offsets of enter_segment + one scalar offset for the chunk / tap
+    //   clip-edge tile: per-slot offsets from the padding rule (src_index); rows the rule zero-fills aim past the last record
+    //   `live` false  : the stage stays on its chunk -- every slot aims past the last record
+    // (a buffer load past num_records returns zeros without touching memory; the range check sees the VGPR offset only)
+    constexpr int A_OOB = 0x7fff0000;
+    auto load_a = [&](int s_, int c_, int j_, bool live) {
+        int voff[A_SLOTS], soff = 0;
+        if (seg_interior || !live) {
+            soff = live ? c_ * 4 + (seg_reload ? j_ * seg_tapoff : 0) : 0;
 #pragma unroll
-            for (int i = 0; i < A_SLOTS; ++i) ra[i] = bufload16(a_rs, a_boff[i], soff);
+            for (int i = 0; i < A_SLOTS; ++i) voff[i] = live ? a_boff[i] : A_OOB;
         } else {
             const TapSeg& sg = p.seg[s_];
             const int R = seg_reload ? BM : BM + sg.J - 1;
             const int jr = seg_reload ? j_ * sg.dil : 0;
-            const float* xb = sg.x + (long long)b * sg.bs;
 #pragma unroll
             for (int i = 0; i < A_SLOTS; ++i) {
                 const int e = tid + i * NT;
@@ -188,10 +206,11 @@ __global__ __launch_bounds__(64 * WGM * WGN, (tap6_occupancy<WGM, WGN, WMT, WN, 
                 const int c = c_ + 4 * q;
                 const int tp = sg.cin_shift >= 0 ? (c >> sg.cin_shift) : (c / sg.cin);
                 const long long jj = row < R ? src_index(sg, (m0 + row + jr) * sg.s + tp - sg.pad) : -1;
-                ra[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (jj >= 0) ra[i] = *reinterpret_cast<const f32x4*>(xb + jj * sg.ts + (c - tp * sg.cin));
+                voff[i] = jj < 0 ? A_OOB : (int)((jj * sg.ts + (c - tp * sg.cin)) * 4);
             }
         }
+#pragma unroll
+        for (int i = 0; i < A_SLOTS; ++i) ra[i] = bufload16(a_rs, voff[i], soff);
     };
     // split 4 fp32 into the three bf16 planes (exact: v = hi + mid + lo) and store them
     auto store_a = [&](__bf16* dst) {
@@ -241,14 +260,26 @@ __global__ __launch_bounds__(64 * WGM * WGN, (tap6_occupancy<WGM, WGN, WMT, WN, 
     };
 
     // ---- prologue
+#ifdef T6_TRACE
+    T6_PHASE(2);
+#endif
     enter_segment(0);
-    load_a(0, 0, 0);
+#ifdef T6_TRACE
+    T6_PHASE(3);
+#endif
+    load_a(0, 0, 0, true);
     // three rotating B register sets: a stage uses (U0, U1) for its two k-steps and loads the NEXT stage's k-steps
     // into (S, U0) -- each load is issued two k-steps before its use (one k-step is shorter than an L2 round trip)
     bf16x8 bx[3][WN], by[3][WN], bz[3][WN];
     load_b(seg_kofs >> 4, bx);
     load_b((seg_kofs >> 4) + 1, by);
+#ifdef T6_TRACE
+    T6_PHASE(4);
+#endif
     store_a(As0);
+#ifdef T6_TRACE
+    T6_PHASE(5);
+#endif
     __syncthreads();
     int abuf = 0;
     const int a_frag = (wm * WMT * 32 + i32) * T6_PITCH + 8 * kh;    // + (a*32 + j)*T6_PITCH + ks*16, + plane*PLANE
@@ -284,12 +315,28 @@ __global__ __launch_bounds__(64 * WGM * WGN, (tap6_occupancy<WGM, WGN, WMT, WN, 
                 acc[a][c] = v;
             }
     };
+#ifdef T6_TRACE
+    int t6_stage = 0;
+    const bool t6_on = p.clk && blockIdx.x == gridDim.x / 2 + 1 && lane == 0 && t6_stage < 16;
+#define T6_STAMP(k) do { if (t6_on && t6_stage < 16) p.clk[16 + (wave * 16 + t6_stage) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#endif
     // LEAN (wave tile of 6-8 accumulator tiles: 128 x 64, 64 x 96): 96-128 accumulator registers leave room for ONE fragment set and TWO
     // weight sets only -- a weight set is reloaded right after the k-step that used it (one k-step ahead of its next use), the
     // A fragments of a k-step are read just before its MFMAs (the co-resident workgroup covers the LDS latency).
     constexpr bool LEAN = WMT * WN >= 6 || (WGM == 1 && tap6_occupancy<WGM, WGN, WMT, WN, NP>() == 3);
-    // one stage; returns true when it was the last one
+    // one stage; returns true when it was the last one.
+    // EVERY stage issues the same loads in the same order -- A_SLOTS activation loads, then a weight set after each k-step --
+    // whether or not it needs them: a stage that stays on its A chunk points the activation loads past the end of the buffer
+    // resource (they return zeros without touching memory, into registers nobody reads), the last stage reloads k-step 0.
+    // The reason is s_waitcnt: vmcnt counts loads in issue order, so "wait for this k-step's weights but not for the younger
+    // loads" can only be encoded when the number of younger loads is the same on every path into the wait.  With `if
+    // (new_chunk)` / `if (has_next)` around the loads the compiler has to assume the fewest, and round 2's kernel waited for the
+    // weight set it had JUST requested before every second k-step (vmcnt(0): one exposed L2 round trip per stage) and for the
+    // first activation load before the first MFMA of every new-chunk stage (profiles/r3_tapgemm_trace.md: s_memtime stamps + ISA).
     auto stage = [&](bf16x8 (&u0)[3][WN], bf16x8 (&u1)[3][WN], bf16x8 (&sp)[3][WN]) -> bool {
+#ifdef T6_TRACE
+        T6_STAMP(6);
+#endif
         int nsi = si, nc0 = c0, nj = j + 1;
         bool new_chunk = false;
         if (nj == seg_J) {
@@ -305,35 +352,70 @@ __global__ __launch_bounds__(64 * WGM * WGN, (tap6_occupancy<WGM, WGN, WMT, WN, 
             if (nsi != si) enter_segment(nsi);
             new_chunk = new_chunk || seg_reload;
             s_next = (seg_kofs + nj * seg_Cw + nc0) >> 4;      // first k-step of the next stage in the packed weight rows
-            if (!LEAN) load_b(s_next, sp);
-            if (new_chunk) load_a(nsi, nc0, nj);
+        } else {
+            new_chunk = false;
         }
+        // (sched_barrier: with every load unconditional a stage is one basic block, and the scheduler would sink the loads to
+        //  their first use -- the fences keep them where the latency plan needs them)
+        load_a(nsi, nc0, nj, new_chunk);
+        if (!LEAN) load_b(s_next, sp);
+        __builtin_amdgcn_sched_barrier(0);
         const __bf16* Ac = As0 + abuf * NPL * PLANE + a_frag + cur_j * T6_PITCH;
+#ifdef T6_TRACE   // developer build: s_memtime stamps of one workgroup's stages (tools/experiments/r3o_trace.py)
+        if (t6_on && t6_stage < 16) p.clk[16 + (wave * 16 + t6_stage) * 8 + 7] = (seg_interior ? 1 : 0) | (new_chunk ? 2 : 0) | (mt << 8);
+        T6_STAMP(0);
+#endif
         if constexpr (LEAN) {
             bf16x8 af[3][WMT];
             read_a(Ac, 0, af);
             mfma_step(af, u0);
-            if (has_next) load_b(s_next, u0);
+#ifdef T6_TRACE
+            T6_STAMP(1);
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+            load_b(s_next, u0);
+            __builtin_amdgcn_sched_barrier(0);
             read_a(Ac, 1, af);
             mfma_step(af, u1);
-            if (has_next) load_b(s_next + 1, u1);
+#ifdef T6_TRACE
+            T6_STAMP(2);
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+            load_b(s_next + 1, u1);
+            __builtin_amdgcn_sched_barrier(0);
         } else {
             bf16x8 af0[3][WMT], af1[3][WMT];
             read_a(Ac, 0, af0);
             read_a(Ac, 1, af1);                                // the second k-step's fragments travel under the first one's MFMAs
             mfma_step(af0, u0);
-            if (has_next) load_b(s_next + 1, u0);
+            __builtin_amdgcn_sched_barrier(0);
+            load_b(s_next + 1, u0);
+            __builtin_amdgcn_sched_barrier(0);
             mfma_step(af1, u1);
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (!has_next) return true;
+#ifdef T6_TRACE
+        T6_STAMP(3);
+#endif
         if (new_chunk) {                                       // the A loads had the whole stage to arrive
             abuf ^= 1;
             store_a(As0 + abuf * NPL * PLANE);
         }
+#ifdef T6_TRACE
+        T6_STAMP(4);
+#endif
         __syncthreads();
+#ifdef T6_TRACE
+        T6_STAMP(5);
+        ++t6_stage;
+#endif
         si = nsi; c0 = nc0; j = nj;
         return false;
     };
+#ifdef T6_TRACE
+    T6_PHASE(6);
+#endif
     if constexpr (LEAN) {
         while (!stage(bx, by, bz)) {}
     } else {
@@ -344,6 +426,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, (tap6_occupancy<WGM, WGN, WMT, WN, 
         }
     }
 
+#ifdef T6_TRACE
+    T6_PHASE(7);
+#endif
     // ---- direct epilogue (split16, plain conv outputs): value r of a 32 x 32 accumulator tile is row 8 (r / 4) + 4 kh + r % 4,
     // column lane & 31 -- for a fixed r the 64 lanes hold two rows x 32 consecutive channels, i.e. two 128-byte segments: stored as
     // they are with one 4-byte buffer store per value (row offset in the scalar offset, rows past the clip fall outside the
@@ -351,30 +436,53 @@ __global__ __launch_bounds__(64 * WGM * WGN, (tap6_occupancy<WGM, WGN, WMT, WN, 
     if (NP == 2 && p.epi_direct) {
         const long long yoff = (long long)b * p.y_bs;
         const int rs4 = (int)p.y_rs * 4, out_bytes = p.M * rs4;
+        // a null output is a descriptor of zero records: its stores fall outside the range check and are dropped
         const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)(p.y ? p.y + yoff : nullptr), 0, p.y ? out_bytes : 0, 0x00020000);
         const __amdgpu_buffer_rsrc_t re = __builtin_amdgcn_make_buffer_rsrc((void*)(p.y_elu ? p.y_elu + yoff : nullptr), 0, p.y_elu ? out_bytes : 0, 0x00020000);
-        const bool full = m0 + BM <= p.M;
         unsigned omax = 0;
+        // The value loop exists in four copies -- (with / without the activated flavour) x (tile inside the clip / last tile) --
+        // chosen ONCE: with the three conditions tested per value the compiler emitted four scalar branches around every store and
+        // the epilogue took ~170 cycles per value (23 k cycles of a 63 k-cycle tile of the up-sampling layers;
+        // profiles/r3_tapgemm_trace.md); inside a copy a value is fma, 3 amax instructions, store.
+        auto values = [&](auto has_elu, auto is_full) {
+            constexpr bool HAS_E = decltype(has_elu)::value, FULL = decltype(is_full)::value;
 #pragma unroll
-        for (int c = 0; c < WN; ++c) {
-            const int ng = n0 + (wn * WN + c) * 32 + i32;
-            const float bv = p.bias ? p.bias[ng] : 0.f;
-            const float iv = a_inv * p.winv[ng];
+            for (int c = 0; c < WN; ++c) {
+                const int ng = n0 + (wn * WN + c) * 32 + i32;
+                const float bv = p.bias ? p.bias[ng] : 0.f;
+                const float iv = a_inv * p.winv[ng];
+#ifdef T6_TRACE
+                if (c == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); T6_PHASE(8); }
+                if (c == 1) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); T6_PHASE(10); }
+#endif
 #pragma unroll
-            for (int a = 0; a < WMT; ++a) {
-                const int mrow = m0 + (wm * WMT + a) * 32 + 4 * kh;
-                const int voff = mrow * rs4 + ng * 4;
+                for (int a = 0; a < WMT; ++a) {
+                    const int mrow = m0 + (wm * WMT + a) * 32 + 4 * kh;
+                    const int voff = mrow * rs4 + ng * 4;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int dr = 8 * (r / 4) + (r % 4);
-                    const float v = __fmaf_rn(acc[a][c][r], iv, bv);
-                    if (p.amax_out && (full || mrow + dr < p.M)) amax_acc(omax, v);
-                    if (p.y) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ry, voff, dr * rs4, 0);
-                    if (p.y_elu) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(elu1(v)), re, voff, dr * rs4, 0);
+                    for (int r = 0; r < 16; ++r) {
+                        const int dr = 8 * (r / 4) + (r % 4);
+                        const float v = __fmaf_rn(acc[a][c][r], iv, bv);
+                        if (FULL || mrow + dr < p.M) amax_acc(omax, v);      // (ELU never exceeds |v|)
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ry, voff, dr * rs4, 0);
+                        if (HAS_E) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(elu1(v)), re, voff, dr * rs4, 0);
+                    }
                 }
             }
+        };
+        const bool full = m0 + BM <= p.M;
+        if (p.y_elu) {
+            if (full) values(std::true_type{}, std::true_type{}); else values(std::true_type{}, std::false_type{});
+        } else {
+            if (full) values(std::false_type{}, std::true_type{}); else values(std::false_type{}, std::false_type{});
         }
+#ifdef T6_TRACE
+        T6_PHASE(11);
+#endif
         if (p.amax_out) amax_flush(omax, amax_at(p.amax_out, b));
+#ifdef T6_TRACE
+        T6_PHASE(9);
+#endif
         if (p.clk && tid == 0) {
             atomicAdd(&p.clk[0], (unsigned long long)(__builtin_amdgcn_s_memtime() - clk_t0));
             atomicAdd(&p.clk[1], (unsigned long long)(__builtin_amdgcn_s_memrealtime() - clk_r0));

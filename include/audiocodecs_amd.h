@@ -342,6 +342,9 @@ int ac_debug_bounds(const ac_handle* h, float* out, int cap);
  * enable != 0 arms the sampling for the following calls, 0 disarms it.  The matrix pipe on this chip is power-capped: the
  * clock under a GEMM is the missing half of its roofline. */
 int ac_debug_clock(ac_handle* h, int enable, double* shader_mhz);
+/* Developer builds only (-DT6_TRACE, tools/experiments/r3o_trace.py): copies the s_memtime stage stamps one tap_gemm6 workgroup
+ * left behind the clock words (ac_debug_clock must be enabled); returns the number of 64-bit words written.  SYNCHRONISES. */
+int ac_debug_trace(ac_handle* h, unsigned long long* out, int words);
 
 /* Test hook (no GPU): the host-side packer's split of ONE weight row in split16 arithmetic (csrc/split16.h): the row's scale
  * exponent s (|w| 2^s < 2^15, chosen from the row's largest magnitude), and per element the fp16 bit patterns of
