@@ -98,7 +98,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (tap6_occupancy<WGM, WGN, WMT, WN, 
     const int b = id / p.mtiles;
     const int m0 = mt * BM, n0 = nt * BN;
 #ifdef T6_TRACE   // developer build: phase stamps of wave 1 of one workgroup (p.clk[4..15]), stage stamps below
-    const bool t6_ph = p.clk && blockIdx.x == gridDim.x / 2 + 1 && tid == 64;
+    const bool t6_ph = p.clk && mt == p.mtiles / 2 && nt == 0 && b == p.B / 2 && tid == 64;      // an interior tile
 #define T6_PHASE(k) do { if (t6_ph) p.clk[4 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
     if (t6_ph) p.clk[4] = clk_t0;
     T6_PHASE(1);
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (tap6_occupancy<WGM, WGN, WMT, WN, 
     };
 #ifdef T6_TRACE
     int t6_stage = 0;
-    const bool t6_on = p.clk && blockIdx.x == gridDim.x / 2 + 1 && lane == 0 && t6_stage < 16;
+    const bool t6_on = p.clk && mt == p.mtiles / 2 && nt == 0 && b == p.B / 2 && lane == 0 && t6_stage < 16;
 #define T6_STAMP(k) do { if (t6_on && t6_stage < 16) p.clk[16 + (wave * 16 + t6_stage) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 #endif
     // LEAN (wave tile of 6-8 accumulator tiles: 128 x 64, 64 x 96): 96-128 accumulator registers leave room for ONE fragment set and TWO
@@ -398,6 +398,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, (tap6_occupancy<WGM, WGN, WMT, WN, 
 #ifdef T6_TRACE
         T6_STAMP(3);
 #endif
+        // One barrier per CHUNK, not per stage: a slab is written only here, after the barrier that ended the chunk which last
+        // read it, and read only after the barrier that follows these writes -- the taps of one chunk need no barrier between them.
         if (new_chunk) {                                       // the A loads had the whole stage to arrive
             abuf ^= 1;
             store_a(As0 + abuf * NPL * PLANE);
@@ -405,7 +407,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (tap6_occupancy<WGM, WGN, WMT, WN, 
 #ifdef T6_TRACE
         T6_STAMP(4);
 #endif
-        __syncthreads();
+        if (new_chunk) __syncthreads();
 #ifdef T6_TRACE
         T6_STAMP(5);
         ++t6_stage;
