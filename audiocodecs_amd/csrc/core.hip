@@ -272,7 +272,7 @@ int run_tap(ac_handle* h, hipStream_t st, TapGemmParams& p) {
         p.clk = h->clk_dev;
         if (const char* ts = std::getenv("AC_TRACE_SHAPE")) {      // developer (T6_TRACE builds): clock / stamps of ONE layer shape "M,N,K"
             int tm = 0, tn = 0, tk = 0;
-            if (std::sscanf(ts, "%d,%d,%d", &tm, &tn, &tk) == 3 && !(tm == p.M && tn == p.N && tk == (int)kk)) p.clk = nullptr;
+            if (std::sscanf(ts, "%d,%d,%d", &tm, &tn, &tk) == 3 && !((tm == 0 || tm == p.M) && tn == p.N && tk == (int)kk)) p.clk = nullptr;   // (M = 0: any M)
         }
         auto iv = h->winv_of.find((size_t)(p.w - h->blob));
         // (row mode only on the caller's request -- the linear layers over merged token matrices: a conv that merely happens to
@@ -304,8 +304,11 @@ int run_tap(ac_handle* h, hipStream_t st, TapGemmParams& p) {
             p.amax_out = amax_new(h);
             // plain conv outputs store straight from the accumulators (tap_gemm6.h); AC_TAP_EPI=staged: the LDS-staged epilogue
             static const bool staged_env = std::getenv("AC_TAP_EPI") && std::strcmp(std::getenv("AC_TAP_EPI"), "staged") == 0;
-            p.epi_direct = !staged_env && !h->gemm_bf16 && !p.gelu && !p.scale && !p.res && !p.tanh_out && !p.alpha && p.y_off == 0 && p.y_len == 0 &&
-                           (p.n_valid == 0 || p.n_valid == p.N) && p.N % 128 == 0 && (long long)p.M * p.y_rs * 4 < 0x7fffffffLL && p.y_rs * 4 < (1 << 20);
+            // (ELU flavour without a residual, Snake flavour with or without one: the combinations the four codecs produce)
+            p.epi_direct = !staged_env && !h->gemm_bf16 && !p.gelu && !p.scale && !p.tanh_out && p.y_off == 0 && p.y_len == 0 &&
+                           (!p.res || (p.alpha && (long long)p.M * p.res_rs * 4 < 0x7fffffffLL && p.res_rs * 4 < (1 << 20))) && (!p.alpha || p.y_elu) &&
+                           (p.n_valid == 0 || p.n_valid == p.N) && (p.alpha ? p.N < 128 && p.N % 32 == 0 : p.N % 128 == 0) &&      // (measured: Snake / residual layers of 128+ channels are faster through the LDS-staged 16-byte rows)
+                           (long long)p.M * p.y_rs * 4 < 0x7fffffffLL && p.y_rs * 4 < (1 << 20);
         }
         { static const int stag = std::getenv("AC_TAP_STAGGER") ? std::atoi(std::getenv("AC_TAP_STAGGER")) : 0; p.stagger = stag; }
 #define TAP6_LAUNCH(WGM, WGN, WMT, WN, NP)                                                                              \

@@ -441,18 +441,36 @@ __global__ __launch_bounds__(64 * WGM * WGN, (tap6_occupancy<WGM, WGN, WMT, WN, 
         // a null output is a descriptor of zero records: its stores fall outside the range check and are dropped
         const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)(p.y ? p.y + yoff : nullptr), 0, p.y ? out_bytes : 0, 0x00020000);
         const __amdgpu_buffer_rsrc_t re = __builtin_amdgcn_make_buffer_rsrc((void*)(p.y_elu ? p.y_elu + yoff : nullptr), 0, p.y_elu ? out_bytes : 0, 0x00020000);
+        // residual operand (DAC residual units): the same two-rows-x-128-bytes pattern as the stores, one 4-byte load per value
+        const int rr4 = (int)p.res_rs * 4;
+        const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)(p.res ? p.res + (long long)b * p.res_bs : nullptr), 0, p.res ? p.M * rr4 : 0, 0x00020000);
         unsigned omax = 0;
-        // The value loop exists in four copies -- (with / without the activated flavour) x (tile inside the clip / last tile) --
-        // chosen ONCE: with the three conditions tested per value the compiler emitted four scalar branches around every store and
-        // the epilogue took ~170 cycles per value (23 k cycles of a 63 k-cycle tile of the up-sampling layers;
-        // profiles/r3_tapgemm_trace.md); inside a copy a value is fma, 3 amax instructions, store.
-        auto values = [&](auto has_elu, auto is_full) {
-            constexpr bool HAS_E = decltype(has_elu)::value, FULL = decltype(is_full)::value;
+        // The value loop exists in straight-line copies -- activated flavour (none / ELU / Snake) x residual x (tile inside the
+        // clip / last tile) -- chosen ONCE: with the conditions tested per value the compiler emitted four scalar branches around
+        // every store and the epilogue took ~170 cycles per value (23 k cycles of a 63 k-cycle tile of EnCodec's up-sampling layers;
+        // the LDS-staged epilogue of a DAC 1 x 1 conv, residual loads waited for one by one: 48 k of 67 k cycles;
+        // profiles/r3_tapgemm_trace.md).  Inside a copy a value is fma, (residual add), amax, store, (activation, amax, store);
+        // the residual values of the NEXT 32 x 32 tile are requested before the current tile is worked on.
+        auto values = [&](auto act_tag, auto res_tag, auto is_full) {
+            constexpr int ACT = decltype(act_tag)::value;             // 0: raw only, 1: + ELU flavour, 2: + Snake flavour
+            constexpr bool RES = decltype(res_tag)::value, FULL = decltype(is_full)::value;
+            float rv[2][16];
+            auto res_load = [&](int c, int a, float (&dst)[16]) {
+                const int ng = n0 + (wn * WN + c) * 32 + i32;
+                const int mrow = m0 + (wm * WMT + a) * 32 + 4 * kh;
+                const int voff = mrow * rr4 + ng * 4;
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    dst[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rr, voff, (8 * (r / 4) + (r % 4)) * rr4, 0));
+            };
+            if (RES) res_load(0, 0, rv[0]);
 #pragma unroll
             for (int c = 0; c < WN; ++c) {
                 const int ng = n0 + (wn * WN + c) * 32 + i32;
                 const float bv = p.bias ? p.bias[ng] : 0.f;
                 const float iv = a_inv * p.winv[ng];
+                float al = 0.f, ai = 0.f;
+                if (ACT == 2) { const int ca = ng % p.alpha_n; al = p.alpha[ca]; ai = p.alpha_inv[ca]; }
 #ifdef T6_TRACE
                 if (c == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); T6_PHASE(8); }
                 if (c == 1) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); T6_PHASE(10); }
@@ -461,23 +479,37 @@ __global__ __launch_bounds__(64 * WGM * WGN, (tap6_occupancy<WGM, WGN, WMT, WN, 
                 for (int a = 0; a < WMT; ++a) {
                     const int mrow = m0 + (wm * WMT + a) * 32 + 4 * kh;
                     const int voff = mrow * rs4 + ng * 4;
+                    const int cur = (c * WMT + a) & 1;
+                    if (RES && c * WMT + a + 1 < WN * WMT) res_load((c * WMT + a + 1) / WMT, (c * WMT + a + 1) % WMT, rv[cur ^ 1]);
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int dr = 8 * (r / 4) + (r % 4);
-                        const float v = __fmaf_rn(acc[a][c][r], iv, bv);
-                        if (FULL || mrow + dr < p.M) amax_acc(omax, v);      // (ELU never exceeds |v|)
+                        float v = __fmaf_rn(acc[a][c][r], iv, bv);
+                        if (RES) v = __fadd_rn(rv[cur][r], v);
+                        const bool in = FULL || mrow + dr < p.M;
+                        if (in) amax_acc(omax, v);
                         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ry, voff, dr * rs4, 0);
-                        if (HAS_E) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(elu1(v)), re, voff, dr * rs4, 0);
+                        if (ACT == 1) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(elu1(v)), re, voff, dr * rs4, 0);   // (ELU never exceeds |v|)
+                        if (ACT == 2) {
+                            const float w = snake1(v, al, ai);
+                            if (in) amax_acc(omax, w);                                                                        // (Snake can)
+                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(w), re, voff, dr * rs4, 0);
+                        }
                     }
                 }
             }
         };
         const bool full = m0 + BM <= p.M;
-        if (p.y_elu) {
-            if (full) values(std::true_type{}, std::true_type{}); else values(std::true_type{}, std::false_type{});
+#define T6_VALUES(ACT, RES) do { if (full) values(std::integral_constant<int, ACT>{}, std::integral_constant<bool, RES>{}, std::true_type{}); \
+                                 else values(std::integral_constant<int, ACT>{}, std::integral_constant<bool, RES>{}, std::false_type{}); } while (0)
+        if (BN < 128 && p.alpha) {          // (Snake layers of 128+ channels go through the staged epilogue: run_tap)
+            if constexpr (BN < 128) { if (p.res) T6_VALUES(2, true); else T6_VALUES(2, false); }
+        } else if (p.y_elu) {
+            T6_VALUES(1, false);
         } else {
-            if (full) values(std::false_type{}, std::true_type{}); else values(std::false_type{}, std::false_type{});
+            T6_VALUES(0, false);
         }
+#undef T6_VALUES
 #ifdef T6_TRACE
         T6_PHASE(11);
 #endif
@@ -502,10 +534,23 @@ __global__ __launch_bounds__(64 * WGM * WGN, (tap6_occupancy<WGM, WGN, WMT, WN, 
     const int nvalid = p.n_valid ? p.n_valid : p.N;
     unsigned omax = 0;
     constexpr int EH = Cfg::EH, ER = 32 * WGM * EH;       // 32-row tiles / rows staged per pass
+    const bool fastpass = NP == 2 && !rowmode && !p.amax_out_rows && !p.gelu && !p.scale && !p.tanh_out && p.y_len == 0 && p.y_off == 0 && nvalid == p.N &&
+                          m0 + BM <= p.M && n0 + BN <= p.N && (ER * (CW / 4)) % NT == 0;
 #pragma unroll
     for (int c = 0; c < WN; ++c)
 #pragma unroll
     for (int a0 = 0; a0 < WMT; a0 += EH) {
+        // the residual rows of this pass are requested BEFORE the pass is staged: they arrive under the barriers and LDS writes
+        // (the store loop used to wait for each of them in turn: 48 k of the 67 k cycles of a DAC 1 x 1 tile, profiles/r3_tapgemm_trace.md)
+        constexpr int EITER = (ER * (CW / 4)) / NT;
+        auto res_at = [&](int i) -> f32x4 {
+            const int e = tid + i * NT;
+            const int row = e / (CW / 4), q = e % (CW / 4);
+            const int m = m0 + (row / (32 * EH)) * (32 * WMT) + a0 * 32 + row % (32 * EH), n = n0 + (q / 8) * (32 * WN) + 32 * c + 4 * (q % 8);
+            return *reinterpret_cast<const f32x4*>(p.res + (long long)b * p.res_bs + (long long)m * p.res_rs + n);
+        };
+        f32x4 rn1 = f32x4{0.f, 0.f, 0.f, 0.f}, rn2 = rn1;              // the residual rows two iterations ahead of the store loop
+        if (fastpass && p.res) { rn1 = res_at(0); if (EITER > 1) rn2 = res_at(1); }
         __syncthreads();
 #pragma unroll
         for (int a = a0; a < a0 + EH; ++a) {
@@ -518,6 +563,37 @@ __global__ __launch_bounds__(64 * WGM * WGN, (tap6_occupancy<WGM, WGN, WMT, WN, 
                 Cs[((wm * EH + a - a0) * 32 + 8 * (r / 4) + 4 * kh + (r % 4)) * CP + wn * 32 + i32] = NP == 2 ? __fmaf_rn(acc[a][c][r], iv, bq) : acc[a][c][r] + bv;
         }
         __syncthreads();
+        if (fastpass) {
+            // the common full-tile case (plain / residual / Snake / ELU outputs of a conv): no bounds, no row words, the residual rows
+            // requested two iterations ahead
+            for (int i = 0; i < EITER; ++i) {
+                const int e = tid + i * NT;
+                const int row = e / (CW / 4), q = e % (CW / 4);
+                const int m = m0 + (row / (32 * EH)) * (32 * WMT) + a0 * 32 + row % (32 * EH), n = n0 + (q / 8) * (32 * WN) + 32 * c + 4 * (q % 8);
+                const long long o = yoff + (long long)m * p.y_rs + n;
+                f32x4 v = *reinterpret_cast<const f32x4*>(&Cs[row * CP + 4 * q]);
+                if (p.res) {
+                    const f32x4 rv = rn1;
+                    rn1 = rn2;
+                    if (i + 2 < EITER) rn2 = res_at(i + 2);
+                    v.x = __fadd_rn(rv.x, v.x); v.y = __fadd_rn(rv.y, v.y); v.z = __fadd_rn(rv.z, v.z); v.w = __fadd_rn(rv.w, v.w);
+                }
+                if (p.amax_out) amax_acc4(omax, v);
+                if (p.y) *reinterpret_cast<f32x4*>(p.y + o) = v;
+                if (p.y_elu) {
+                    f32x4 w;
+                    if (p.alpha) {
+                        const int ca = n % p.alpha_n;
+                        const f32x4 al = *reinterpret_cast<const f32x4*>(p.alpha + ca), ai = *reinterpret_cast<const f32x4*>(p.alpha_inv + ca);
+                        w.x = snake1(v.x, al.x, ai.x); w.y = snake1(v.y, al.y, ai.y); w.z = snake1(v.z, al.z, ai.z); w.w = snake1(v.w, al.w, ai.w);
+                        if (p.amax_out) amax_acc4(omax, w);
+                    } else {
+                        w = elu4(v);
+                    }
+                    *reinterpret_cast<f32x4*>(p.y_elu + o) = w;
+                }
+            }
+        } else
         for (int e = tid; e < ER * (CW / 4); e += NT) {
             const int row = e / (CW / 4), q = e % (CW / 4);
             // staged row -> row of the workgroup tile: wave row group row / (32 EH), then the pass's EH tiles
@@ -570,7 +646,13 @@ __global__ __launch_bounds__(64 * WGM * WGN, (tap6_occupancy<WGM, WGN, WMT, WN, 
             }
         }
     }
+#ifdef T6_TRACE
+    T6_PHASE(11);
+#endif
     if (p.amax_out) amax_flush(omax, amax_at(p.amax_out, b));
+#ifdef T6_TRACE
+    T6_PHASE(9);
+#endif
     if (p.clk && tid == 0) {   // shader clock while this workgroup lived: sum of ticks / sum of 100 MHz real-time ticks
         atomicAdd(&p.clk[0], (unsigned long long)(__builtin_amdgcn_s_memtime() - clk_t0));
         atomicAdd(&p.clk[1], (unsigned long long)(__builtin_amdgcn_s_memrealtime() - clk_r0));
