@@ -250,7 +250,7 @@ int run_tap(ac_handle* h, hipStream_t st, TapGemmParams& p) {
     int rc = AC_OK;
     char shape[64] = "";
     if (h->prof && h->prof_detail)
-        std::snprintf(shape, sizeof shape, " B%d M%d N%d K%d J%d s%d", p.B, p.M, p.N, (int)kk, p.seg[0].J, p.seg[0].s);
+        std::snprintf(shape, sizeof shape, " B%d M%d N%d K%d J%d s%d%s", p.B, p.M, p.N, (int)kk, p.seg[0].J, p.seg[0].s, p.seg[0].dil == 1 ? "" : p.seg[0].dil == 3 ? " d3" : " d9");
 #define TAP_CASE(WGM, WGN, WM, WN)                                                                          \
     do {                                                                                                    \
         if (fast) {                                                                                         \

@@ -50,6 +50,14 @@ struct LstmLaunchParams {
 // error ~1e-7, the same class as the reference's vectorised CPU kernels; they sit on the critical path
 // of every one of the 1504 dependent launches.
 __device__ __forceinline__ float sigmoidf_(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+// the same two functions with v_rcp_f32 (1 ulp) in place of the correctly rounded reciprocal (an 11-instruction dependent
+// sequence, five of them per gate thread and time step): lstm_persist16.h, whose time step IS this dependency chain
+__device__ __forceinline__ float sigmoid_rcp(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanh_rcp(float x) {
+    const float a = fminf(fabsf(x), 15.0f);
+    const float t = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * a));
+    return copysignf(t, x);
+}
 __device__ __forceinline__ float tanhf_(float x) {
     const float a = fminf(fabsf(x), 15.0f);                 // tanh(15) == 1 in fp32; avoids exp overflow
     const float t = 1.0f - 2.0f * __frcp_rn(1.0f + __expf(2.0f * a));

@@ -290,11 +290,10 @@ __global__ __launch_bounds__(512) void lstm_persist16_kernel(const LstmPersist6P
                                   ((pt[4][q][ec][ej] + pt[5][q][ec][ej]) + (pt[6][q][ec][ej] + pt[7][q][ec][ej]));
                 pre[q] = __fmaf_rn(sum, wiv[q], gpre[q]);
             }
-            LP16_TRC(6);
-            const float ig = sigmoidf_(pre[0]), fg = sigmoidf_(pre[1]), gg = tanhf_(pre[2]), og = sigmoidf_(pre[3]);
+            const float ig = sigmoid_rcp(pre[0]), fg = sigmoid_rcp(pre[1]), gg = tanh_rcp(pre[2]), og = sigmoid_rcp(pre[3]);
             cstate = fg * cstate + ig * gg;
-            hn = og * tanhf_(cstate);
-            LP16_TRC(7);
+            hn = og * tanh_rcp(cstate);
+            LP16_TRC(6);
             // ---- publish h[t] (no flag, no wait).  A non-finite state must not look like "not yet written": publish a finite
             // stand-in and record the step; lstm_tail_kernel turns this clip's outputs from that step on into NaN (lstm_persist6.h)
             const bool nonfinite = !(fabsf(hn) < 2.0f);
@@ -312,6 +311,7 @@ __global__ __launch_bounds__(512) void lstm_persist16_kernel(const LstmPersist6P
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)dst, 0, SLICE_BYTES, 0x00020000);
             __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, hh), rs, hpos, 0, LP_SC0);
             __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, hl), rs, 512 + hpos, 0, LP_SC0);
+            LP16_TRC(7);
             if (layer == 0) {   // the copy layer 1 reads from the neighbouring XCD: kept for the batch store below
                 hist[t % LP16_BATCH][0][tid] = __builtin_bit_cast(unsigned short, hh);
                 hist[t % LP16_BATCH][1][tid] = __builtin_bit_cast(unsigned short, hl);
