@@ -965,7 +965,8 @@ int mimi_decoder_fwd(ac_handle* h, hipStream_t st, const float* qfeats, int B, i
 // y[rows][N] = epi(x[rows][cin-slice] * W^T): a 1-tap GEMM over a merged token matrix (core.hip; Mimi and WavTokenizer use it)
 int mimi_linear(ac_handle* h, hipStream_t st, const PackedGemm& g, const float* x, long long rows, int cin, int x_pitch, int kofs,
                 float* y, int y_pitch, const Epi& epi = Epi{});
-int layernorm_fwd(ac_handle* h, hipStream_t st, const float* x, size_t w_off, size_t b_off, float* y, long long rows, int H, float eps);   // mimi_path.hip
+int layernorm_fwd(ac_handle* h, hipStream_t st, const float* x, size_t w_off, size_t b_off, float* y, long long rows, int H, float eps,
+                  const unsigned** rows_out = nullptr);   // mimi_path.hip
 int mimi_rvq_encode(ac_handle* h, hipStream_t st, const float* proj, int F, int K, long long* toks);
 int mimi_rvq_decode(ac_handle* h, hipStream_t st, const long long* toks, int F, int K, float* qsum, float* qfeats);
 int dac_finalize(ac_handle* h, Packer& pk);

@@ -8,6 +8,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "tap_gemm.h"
+#include "split16.h"
 
 namespace ac {
 
@@ -23,6 +24,8 @@ struct LayerNormParams {
     long long rows;
     int H;
     float eps;
+    unsigned* rowmax;    // optional [rows]: bit pattern of the largest finite |y| of each row (split16.h row mode: the linear layer
+                         // that reads y scales by it -- saves that layer's rowmax_kernel launch and its second read of y)
 };
 
 constexpr int LN_MAXV = 16;   // H <= 1024
@@ -54,10 +57,23 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LayerNormParams p)
     for (int sh = 1; sh < 64; sh <<= 1) sq += __shfl_xor(sq, sh);
     const float rstd = 1.0f / sqrtf(sq / (float)p.H + p.eps);
     float* yr = p.y + row * p.H;
+    unsigned rmax = 0;
 #pragma unroll
     for (int i = 0; i < LN_MAXV; ++i) {
         const int c = lane + 64 * i;
-        if (c < p.H) yr[c] = (v[i] - mean) * rstd * p.w[c] + p.b[c];
+        if (c < p.H) {
+            const float o = (v[i] - mean) * rstd * p.w[c] + p.b[c];
+            yr[c] = o;
+            amax_acc(rmax, o);
+        }
+    }
+    if (p.rowmax) {
+#pragma unroll
+        for (int sh = 1; sh < 64; sh <<= 1) {
+            const unsigned t = (unsigned)__shfl_xor((int)rmax, sh);
+            rmax = t > rmax ? t : rmax;
+        }
+        if (lane == 0) p.rowmax[row] = rmax;
     }
 }
 

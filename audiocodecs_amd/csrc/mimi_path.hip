@@ -89,9 +89,15 @@ bool mimi_rb_self_elu(const ac_handle* h, const ac_mimi_config& c, int C) {
     return (C == 64 || (C == 128 && !h->gemm_fp32 && !h->dbg)) && c.residual_kernel_size == 3 && c.compress == 2;
 }
 
-int layernorm_fwd(ac_handle* h, hipStream_t st, const float* x, size_t w_off, size_t b_off, float* y, long long rows, int H, float eps) {
+int layernorm_fwd(ac_handle* h, hipStream_t st, const float* x, size_t w_off, size_t b_off, float* y, long long rows, int H, float eps,
+                  const unsigned** rows_out) {
     if (H > 64 * LN_MAXV) return fail(h, AC_EINVAL, "hidden size %d exceeds the LayerNorm kernel limit", H);
-    LayerNormParams p{x, h->blob + w_off, h->blob + b_off, y, rows, H, eps};
+    LayerNormParams p{x, h->blob + w_off, h->blob + b_off, y, rows, H, eps, nullptr};
+    if (rows_out) {                       // row words for the linear layer that reads y (split16.h row mode); every row is written
+        *rows_out = nullptr;
+        if (!h->gemm_fp32 && !h->gemm_bf16 && rows <= 0x7fffffffLL) p.rowmax = rowmax_new(h, st, rows, false);
+        *rows_out = p.rowmax;
+    }
     ProfScope ps(h, st, "layernorm_kernel", 8.0 * rows * H, 8.0 * rows * H);
     hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, p);
     HIPCHK(h, hipGetLastError());
@@ -139,18 +145,22 @@ int transformer_fwd(ac_handle* h, hipStream_t st, const std::vector<MimiTfLayer>
     const int H = c.hidden_size, A = c.num_attention_heads * c.head_dim, I = c.intermediate_size;
     const long long rows = (long long)B * T;
     for (const MimiTfLayer& L : layers) {
-        int rc = layernorm_fwd(h, st, x, L.ln1_w, L.ln1_b, s.ln, rows, H, c.norm_eps);
+        const unsigned* ln_rows = nullptr;       // split16.h row mode: the LayerNorm leaves the row amax of its output for the projection
+        int rc = layernorm_fwd(h, st, x, L.ln1_w, L.ln1_b, s.ln, rows, H, c.norm_eps, &ln_rows);
         if (rc) return rc;
-        if ((rc = mimi_linear(h, st, L.qkv, s.ln, rows, H, H, 0, s.qkv, 3 * A))) return rc;
+        Epi eq;
+        eq.rowmax_in = ln_rows;
+        if ((rc = mimi_linear(h, st, L.qkv, s.ln, rows, H, H, 0, s.qkv, 3 * A, eq))) return rc;
         if ((rc = attention_fwd(h, st, s.qkv, s.att, B, T))) return rc;
         Epi ea;
         ea.scale = h->blob + L.sc_a;
         ea.res = x;
         ea.res_rs = H;
         if ((rc = mimi_linear(h, st, L.o, s.att, rows, A, A, 0, x, H, ea))) return rc;
-        if ((rc = layernorm_fwd(h, st, x, L.ln2_w, L.ln2_b, s.ln, rows, H, c.norm_eps))) return rc;
+        if ((rc = layernorm_fwd(h, st, x, L.ln2_w, L.ln2_b, s.ln, rows, H, c.norm_eps, &ln_rows))) return rc;
         Epi eg;
         eg.gelu = 1;
+        eg.rowmax_in = ln_rows;
         const unsigned* hid_rows = nullptr;      // split16.h row mode: fc1's epilogue leaves the row amax of its output for fc2
         eg.rowmax_out = &hid_rows;
         if ((rc = mimi_linear(h, st, L.fc1, s.ln, rows, H, H, 0, s.hid, I, eg))) return rc;

@@ -251,6 +251,7 @@ struct DwLnParams {
     float* y;            // [B][N][C]
     int B, N, C;
     float eps;
+    unsigned* rowmax;    // optional [B*N]: bit pattern of the largest finite |y| of each row (split16.h row mode, as LayerNormParams::rowmax)
 };
 
 constexpr int DWLN_MAXV = 4;    // 16-byte vectors per lane: C <= 1024, C % 4 == 0
@@ -299,14 +300,25 @@ __global__ __launch_bounds__(256) void dwconv_ln_kernel(const DwLnParams p) {
     for (int sh = 1; sh < 64; sh <<= 1) sq += __shfl_xor(sq, sh);
     const float rstd = 1.0f / sqrtf(sq / (float)p.C + p.eps);
     float* yr = p.y + row * p.C;
+    unsigned rmax = 0;
 #pragma unroll
     for (int i = 0; i < DWLN_MAXV; ++i) {
         const int q = lane + 64 * i;
         if (q < cv) {
             const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + 4 * q), sh = *reinterpret_cast<const f32x4*>(p.shift + 4 * q);
-            *reinterpret_cast<f32x4*>(yr + 4 * q) = f32x4{(v[i].x - mean) * rstd * sc.x + sh.x, (v[i].y - mean) * rstd * sc.y + sh.y,
-                                                           (v[i].z - mean) * rstd * sc.z + sh.z, (v[i].w - mean) * rstd * sc.w + sh.w};
+            const f32x4 o = f32x4{(v[i].x - mean) * rstd * sc.x + sh.x, (v[i].y - mean) * rstd * sc.y + sh.y,
+                                  (v[i].z - mean) * rstd * sc.z + sh.z, (v[i].w - mean) * rstd * sc.w + sh.w};
+            *reinterpret_cast<f32x4*>(yr + 4 * q) = o;
+            amax_acc4(rmax, o);
         }
+    }
+    if (p.rowmax) {
+#pragma unroll
+        for (int sh = 1; sh < 64; sh <<= 1) {
+            const unsigned t2 = (unsigned)__shfl_xor((int)rmax, sh);
+            rmax = t2 > rmax ? t2 : rmax;
+        }
+        if (lane == 0) p.rowmax[row] = rmax;
     }
 }
 

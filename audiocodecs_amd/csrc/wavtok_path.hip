@@ -279,14 +279,18 @@ int wavtok_decoder_fwd(ac_handle* h, hipStream_t st, const float* feats, int B, 
     if ((rc = layernorm_fwd(h, st, t, m.nsc, m.nsh, x, rows, C, 1e-6f))) return rc;   // AdaLayerNorm: LN * scale[cond] + shift[cond]
     capture(h, st, xa, B);
     for (const WtCnxPlan& L : m.cnx) {
+        const unsigned* t_rows = nullptr;
         {
-            DwLnParams p{x, h->blob + L.dww, h->blob + L.dwb, h->blob + L.sc, h->blob + L.sh, t, B, N, C, 1e-6f};
+            DwLnParams p{x, h->blob + L.dww, h->blob + L.dwb, h->blob + L.sc, h->blob + L.sh, t, B, N, C, 1e-6f, nullptr};
+            if (!h->gemm_fp32 && !h->gemm_bf16) p.rowmax = rowmax_new(h, st, rows, false);   // row words for p1 (split16.h row mode)
+            t_rows = p.rowmax;
             ProfScope ps(h, st, "dwconv_ln_kernel", 2.0 * rows * C * 7, 8.0 * rows * C);
             hipLaunchKernelGGL(dwconv_ln_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, p);
             HIPCHK(h, hipGetLastError());
         }
         Epi eg;
         eg.gelu = 1;
+        eg.rowmax_in = t_rows;
         const unsigned* u_rows = nullptr;        // split16.h row mode: p1's epilogue leaves the row amax of its output for p2
         eg.rowmax_out = &u_rows;
         if ((rc = mimi_linear(h, st, L.p1, t, rows, C, C, 0, u, I, eg))) return rc;
@@ -298,10 +302,13 @@ int wavtok_decoder_fwd(ac_handle* h, hipStream_t st, const float* feats, int B, 
         if ((rc = mimi_linear(h, st, L.p2, u, rows, I, I, 0, x, C, em))) return rc;
         capture(h, st, xa, B);
     }
-    if ((rc = layernorm_fwd(h, st, x, m.flw, m.flb, t, rows, C, 1e-6f))) return rc;
+    const unsigned* fl_rows = nullptr;
+    if ((rc = layernorm_fwd(h, st, x, m.flw, m.flb, t, rows, C, 1e-6f, &fl_rows))) return rc;
     capture(h, st, Act{t, (long long)N * C, C, N, C}, B);
     // ---- head
-    if ((rc = mimi_linear(h, st, m.head, t, rows, C, C, 0, u, m.npad))) return rc;
+    Epi eh;
+    eh.rowmax_in = fl_rows;
+    if ((rc = mimi_linear(h, st, m.head, t, rows, C, C, 0, u, m.npad, eh))) return rc;
     {
         PolarParams p{u, rows, m.npad, m.bins};
         const long long total = rows * (m.npad / 2);
