@@ -975,7 +975,7 @@ int lstm_fwd(ac_handle* h, hipStream_t st, const LstmPlan& lp, const Act& x, con
                             for (int k = 1; k < 8; ++k) std::fprintf(stderr, " %lld", r[k] ? (long long)(r[k] - r[0]) : -1LL);
                             if (s_ < 3) std::fprintf(stderr, " next %lld ", (long long)(r[8] - r[0]));
                         }
-                        std::fprintf(stderr, "\n");
+                        std::fprintf(stderr, " | steps that had to poll: %llu of %d\n", tr[role * 64 + 63], T);
                     }
                 }
                 continue;

@@ -265,7 +265,9 @@ __global__ __launch_bounds__(512) void lstm_persist16_kernel(const LstmPersist6P
         for (int n = 0; n < 4; ++n) acc[n] = accP[n];
         if (t > 0) {
             // (arec: requested in the previous step's projection; incomplete, or never requested without a projection: poll)
-            if (!((layer == 1 || fuse0) && (valid(arec) || (p.dbg & 4))) && !load_valid(hmine, t - 1, arec)) return false;
+            const bool first_ok = (layer == 1 || fuse0) && (valid(arec) || (p.dbg & 4));
+            if (trc && !first_ok) trw[63] += 1;                    // developer trace: steps whose early request came back incomplete
+            if (!first_ok && !load_valid(hmine, t - 1, arec)) return false;
             LP16_TRC(1);
             if (layer == 0) mac(arec, wa, acc);
             else mac(arec, wb, acc);
