@@ -311,6 +311,8 @@ int run_tap(ac_handle* h, hipStream_t st, TapGemmParams& p) {
                            (long long)p.M * p.y_rs * 4 < 0x7fffffffLL && p.y_rs * 4 < (1 << 20);
         }
         { static const int stag = std::getenv("AC_TAP_STAGGER") ? std::atoi(std::getenv("AC_TAP_STAGGER")) : 0; p.stagger = stag; }
+        static const bool dil_env = !(std::getenv("AC_TAP_DIL") && std::atoi(std::getenv("AC_TAP_DIL")) == 0);      // developer: AC_TAP_DIL=0 -> slab reload per tap
+        const bool dil_slab = dil_env && p.nseg == 1 && p.seg[0].dil != 1 && p.seg[0].s == 1 && (p.seg[0].J - 1) * p.seg[0].dil <= T6_DIL_HALO;
 #define TAP6_LAUNCH(WGM, WGN, WMT, WN, NP)                                                                              \
     do {                                                                                                                \
         if ((rc = ensure_lds(h, reinterpret_cast<const void*>(tap_gemm6_kernel<WGM, WGN, WMT, WN, NP>), Cfg6::lds_for(NP)))) return rc; \
@@ -324,7 +326,14 @@ int run_tap(ac_handle* h, hipStream_t st, TapGemmParams& p) {
         p.ntiles = p.N / Cfg6::BN;                                                                                      \
         const long long blocks = (long long)p.B * p.mtiles * p.ntiles;                                                  \
         if (h->gemm_bf16) TAP6_LAUNCH(WGM, WGN, WMT, WN, 1);                                                            \
-        else if (p.winv) TAP6_LAUNCH(WGM, WGN, WMT, WN, 2);                                                             \
+        else if (p.winv && dil_slab && (WN >= 2 || (WGM == 1 && WGN == 4 && kk >= 2048))) {                                  \
+            /* dilated taps out of one wide slab (tap_gemm6.h: T6_DIL_HALO); measured per arrangement on DAC's layers: the 128 x 32  \
+               tile loses its third workgroup per CU to the larger slab and gains only for long contractions, 64 x 32 tiles lose */ \
+            using Cfg6D = Tap6Cfg<WGM, WGN, WMT, WN, T6_DIL_HALO>;                                                      \
+            if ((rc = ensure_lds(h, reinterpret_cast<const void*>(tap_gemm6_kernel<WGM, WGN, WMT, WN, 2, T6_DIL_HALO>), Cfg6D::lds_for(2)))) return rc; \
+            ProfScope ps(h, st, (std::string("tap_gemm6_kernel<" #WGM ", " #WGN ", " #WMT ", " #WN ", 2, dil>") + shape).c_str(), flops, bytes); \
+            hipLaunchKernelGGL((tap_gemm6_kernel<WGM, WGN, WMT, WN, 2, T6_DIL_HALO>), dim3((unsigned)blocks), dim3(Cfg6D::NT), Cfg6D::lds_for(2), st, p, w6); \
+        } else if (p.winv) TAP6_LAUNCH(WGM, WGN, WMT, WN, 2);                                                           \
         else TAP6_LAUNCH(WGM, WGN, WMT, WN, 3);                                                                         \
     } while (0)
         // Tile / wave arrangement (measured, profiles/r2_tapgemm_variants.md).  The weight fragments come L2 -> registers and the

@@ -36,12 +36,15 @@ __device__ __forceinline__ void lds_barrier() {
 
 constexpr int T6_PITCH = 40;        // bf16 per LDS row (32 + 8): 80-byte rows keep 16-byte alignment, spread banks
 
-template <int WGM, int WGN, int WMT, int WN>
+// HALO: rows of the A slab beyond BM.  7 = the taps of a k <= 8 conv on consecutive rows; T6_DIL_HALO = the dilated k7 convs of
+// DAC's residual units (6 x 9 rows) read from ONE slab per chunk like any other conv, instead of a slab reload per tap
+// (13 - 22 % slower per launch, profiles/r3_tapgemm_trace.md).  The larger slab costs LDS (59 KB instead of 43 KB: two workgroups per CU).
+constexpr int T6_DIL_HALO = 56;
+template <int WGM, int WGN, int WMT, int WN, int HALO = 7>
 struct Tap6Cfg {
     static_assert((WGM * WGN == 4 || WGM * WGN == 8) && (WGM * WMT == 4 || WGM * WMT == 8), "4 or 8 waves, 128 or 256 rows");
     static constexpr int BM = 32 * WGM * WMT, BN = 32 * WGN * WN, NT = 64 * WGM * WGN;
-    static constexpr int MAXJ = 8;
-    static constexpr int A_ROWS = BM + MAXJ - 1;
+    static constexpr int A_ROWS = BM + HALO;
     static constexpr int A_SLOTS = (A_ROWS * (KC / 4) + NT - 1) / NT;
     static constexpr int PLANE = A_ROWS * T6_PITCH;                 // bf16 elements per plane
     static constexpr int CP = 32 * WGN + 4;      // epilogue staging: one wave column tile per pass
@@ -68,9 +71,9 @@ constexpr int tap6_occupancy() {
 // NP = 2: split16.h -- two fp16 planes per operand, 3 partial products, per-clip / per-output-channel power-of-two scales:
 //         the same fp32 fidelity at half the MFMAs and two thirds of the operand bytes.  Weight image
 //         [n-tile of 32][k-step of 16][plane 2][lane 64][8 fp16] of the SCALED rows; needs seg[].amax and winv.
-template <int WGM, int WGN, int WMT, int WN, int NP = 3>
+template <int WGM, int WGN, int WMT, int WN, int NP = 3, int HALO = 7>
 __global__ __launch_bounds__(64 * WGM * WGN, (tap6_occupancy<WGM, WGN, WMT, WN, NP>())) void tap_gemm6_kernel(const TapGemmParams p, const __bf16* __restrict__ wp) {
-    using Cfg = Tap6Cfg<WGM, WGN, WMT, WN>;
+    using Cfg = Tap6Cfg<WGM, WGN, WMT, WN, HALO>;
     constexpr int BM = Cfg::BM, BN = Cfg::BN, NT = Cfg::NT, A_SLOTS = Cfg::A_SLOTS, PLANE = Cfg::PLANE;
     unsigned long long clk_t0 = 0, clk_r0 = 0;
     if (p.clk) { clk_t0 = __builtin_amdgcn_s_memtime(); clk_r0 = __builtin_amdgcn_s_memrealtime(); }
@@ -124,6 +127,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (tap6_occupancy<WGM, WGN, WMT, WN, 
     int seg_J, seg_Cw, seg_kofs;
     int seg_tapoff = 0;
     bool seg_reload = false;
+    int seg_rowstep = 1;                // slab rows between the taps of a segment (its dilation when the taps share one slab)
     bool seg_interior;
     unsigned a_zero = 0;
     __amdgpu_buffer_rsrc_t a_rs;
@@ -132,7 +136,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, (tap6_occupancy<WGM, WGN, WMT, WN, 
         seg_J = sg.J;
         seg_Cw = sg.s * sg.cin;
         seg_kofs = sg.kofs;
-        seg_reload = sg.dil != 1;
+        seg_reload = sg.dil != 1 && (sg.s != 1 || (sg.J - 1) * sg.dil > HALO);     // dilated taps that fit the slab read it like any others
+        seg_rowstep = seg_reload ? 1 : sg.dil;
         const long long lo = (long long)m0 * sg.s - sg.pad;
         const long long hi = (long long)(m0 + BM - 1 + (sg.J - 1) * sg.dil) * sg.s + (sg.s - 1) - sg.pad;
         const bool inside = lo >= 0 && hi < sg.L;
@@ -142,7 +147,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (tap6_occupancy<WGM, WGN, WMT, WN, 
         seg_tapoff = sg.dil * sg.s * tsf * 4;
         a_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(sg.x + (long long)b * sg.bs), 0,
                                                  (int)(((long long)(sg.L - 1) * sg.ts + sg.cin) * 4), 0x00020000);
-        const int R = seg_reload ? BM : BM + sg.J - 1;
+        const int R = seg_reload ? BM : BM + (sg.J - 1) * sg.dil;
 #pragma unroll
         for (int i = 0; i < A_SLOTS; ++i) {
             const int e = tid + i * NT;
@@ -197,7 +202,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (tap6_occupancy<WGM, WGN, WMT, WN, 
             for (int i = 0; i < A_SLOTS; ++i) voff[i] = live ? a_boff[i] : A_OOB;
         } else {
             const TapSeg& sg = p.seg[s_];
-            const int R = seg_reload ? BM : BM + sg.J - 1;
+            const int R = seg_reload ? BM : BM + (sg.J - 1) * sg.dil;
             const int jr = seg_reload ? j_ * sg.dil : 0;
 #pragma unroll
             for (int i = 0; i < A_SLOTS; ++i) {
@@ -346,7 +351,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (tap6_occupancy<WGM, WGN, WMT, WN, 
             if (nc0 >= seg_Cw) { nc0 = 0; nsi = si + 1; }
         }
         const bool has_next = nsi < p.nseg;
-        const int cur_j = seg_reload ? 0 : j;
+        const int cur_j = seg_reload ? 0 : j * seg_rowstep;
         int s_next = 0;
         if (has_next) {
             if (nsi != si) enter_segment(nsi);
