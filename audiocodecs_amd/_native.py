@@ -167,6 +167,7 @@ EXPORTS = {
     "ac_debug_capture": (_i, [_vp, _vp, _sz]),
     "ac_debug_captured": (_sz, [_vp]),
     "ac_lstm_status": (_i, [_vp]),
+    "ac_poll_status": (_i, [_vp, _vp]),
     "ac_last_error": (C.c_char_p, [_vp]),
     "ac_destroy": (None, [_vp]),
 }

@@ -26,6 +26,10 @@ class Codec(torch.nn.Module, ABC):
         self.orig_sample_rate = orig_sample_rate
         self.mode = mode
         self._logits = None
+        # strict=True (keyword of every wrapper): after each public call, synchronise the stream and poll the handle for
+        # failures only the device can see (a failed persistent LSTM launch, token ids out of range) so that THIS call raises,
+        # not an unrelated later one (include/audiocodecs_amd.h: ac_poll_status).  Default off: no entry point synchronises.
+        self.strict = False
 
     # codec.py:45-55
     def forward(self, input, length=None):
@@ -48,27 +52,39 @@ class Codec(torch.nn.Module, ABC):
         # codec.py:64-65: length defaults to ones(B) -- the "no padding" case
         return None if self._accepts_none_length else torch.ones(len(x), device=x.device)
 
+    def _polled(self, out):
+        """strict mode: surface device-side failures of the call that just ran (ac_poll_status synchronises the stream)."""
+        if self.strict and out.is_cuda:
+            nat = getattr(self, "_natives", {}).get(out.device.index)
+            if nat is not None:
+                from . import _native
+
+                with torch.cuda.device(out.device):
+                    stream = torch.cuda.current_stream().cuda_stream
+                    _native.check(nat.lib.ac_poll_status(nat.h, stream), nat.h, "ac_poll_status")
+        return out
+
     def sig_to_toks(self, sig, length=None):  # codec.py:57-66
         sig = self._in(sig)
-        return self._sig_to_toks(sig, self._ones(sig) if length is None else length)
+        return self._polled(self._sig_to_toks(sig, self._ones(sig) if length is None else length))
 
     def sig_to_feats(self, sig, length=None):  # codec.py:68-77
         sig = self._in(sig)
-        return self._sig_to_feats(sig, self._ones(sig) if length is None else length)
+        return self._polled(self._sig_to_feats(sig, self._ones(sig) if length is None else length))
 
     def sig_to_qfeats(self, sig, length=None):  # codec.py:79-88
         sig = self._in(sig)
-        return self._sig_to_qfeats(sig, self._ones(sig) if length is None else length)
+        return self._polled(self._sig_to_qfeats(sig, self._ones(sig) if length is None else length))
 
     def toks_to_sig(self, toks, length=None):  # codec.py:90-100
-        sig = self._toks_to_sig(toks, self._ones(toks) if length is None else length)
+        sig = self._polled(self._toks_to_sig(toks, self._ones(toks) if length is None else length))
         return self._out(sig)
 
     def toks_to_qfeats(self, toks, length=None):  # codec.py:102-107
-        return self._toks_to_qfeats(toks, self._ones(toks) if length is None else length)
+        return self._polled(self._toks_to_qfeats(toks, self._ones(toks) if length is None else length))
 
     def feats_to_sig(self, feats, length=None):  # codec.py:109-119
-        sig = self._feats_to_sig(feats, self._ones(feats) if length is None else length)
+        sig = self._polled(self._feats_to_sig(feats, self._ones(feats) if length is None else length))
         return self._out(sig)
 
     # ---- token-resampling utilities (codec.py:121-180; no caller in the reference tree) --------

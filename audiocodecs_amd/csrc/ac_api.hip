@@ -480,6 +480,12 @@ int ac_encode_feats_latent(ac_handle* h, const float* sig, int B, int T, float* 
     return dac_encode_impl(h, sig, B, T, 0, nullptr, feats_latent, nullptr, nullptr, ws, ws_bytes, (hipStream_t)stream);
 }
 
+int ac_poll_status(ac_handle* h, void* stream) {
+    if (!h) return AC_EINVAL;
+    HIPCHK(h, hipStreamSynchronize((hipStream_t)stream));
+    return check_ready(h);
+}
+
 int ac_lstm_status(ac_handle* h) {
     if (!h) return AC_EINVAL;
     if (!h->lp_ctl) return 0;

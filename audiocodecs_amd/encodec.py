@@ -101,6 +101,7 @@ class Encodec(Codec):
         state_dict: Optional[Dict[str, torch.Tensor]] = None,
         config: EncodecConfig = ENCODEC_24KHZ,
         precision: Optional[str] = None,
+        strict: bool = False,
     ):
         """`state_dict`: an HF-format EncodecModel state dict (keys of SURVEY.md Appendix A.3, e.g.
         `safetensors.torch.load_file(model.safetensors)` of facebook/encodec_24khz, or
@@ -109,6 +110,7 @@ class Encodec(Codec):
         `precision`: None / "fp32" = fp32 fidelity (the parity arithmetic, default); "fp32_exact" = exact fp32 products;
         "bf16" = OPT-IN reduced precision for the tap-GEMMs (include/audiocodecs_amd.h ac_set_precision) -- not a parity mode."""
         super().__init__(sample_rate, orig_sample_rate, mode)
+        self.strict = bool(strict)   # codec.py: poll the handle after every call
         self.precision = _native.check_precision(precision)
         if use_vocos:
             raise NotImplementedError("the Vocos decoder variant (encodec.py:53-66) is outside the MI355X path")

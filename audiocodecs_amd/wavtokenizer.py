@@ -104,12 +104,14 @@ class WavTokenizer(Codec):
         state_dict: Optional[Dict[str, torch.Tensor]] = None,
         arch: Optional[WavTokenizerConfig] = None,
         precision: Optional[str] = None,
+        strict: bool = False,
     ):
         """`state_dict`: the `state_dict` of the upstream Lightning checkpoint (keys feature_extractor.* / backbone.* /
         head.*), or `checkpoint.synthetic_wavtok_state_dict(arch, seed)`; when omitted it is fetched through
         huggingface_hub like the reference does (wavtokenizer.py:72-78; needs network or a warm cache).  `arch`: the
         architecture the YAML `config` describes (default: picked from the config's name -- frame40 / frame75)."""
         super().__init__(sample_rate, 24000, mode)  # wavtokenizer.py:68
+        self.strict = bool(strict)   # codec.py: poll the handle after every call
         if arch is None:
             arch = WAVTOK_75 if "frame75" in config else WAVTOK_40
         self.num_codebooks = 1

@@ -364,6 +364,13 @@ int ac_debug_split_row(const float* w, int n, uint16_t* hi, uint16_t* lo);
  * the batch: its LSTM outputs are NaN from that frame on, like the reference's. */
 int ac_lstm_status(ac_handle* h);
 
+/* Explicit poll for those sticky device-side failures (round-2 advisor finding: otherwise an unrelated, correct later call is
+ * the one that raises).  SYNCHRONISES `stream`, then returns what the next entry point would have returned -- AC_EHIP (a
+ * persistent LSTM launch failed; the handle has switched to the per-step kernels), AC_EINVAL (token ids out of range) or AC_OK --
+ * and clears the words, so that later calls are not affected.  The Python wrappers call it after each of their own calls when
+ * constructed with strict=True. */
+int ac_poll_status(ac_handle* h, void* stream);
+
 const char* ac_last_error(const ac_handle* h);
 void ac_destroy(ac_handle* h);
 

@@ -423,3 +423,29 @@ def test_failed_persistent_launch_is_reported_and_healed(checkpoints, monkeypatc
     toks = codec.sig_to_toks(sig)            # healed: per-step kernels from now on
     assert nat.lib.ac_lstm_status(nat.h) == 0
     assert float((toks == want).float().mean()) > 0.999   # per-step vs persistent: same function up to fp32 rounding
+
+
+def test_strict_mode_raises_in_the_call_that_failed(checkpoints, monkeypatch):
+    """strict=True (round-2 advisor finding on sticky errors): the wrapper polls the handle after its own call
+    (ac_poll_status: synchronises the stream, reports and clears the sticky words), so the call whose persistent LSTM launch
+    failed raises -- not an unrelated later one -- and the next call runs on the healed handle without an exception."""
+    from audiocodecs_amd import Encodec
+    from audiocodecs_amd._native import NativeError
+
+    cfg, sd = checkpoints("full", 0)
+    good = Encodec(24000, num_codebooks=8, state_dict=sd, config=cfg).eval()
+    codec = Encodec(24000, num_codebooks=8, state_dict=sd, config=cfg, strict=True).eval()
+    sig = noise(8283, 2, 16000).cuda()
+    want = good.sig_to_toks(sig)
+    monkeypatch.setenv("AC_LSTM_DBG", "16")
+    with pytest.raises(NativeError, match="persistent LSTM launch failed"):
+        codec.sig_to_feats(sig)
+    monkeypatch.delenv("AC_LSTM_DBG")
+    toks = codec.sig_to_toks(sig)            # no leftover error: the poll cleared it; per-step kernels from now on
+    assert float((toks == want).float().mean()) > 0.999
+    bad = toks.clone()
+    bad[0, 3, 2] = 5000                      # outside [0, 1024)
+    with pytest.raises(NativeError, match="token ids outside"):
+        codec.toks_to_sig(bad)
+    rec = codec.toks_to_sig(toks)            # unaffected
+    assert bool(torch.isfinite(rec).all())
