@@ -311,7 +311,8 @@ int run_tap(ac_handle* h, hipStream_t st, TapGemmParams& p) {
                            (long long)p.M * p.y_rs * 4 < 0x7fffffffLL && p.y_rs * 4 < (1 << 20);
         }
         { static const int stag = std::getenv("AC_TAP_STAGGER") ? std::atoi(std::getenv("AC_TAP_STAGGER")) : 0; p.stagger = stag; }
-        static const bool dil_env = !(std::getenv("AC_TAP_DIL") && std::atoi(std::getenv("AC_TAP_DIL")) == 0);      // developer: AC_TAP_DIL=0 -> slab reload per tap
+        const char* dil_s = std::getenv("AC_TAP_DIL");            // developer / tests: AC_TAP_DIL=0 -> slab reload per tap (read per launch: a test flips it)
+        const bool dil_env = !(dil_s && std::atoi(dil_s) == 0);
         const bool dil_slab = dil_env && p.nseg == 1 && p.seg[0].dil != 1 && p.seg[0].s == 1 && (p.seg[0].J - 1) * p.seg[0].dil <= T6_DIL_HALO;
 #define TAP6_LAUNCH(WGM, WGN, WMT, WN, NP)                                                                              \
     do {                                                                                                                \

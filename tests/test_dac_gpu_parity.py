@@ -175,3 +175,28 @@ def test_errors_and_codebook_clamp(codecs, dac_checkpoints):
     assert many.sig_to_toks(noise(5, 1, 4000).cuda()).shape[-1] == cfg.n_codebooks   # upstream's loop just runs out of quantisers
     with pytest.raises(ImportError):
         DAC(16000)                                          # no bundled weights
+
+
+def test_dilated_taps_from_one_slab_equal_the_reload_per_tap_path(dac_checkpoints, monkeypatch):
+    """csrc/tap_gemm6.h T6_DIL_HALO: the dilated k7 convs of the residual units read their seven taps from one wide A slab per
+    chunk (the instantiation run_tap picks where it measured faster) instead of reloading the slab per tap.  Both walk
+    (chunk, tap) in the same order, so tokens AND waveform must be bit-equal between the two (AC_TAP_DIL=0 = reload path),
+    also at lengths that put clip edges inside the halo."""
+    from audiocodecs_amd import DAC
+
+    cfg, sd = dac_checkpoints("full", 0)
+    codec = DAC(44100, 44100, num_codebooks=9, state_dict=sd, config=cfg).eval()
+    for B, T in ((2, 8192), (3, 5003), (1, 700)):
+        sig = noise(5150 + T, B, T).cuda()
+        names = {s[0] for s in codec.profile_kernels(lambda: codec.toks_to_sig(codec.sig_to_toks(sig)))}
+        assert any(", dil>" in n for n in names), names              # the wide-slab instantiation is what runs by default (decoder: 96 / 192 / 384 / 768 channels)
+        toks, rec = codec.sig_to_toks(sig), None
+        rec = codec.toks_to_sig(toks)
+        monkeypatch.setenv("AC_TAP_DIL", "0")
+        names0 = {s[0] for s in codec.profile_kernels(lambda: codec.toks_to_sig(codec.sig_to_toks(sig)))}
+        assert not any(", dil>" in n for n in names0), names0
+        toks0 = codec.sig_to_toks(sig)
+        rec0 = codec.toks_to_sig(toks)
+        monkeypatch.delenv("AC_TAP_DIL")
+        assert torch.equal(toks, toks0), (B, T)
+        assert torch.equal(rec, rec0), (B, T)
