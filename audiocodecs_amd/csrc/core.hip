@@ -303,7 +303,8 @@ int run_tap(ac_handle* h, hipStream_t st, TapGemmParams& p) {
             p.winv = h->blob + iv->second;
             p.amax_out = amax_new(h);
             // plain conv outputs store straight from the accumulators (tap_gemm6.h); AC_TAP_EPI=staged: the LDS-staged epilogue
-            static const bool staged_env = std::getenv("AC_TAP_EPI") && std::strcmp(std::getenv("AC_TAP_EPI"), "staged") == 0;
+            const char* epi_s = std::getenv("AC_TAP_EPI");            // (read per launch: a test flips it)
+            const bool staged_env = epi_s && std::strcmp(epi_s, "staged") == 0;
             // (ELU flavour without a residual, Snake flavour with or without one: the combinations the four codecs produce)
             p.epi_direct = !staged_env && !h->gemm_bf16 && !p.gelu && !p.scale && !p.tanh_out && p.y_off == 0 && p.y_len == 0 &&
                            (!p.res || (p.alpha && (long long)p.M * p.res_rs * 4 < 0x7fffffffLL && p.res_rs * 4 < (1 << 20))) && (!p.alpha || p.y_elu) &&

@@ -200,3 +200,31 @@ def test_dilated_taps_from_one_slab_equal_the_reload_per_tap_path(dac_checkpoint
         monkeypatch.delenv("AC_TAP_DIL")
         assert torch.equal(toks, toks0), (B, T)
         assert torch.equal(rec, rec0), (B, T)
+
+
+@pytest.mark.parametrize("codec_name", ["dac", "encodec"])
+def test_direct_epilogue_equals_the_staged_one(codec_name, dac_checkpoints, checkpoints, monkeypatch):
+    """csrc/tap_gemm6.h: conv outputs leave the accumulators either through the direct epilogue (one 4-byte store per value;
+    plain / ELU flavours of 128-column layers, and -- with residual / Snake copies -- DAC's layers under 128 channels) or
+    through LDS-staged 16-byte rows (AC_TAP_EPI=staged forces it everywhere).  The same operations in the same order per
+    element: tokens and waveform must be bit-equal, edge tiles included."""
+    from audiocodecs_amd import DAC, Encodec
+
+    if codec_name == "dac":
+        cfg, sd = dac_checkpoints("full", 0)
+        codec = DAC(44100, 44100, num_codebooks=9, state_dict=sd, config=cfg).eval()
+        shapes = ((2, 6151), (1, 1024))
+    else:
+        cfg, sd = checkpoints("full", 0)
+        codec = Encodec(24000, num_codebooks=8, state_dict=sd, config=cfg).eval()
+        shapes = ((3, 9999), (1, 24000))
+    for B, T in shapes:
+        sig = noise(6160 + T, B, T).cuda()
+        toks = codec.sig_to_toks(sig)
+        rec = codec.toks_to_sig(toks)
+        monkeypatch.setenv("AC_TAP_EPI", "staged")
+        toks0 = codec.sig_to_toks(sig)
+        rec0 = codec.toks_to_sig(toks)
+        monkeypatch.delenv("AC_TAP_EPI")
+        assert torch.equal(toks, toks0), (codec_name, B, T)
+        assert torch.equal(rec, rec0), (codec_name, B, T)
