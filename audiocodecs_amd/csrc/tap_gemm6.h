@@ -539,8 +539,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (tap6_occupancy<WGM, WGN, WMT, WN, 
     const int nvalid = p.n_valid ? p.n_valid : p.N;
     unsigned omax = 0;
     constexpr int EH = Cfg::EH, ER = 32 * WGM * EH;       // 32-row tiles / rows staged per pass
-    const bool fastpass = NP == 2 && !rowmode && !p.amax_out_rows && !p.gelu && !p.scale && !p.tanh_out && p.y_len == 0 && p.y_off == 0 && nvalid == p.N &&
-                          m0 + BM <= p.M && n0 + BN <= p.N && (ER * (CW / 4)) % NT == 0;
+    const bool fastpass = NP == 2 && p.y_len == 0 && p.y_off == 0 && nvalid == p.N && m0 + BM <= p.M && n0 + BN <= p.N && (ER * (CW / 4)) % NT == 0;
 #pragma unroll
     for (int c = 0; c < WN; ++c)
 #pragma unroll
@@ -556,6 +555,20 @@ __global__ __launch_bounds__(64 * WGM * WGN, (tap6_occupancy<WGM, WGN, WMT, WN, 
         };
         f32x4 rn1 = f32x4{0.f, 0.f, 0.f, 0.f}, rn2 = rn1;              // the residual rows two iterations ahead of the store loop
         if (fastpass && p.res) { rn1 = res_at(0); if (EITER > 1) rn2 = res_at(1); }
+        // row mode: the rows' amax words likewise; a thread's four columns are the same in every iteration of a pass (NT is a
+        // multiple of CW / 4), so bias / LayerScale / Snake vectors are loaded once per pass, before it is staged
+        auto roww_at = [&](int i) -> unsigned {
+            const int row = (tid + i * NT) / (CW / 4);
+            return p.seg[0].amax[m0 + (row / (32 * EH)) * (32 * WMT) + a0 * 32 + row % (32 * EH)];
+        };
+        unsigned rw1 = 0, rw2 = 0;
+        const int fq = tid % (CW / 4), fn = n0 + (fq / 8) * (32 * WN) + 32 * c + 4 * (fq % 8);
+        f32x4 fb4 = f32x4{0.f, 0.f, 0.f, 0.f}, fsc4 = f32x4{1.f, 1.f, 1.f, 1.f}, fal = fb4, fai = fb4;
+        if (fastpass) {
+            if (rowmode) { rw1 = roww_at(0); if (EITER > 1) rw2 = roww_at(1); if (p.bias) fb4 = *reinterpret_cast<const f32x4*>(p.bias + fn); }
+            if (p.scale) fsc4 = *reinterpret_cast<const f32x4*>(p.scale + fn);
+            if (p.alpha && p.y_elu) { const int ca = fn % p.alpha_n; fal = *reinterpret_cast<const f32x4*>(p.alpha + ca); fai = *reinterpret_cast<const f32x4*>(p.alpha_inv + ca); }
+        }
         __syncthreads();
 #pragma unroll
         for (int a = a0; a < a0 + EH; ++a) {
@@ -569,33 +582,51 @@ __global__ __launch_bounds__(64 * WGM * WGN, (tap6_occupancy<WGM, WGN, WMT, WN, 
         }
         __syncthreads();
         if (fastpass) {
-            // the common full-tile case (plain / residual / Snake / ELU outputs of a conv): no bounds, no row words, the residual rows
-            // requested two iterations ahead
+            // the full-tile case (every epilogue flavour): no bounds; residual rows and row words requested two iterations ahead,
+            // the per-column vectors already in registers -- the generic loop below waits for each of those loads in turn, which
+            // was 48 k of the 67 k cycles of a DAC 1 x 1 tile and 150 k of the 250 k cycles of a Mimi o-projection tile
+            // (profiles/r3_tapgemm_trace.md)
             for (int i = 0; i < EITER; ++i) {
-                const int e = tid + i * NT;
-                const int row = e / (CW / 4), q = e % (CW / 4);
-                const int m = m0 + (row / (32 * EH)) * (32 * WMT) + a0 * 32 + row % (32 * EH), n = n0 + (q / 8) * (32 * WN) + 32 * c + 4 * (q % 8);
-                const long long o = yoff + (long long)m * p.y_rs + n;
-                f32x4 v = *reinterpret_cast<const f32x4*>(&Cs[row * CP + 4 * q]);
+                const int row = (tid + i * NT) / (CW / 4);
+                const int m = m0 + (row / (32 * EH)) * (32 * WMT) + a0 * 32 + row % (32 * EH);
+                const long long o = yoff + (long long)m * p.y_rs + fn;
+                f32x4 v = *reinterpret_cast<const f32x4*>(&Cs[row * CP + 4 * fq]);
+                if (rowmode) {
+                    const float ri = s16_pow2(-s16_exponent(rw1));
+                    rw1 = rw2;
+                    if (i + 2 < EITER) rw2 = roww_at(i + 2);
+                    v = f32x4{__fmaf_rn(v.x, ri, fb4.x), __fmaf_rn(v.y, ri, fb4.y), __fmaf_rn(v.z, ri, fb4.z), __fmaf_rn(v.w, ri, fb4.w)};
+                }
+                if (p.gelu) { v.x = gelu1(v.x); v.y = gelu1(v.y); v.z = gelu1(v.z); v.w = gelu1(v.w); }
+                if (p.scale) { v.x = __fmul_rn(fsc4.x, v.x); v.y = __fmul_rn(fsc4.y, v.y); v.z = __fmul_rn(fsc4.z, v.z); v.w = __fmul_rn(fsc4.w, v.w); }
                 if (p.res) {
                     const f32x4 rv = rn1;
                     rn1 = rn2;
                     if (i + 2 < EITER) rn2 = res_at(i + 2);
                     v.x = __fadd_rn(rv.x, v.x); v.y = __fadd_rn(rv.y, v.y); v.z = __fadd_rn(rv.z, v.z); v.w = __fadd_rn(rv.w, v.w);
                 }
+                if (p.tanh_out) { v.x = tanhf(v.x); v.y = tanhf(v.y); v.z = tanhf(v.z); v.w = tanhf(v.w); }
                 if (p.amax_out) amax_acc4(omax, v);
                 if (p.y) *reinterpret_cast<f32x4*>(p.y + o) = v;
                 if (p.y_elu) {
                     f32x4 w;
                     if (p.alpha) {
-                        const int ca = n % p.alpha_n;
-                        const f32x4 al = *reinterpret_cast<const f32x4*>(p.alpha + ca), ai = *reinterpret_cast<const f32x4*>(p.alpha_inv + ca);
-                        w.x = snake1(v.x, al.x, ai.x); w.y = snake1(v.y, al.y, ai.y); w.z = snake1(v.z, al.z, ai.z); w.w = snake1(v.w, al.w, ai.w);
+                        w.x = snake1(v.x, fal.x, fai.x); w.y = snake1(v.y, fal.y, fai.y); w.z = snake1(v.z, fal.z, fai.z); w.w = snake1(v.w, fal.w, fai.w);
                         if (p.amax_out) amax_acc4(omax, w);
                     } else {
                         w = elu4(v);
                     }
                     *reinterpret_cast<f32x4*>(p.y_elu + o) = w;
+                }
+                if (p.amax_out_rows) {      // the CW / 4 lanes that share this row (every lane runs every iteration)
+                    unsigned rmax = 0;
+                    amax_acc4(rmax, v);
+#pragma unroll
+                    for (int o2 = CW / 8; o2; o2 >>= 1) {
+                        const unsigned t2 = (unsigned)__shfl_xor((int)rmax, o2);
+                        rmax = t2 > rmax ? t2 : rmax;
+                    }
+                    if (fq == 0 && rmax) atomicMax(p.amax_out_rows + m, rmax);
                 }
             }
         } else
