@@ -11,8 +11,8 @@ exist offline).  Clips are independent units: every rank encodes/decodes its own
 inside the timed step.  Rank 0 prints ONE JSON line (contract in the task statement) carrying
   roofline     -- dominant kernel (by HIP-event time measured in the timed steps) against the pipe that bounds it:
                   the dense fp16 MFMA peak (2.5 PF) for the split-operand tap-GEMM (3 fp16 partial products per fp32
-                  product, split16.h; --precision fp32_bf16x3: 6 bf16 products, tap_gemm6.h; fp32_exact: the exact-product
-                  kernels, bounded by the 157.3 TF fp32 MFMA peak) or HBM (8 TB/s)
+                  product, split16.h; --precision fp32_exact: the exact-product kernels, bounded by the 157.3 TF fp32 MFMA
+                  peak) or HBM (8 TB/s)
   cpu_baseline -- the CPU oracle (torch-CPU restatement of the reference) timed on this host's
                   cores on a bounded sample of the same workload.  Baseline only.
 and, at N = 1, outside the timed region (all skipped by --no-parity):
@@ -20,12 +20,17 @@ and, at N = 1, outside the timed region (all skipped by --no-parity):
   exact_fp32_ms_per_step -- the same step with every product an IEEE fp32 product (precision="fp32_exact"), so the
                             split16 figure never travels without its exact-product twin
   other_configs          -- BASELINE.json configs 3-5 at their per-GPU sizes (DAC 256 x 10 s, Mimi 128 x 10 s,
-                            WavTokenizer 64 x 10 s): value, ms_per_step and parity gate of a short (1 + 3 step) run each
-Nothing inside an `if rank == 0` block issues a collective (tests/test_bench_contract.py checks the source for it).
+                            WavTokenizer 64 x 10 s): value, ms_per_step, roofline (dominant kernel family) and parity gate of a
+                            short (1 + 3 step) run each
+  latency                -- the reference's own measurement regime (batch 1, its profiler's clip lengths): encode + decode of
+                            B = 1 / 8 clips of 1 / 10 / 32 s, ms per call, RTF, top-3 kernels
+Nothing inside an `if rank == 0` block issues a collective (tests/test_bench_contract.py checks the source for it), and the
+flow from the warm-ups to the JSON line is `run()`, which tests/test_bench_flow_gloo.py executes at world size 2 over gloo.
 """
 import argparse
 import json
 import os
+import re
 import sys
 import time
 
@@ -36,16 +41,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
-PEAK_BF16_MFMA_TFLOPS = 2500.0  # same guide: dense bf16 MFMA peak (the 5 PF headline includes 2:1 sparsity)
-SPLIT_TERMS = 6                 # tap_gemm6.h, three bf16 planes: partial products executed per fp32 product
 SPLIT16_TERMS = 3               # split16.h, two fp16 planes (the default arithmetic): partial products per fp32 product
-PEAK_F16_MFMA_TFLOPS = 2500.0   # same guide: dense fp16 MFMA peak = the bf16 one
+PEAK_F16_MFMA_TFLOPS = 2500.0   # same guide: dense fp16 / bf16 MFMA peak (the 5 PF headline includes 2:1 sparsity)
 # bare v_mfma_f32_32x32x16_f16 stream on random operands (tools/ubench/mfma_f16_probe.hip): 1.58-1.68 PF at 1.54-1.69 GHz
 SUSTAINED_F16_MFMA_TFLOPS = 1680.0
 PEAK_HBM_GBS = 8000.0          # same guide, "HBM3E peak BW" (spec; 6.29 TB/s achievable)
-# What the bf16 matrix pipe SUSTAINS on random operands: the bare v_mfma_f32_32x32x16_bf16 stream keeps the pipe 100 % busy and
-# power management drops the shader clock to 1.66-1.8 GHz (measured in-kernel, profiles/r2_tapgemm_variants.md): 1.69-1.83 PF
-SUSTAINED_BF16_MFMA_TFLOPS = 1760.0
 # algorithmic work per audio-second of encode+decode (EnCodec-24k, K=8)
 FLOP_PER_AUDIO_S = 6.12e9
 LAYER_BYTES_PER_AUDIO_S = 117.6e6
@@ -75,15 +75,17 @@ def host_cpu():
 
 def cpu_baseline(codec_name, cfg, sd, sig_cpu, ncb):
     """The CPU oracle (kind "port": torch-CPU restatement of the reference's path, oracle/*.py -- checker/baseline only,
-    never on the product path) timed on this host's cores, BASELINE.md section 3 protocol: 2 warm-ups + 3 timed runs of
-    encode+decode on a bounded sample of the same batch, median reported.  torch's CPU convolutions do not scale to
-    every core of a 2-socket host on a few clips, so the thread count is picked first by a short scan (1 clip x 2 s each)
-    and reported as `cores` next to the host's physical core count and CPU model."""
+    never on the product path) timed on this host's cores, BASELINE.md section 3 protocol: B = min(config B, 8) clips of the
+    same batch per call, fp32, torch.inference_mode(), 2 warm-ups + 3 timed runs of encode+decode, median reported.
+    Threads: section 3 says all physical cores of the GPU host -- that run is made and reported (`all_physical_cores`), but
+    torch's CPU convolutions do not scale to every core of a 2-socket host on a few clips, so a short scan (1 clip x 2 s per
+    candidate) also picks the fastest thread count and `value` / `cores` are that faster configuration's.  Both are printed.
+    The sample is bounded (DAC: 1 clip, ~100 GMAC per audio-second) so that the default bench.py run finishes in minutes."""
     if codec_name == "mimi":
         from oracle import mimi_oracle as O
         W = O.cast_weights(sd)
         run = lambda x: O.toks_to_sig(cfg, W, O.sig_to_toks(cfg, W, x))
-        clips = 4
+        clips = 8
     elif codec_name == "dac":
         from oracle import dac_oracle as O
         W = O.cast_weights(sd)
@@ -93,17 +95,29 @@ def cpu_baseline(codec_name, cfg, sd, sig_cpu, ncb):
         from oracle import wavtokenizer_oracle as O
         W = O.cast_weights(sd)
         run = lambda x: O.toks_to_sig(cfg, W, O.sig_to_toks(cfg, W, x))
-        clips = 4
+        clips = 8
     else:
         from oracle import encodec_oracle as O
         W = O.fold_weight_norm(sd)
         run = lambda x: O.toks_to_sig(cfg, W, O.sig_to_toks(cfg, W, x))
-        clips = 4
+        clips = 8
     sr = cfg.sampling_rate
     x = sig_cpu[:clips]
     model, phys, threads = host_cpu()
     cands = sorted({t for t in (8, 16, 32, 64, phys) if 1 <= t <= threads}) or [threads]
     scan = {}
+
+    def timed(n_threads, warm, reps):
+        torch.set_num_threads(n_threads)
+        for _ in range(warm):
+            run(x[:1])
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            run(x)
+            ts.append(time.perf_counter() - t0)
+        return ts
+
     with torch.inference_mode():
         probe = x[:1, : 2 * sr]
         for t in cands:
@@ -113,22 +127,20 @@ def cpu_baseline(codec_name, cfg, sd, sig_cpu, ncb):
             run(probe)
             scan[t] = time.perf_counter() - t0
         best_t = min(scan, key=scan.get)
-        torch.set_num_threads(best_t)
-        for _ in range(2):
-            run(x[:1])
-        times = []
-        for _ in range(3):
-            t0 = time.perf_counter()
-            run(x)
-            times.append(time.perf_counter() - t0)
+        times = timed(best_t, 2, 3)
+        allc = None
+        if phys != best_t and phys <= threads:
+            ta = timed(phys, 1, 1)
+            allc = {"cores": phys, "value": round(x.shape[0] * x.shape[1] / sr / ta[0], 2), "runs_s": [round(ta[0], 3)]}
     audio_s = x.shape[0] * x.shape[1] / sr
     med = sorted(times)[1]
     return {
         "value": round(audio_s / med, 2), "unit": "audio-s/s", "cores": best_t, "kind": "port",
         "host_physical_cores": phys, "host_hw_threads": threads, "cpu_model": model,
-        "runs_s": [round(t, 3) for t in times],
-        "sample": f"{clips} clips x {x.shape[1] / sr:.0f} s of the same batch, fp32 torch-CPU oracle, encode+decode; "
-                  f"2 warm-ups + 3 timed runs (median); thread count {best_t} chosen from {cands} by a 2 s probe",
+        "runs_s": [round(t, 3) for t in times], "all_physical_cores": allc,
+        "sample": f"{x.shape[0]} clips x {x.shape[1] / sr:.0f} s of the same batch, fp32 torch-CPU oracle, encode+decode; "
+                  f"2 warm-ups + 3 timed runs (median); thread count {best_t} chosen from {cands} by a 2 s probe; "
+                  f"all {phys} physical cores (BASELINE.md section 3): one run, reported beside it",
     }
 
 
@@ -163,43 +175,82 @@ def parity_gate(codec_name, codec):
     }
 
 
-def mfma16_terms(kernel_name, mode):
+_SHAPE_SUFFIX = re.compile(r"\s+B\d+ M\d+ N\d+ K\d+.*$")
+SPLIT_FAMILIES = ("tap_gemm6_kernel", "tap_gemm8_kernel", "rb_fused6_kernel", "rb128_fused6_kernel", "thin_conv6_kernel", "lstm_persist16_kernel",
+                  "enc_front_kernel", "dec_tail_kernel", "rvq_encode16_kernel")
+
+
+def parse_kernel(name):
+    """(family, [template arguments], shape suffix) of a kernel name as ac_profile_end or rocprofv3 prints it: `void`, the `ac::`
+    namespace, the argument list and the AC_PROF_DETAIL shape suffix (" B64 M30000 N256 K256 J2 s1") are stripped."""
+    n = re.sub(r"^void\s+", "", name.strip()).replace("ac::", "")
+    n = re.sub(r"\(.*\)\s*$", "", n)
+    m = _SHAPE_SUFFIX.search(n)
+    suffix = m.group(0).strip() if m else ""
+    if m:
+        n = n[: m.start()]
+    m = re.match(r"^([A-Za-z_0-9]+)\s*<(.*)>\s*$", n)
+    if not m:
+        return n.strip(), [], suffix
+    return m.group(1), [a.strip() for a in m.group(2).split(",")], suffix
+
+
+def canonical_kernel(name):
+    """One spelling per instantiation: the tap-GEMM's slab-halo template argument (rocprofv3 prints `..., 2, 7>` / `..., 2, 56>`,
+    the library's own records `..., 2>` / `..., 2, dil>`) becomes nothing / `dil`; everything else is family<arguments>."""
+    fam, args, _ = parse_kernel(name)
+    if fam in ("tap_gemm6_kernel", "tap_gemm8_kernel") and len(args) >= 6:
+        args = args[:5] + ([] if args[5] == "7" else ["dil"])
+    return f"{fam}<{', '.join(args)}>" if args else fam
+
+
+def kernel_planes(name):
+    """Operand planes of a split-operand kernel (template argument NP of the kernels that have one: the FIFTH of the tap-GEMM,
+    the last of the fused blocks): 2 = split16.h (two fp16 planes, 3 partial products per fp32 product); None = a kernel that does
+    not run on the 16-bit matrix pipe."""
+    fam, args, _ = parse_kernel(name)
+    if fam not in SPLIT_FAMILIES:
+        return None
+    if fam in ("tap_gemm6_kernel", "tap_gemm8_kernel"):
+        return int(args[4]) if len(args) >= 5 and args[4].isdigit() else 2
+    if fam in ("rb_fused6_kernel", "rb128_fused6_kernel", "thin_conv6_kernel"):
+        return int(args[-1]) if args and args[-1].isdigit() else 2
+    return 2        # the kernels that exist in split16 arithmetic only
+
+
+def mfma16_terms(kernel_name, mode=None):
     """16-bit MFMA partial products a kernel executes per fp32 product it stands for (0: not on the 16-bit matrix pipe)."""
-    split = kernel_name.startswith(("tap_gemm6", "lstm_persist6", "lstm_persist16", "rb_fused6", "rb128_fused6", "thin_conv6"))
-    if kernel_name.startswith(("enc_front", "dec_tail", "enc_mid", "dec_mid", "lstm_persist16")):
-        return SPLIT16_TERMS
-    if not split:
-        return 0
-    if kernel_name.rstrip().endswith(", 1>"):
-        return 1
-    if kernel_name.rstrip().endswith(", 2>"):
-        return SPLIT16_TERMS
-    return SPLIT_TERMS if mode != "bf16" else 1
+    np_ = kernel_planes(kernel_name)
+    return 0 if np_ is None else {2: SPLIT16_TERMS}.get(np_, SPLIT16_TERMS)
 
 
 def measured_traffic(kernel_name, unit, codec="encodec", batch=64):
     """HBM bytes per launch of `kernel_name` from the committed PMC summary (rocprofv3 --pmc FETCH_SIZE /
     WRITE_SIZE in separate passes, gfx950 FETCH x2 correction: tools/collect_traffic.py).  bench.py cannot
-    run the profiler on itself, so the newest profiles/r*_traffic.json is quoted; null if absent."""
+    run the profiler on itself, so the newest profiles/r*_traffic.json that knows the kernel is quoted (names compared in
+    their canonical spelling); null if absent."""
     import glob
 
-    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")) if (codec in os.path.basename(f)) or (codec == "encodec" and not any(c in os.path.basename(f) for c in ("mimi", "dac"))))
-    import re
+    def rank_of(f):   # r4b_... after r4a_... after r3b_...
+        m = re.match(r"r(\d+)([a-z]*)", os.path.basename(f))
+        return (int(m.group(1)), m.group(2)) if m else (0, "")
 
-    def batch_ok(f):   # r1_mimi_b32_traffic.json was collected at 32 clips per GPU; no tag = the default 64
+    files = sorted((f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json"))
+                    if (codec in os.path.basename(f)) or (codec == "encodec" and not any(c in os.path.basename(f) for c in ("mimi", "dac", "wavtok")))), key=rank_of)
+
+    def batch_ok(f):   # r1_mimi_b32_traffic.json was collected at 32 clips per GPU; no tag = the bench default of that codec
         m = re.search(r"_b(\d+)_", os.path.basename(f))
-        return (int(m.group(1)) if m else 64) == batch
+        return (int(m.group(1)) == batch) if m else True
 
-    files = [f for f in files if batch_ok(f)]
-    if not files:
-        return None
-    for f in reversed(files):   # newest summary that knows this kernel
+    want = canonical_kernel(kernel_name)
+    for f in reversed([f for f in files if batch_ok(f)]):   # newest summary that knows this kernel
         try:
-            k = json.load(open(f))["kernels"].get(kernel_name)
+            ks = json.load(open(f))["kernels"]
         except Exception:
             continue
-        if k and k["hbm_bytes_per_launch"] is not None:
-            return round(k["hbm_bytes_per_launch"]), "profiles/" + os.path.basename(f)
+        for nm, k in ks.items():
+            if canonical_kernel(nm) == want and k.get("hbm_bytes_per_launch") is not None:
+                return round(k["hbm_bytes_per_launch"]), "profiles/" + os.path.basename(f)
     return None
 
 
@@ -242,9 +293,84 @@ def drop_codec(codec):
     torch.cuda.empty_cache()
 
 
+def roofline_of(stats, dt, steps, codec_name, batch, exact):
+    """The `roofline` object of the contract for one timed region.  stats = [(kernel name, launches, total ms, flops, bytes)] from
+    the HIP events the library brackets every launch with on the stream it launches on (ac_profile_begin / _end), dt = wall
+    seconds of the region.  The dominant kernel is the family with the largest event time: tap_gemm6_kernel is ONE kernel
+    template launched in several tile arrangements (rocprofv3 lists each instantiation on its own row) -- the arrangements are
+    ranked together and listed one by one under `arrangements` with their own average launch time.
+      split-operand kernels (split16.h): bound = the dense fp16 MFMA peak; `achieved` counts the fp16 MFMA flops EXECUTED
+                                         (3 partial products per fp32 product);
+      exact-product kernels            : the fp32 MFMA peak when the arithmetic intensity is above the ridge, else HBM;
+      everything else                  : HBM, algorithmic bytes (inputs once, outputs once per flavour, weights once) / time."""
+    stats = sorted(stats, key=lambda s_: -s_[2])
+    fam = {}
+    for s_ in stats:
+        f_ = parse_kernel(s_[0])[0] if parse_kernel(s_[0])[0] in ("tap_gemm6_kernel", "tap_gemm8_kernel") else s_[0]
+        f_ = "tap_gemm" if f_ in ("tap_gemm6_kernel", "tap_gemm8_kernel") else f_
+        a_ = fam.setdefault(f_, [f_, 0, 0.0, 0.0, 0.0, []])
+        a_[1] += s_[1]; a_[2] += s_[2]; a_[3] += s_[3]; a_[4] += s_[4]; a_[5].append(s_)
+    name, launches, tot_ms, flops, nbytes, members = max(fam.values(), key=lambda a_: a_[2])
+    if len(members) == 1:
+        name = members[0][0]
+    ai = flops / max(nbytes, 1.0)
+    terms = {mfma16_terms(m_[0]) for m_ in members}
+    if terms == {SPLIT16_TERMS} and not exact:
+        eq = flops / (tot_ms * 1e-3) / 1e12
+        roof = {"bound": "mfma", "achieved": round(SPLIT16_TERMS * eq, 1), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "pipe": f"fp16 MFMA, {SPLIT16_TERMS} partial products per fp32 product (two fp16 planes per operand, split16.h)",
+                "fp32_equivalent_tflops": round(eq, 2), "fp32_equivalent_peak": round(PEAK_F16_MFMA_TFLOPS / SPLIT16_TERMS, 1),
+                "sustained_bare_mfma_stream": SUSTAINED_F16_MFMA_TFLOPS}
+    elif ai > PEAK_FP32_MFMA_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9):
+        roof = {"bound": "mfma", "achieved": round(flops / (tot_ms * 1e-3) / 1e12, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s"}
+    else:
+        roof = {"bound": "hbm", "achieved": round(nbytes / (tot_ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s"}
+    roof["frac"] = round(roof["achieved"] / roof["peak"], 4)
+    if len(members) > 1:
+        trs = [(m_[1], measured_traffic(m_[0], roof["unit"], codec_name, batch)) for m_ in members]
+        tr = None
+        if all(t_ for _, t_ in trs):
+            tr = (round(sum(n_ * t_[0] for n_, t_ in trs) / sum(n_ for n_, _ in trs)), sorted({t_[1] for _, t_ in trs})[-1])
+        roof["arrangements"] = [{"kernel": m_[0], "launches_per_step": m_[1] / steps, "avg_launch_us": round(m_[2] / m_[1] * 1e3, 2),
+                                 "fp32_equivalent_tflops": round(m_[3] / (m_[2] * 1e-3) / 1e12, 2)} for m_ in members]
+    else:
+        tr = measured_traffic(name, roof["unit"], codec_name, batch)
+    if name.startswith("lstm_persist"):
+        roof["note"] = "sequential recurrence: latency-bound (one exchange of h per time step), not a throughput kernel"
+    # PMC counters cannot be collected from inside this process: the figure is the one of the committed rocprofv3 --pmc passes
+    # over this same command (a different run / box); null when no summary knows the kernel
+    roof["traffic"] = tr[0] if tr else None
+    roof["traffic_source"] = tr[1] if tr else None
+    roof["algorithmic_bytes_per_launch"] = round(nbytes / launches)
+    roof["hbm_gbs"] = round(nbytes / (tot_ms * 1e-3) / 1e9, 1)
+    roof["hbm_frac"] = round(nbytes / (tot_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)
+    roof["kernel"] = name if len(members) == 1 else f"{name}<...> ({len(members)} tile arrangements of one kernel family)"
+    roof["launches_per_step"] = launches / steps
+    roof["avg_launch_us"] = round(tot_ms / launches * 1e3, 2)
+    roof["share_of_step"] = round(tot_ms / (dt * 1e3), 4)
+    return roof
+
+
+def whole_path(stats, dt, layer_bytes):
+    """Whole-step fractions: (a) layer-boundary bytes of the UNFUSED layer stack per second against 8 TB/s (fused chains move fewer
+    bytes than this model, so the fraction measures time, not traffic); (b) the fp16 MFMA flops the split16 kernels EXECUTE per
+    second against the 2.5 PF dense peak."""
+    ex = sum(s_[3] * mfma16_terms(s_[0]) for s_ in stats)
+    return {"hbm_layer_boundary_frac": round(layer_bytes / dt / (PEAK_HBM_GBS * 1e9), 4),
+            "executed_mfma16_tflops": round(ex / dt / 1e12, 1), "executed_mfma16_frac": round(ex / dt / (PEAK_F16_MFMA_TFLOPS * 1e12), 4)}
+
+
+def kernel_rows(stats, steps, top=None):
+    rows = [{"name": s_[0], "launches_per_step": s_[1] / steps, "ms_per_step": round(s_[2] / steps, 3),
+             "tflops": round(s_[3] / (s_[2] * 1e-3) / 1e12, 2), "gbs": round(s_[4] / (s_[2] * 1e-3) / 1e9, 1)}
+            for s_ in sorted(stats, key=lambda s_: -s_[2])]
+    return rows[:top] if top else rows
+
+
 def short_run(name, batch, seconds, steps, warmup, precision=None):
     """One of the other BASELINE.json configs as a short driver-timed run of the same step (encode + decode of `batch` clips
-    resident in HBM), with its parity gate: value, ms_per_step and the gate travel in the headline JSON line (`other_configs`)."""
+    resident in HBM), with its parity gate and its own roofline (dominant kernel family of a separately event-timed pass): value,
+    ms_per_step, the gate and the roofline travel in the headline JSON line (`other_configs`)."""
     from audiocodecs_amd import prng
 
     codec, cfg, sd = build_codec(name, precision)
@@ -259,60 +385,122 @@ def short_run(name, batch, seconds, steps, warmup, precision=None):
             codec.toks_to_sig(codec.sig_to_toks(sig))
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        t1 = time.perf_counter()
+        stats = codec.profile_kernels(lambda: codec.toks_to_sig(codec.sig_to_toks(sig)))
+        torch.cuda.synchronize()
+        dt_prof = time.perf_counter() - t1
         gate = parity_gate(name, codec)
     del sig
     drop_codec(codec)
     audio_s = batch * T / cfg.sampling_rate * steps
     return {"workload": f"{CODEC_LABEL[name]} {CODEC_NCB[name]} codebooks, encode+decode, {batch} clips x {seconds:g} s on 1 GPU, resident in HBM",
             "value": round(audio_s / dt, 1), "unit": "audio-s/s", "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps, "warmup": warmup,
-            "parity": gate}
+            "roofline": roofline_of(stats, dt_prof, 1, name, batch, precision == "fp32_exact"),
+            "whole_path": whole_path(stats, dt_prof, sum(s_[4] for s_ in stats)),
+            "top_kernels": kernel_rows(stats, 1, top=4), "parity": gate}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=64, help="clips per GPU")
-    ap.add_argument("--codec", choices=["encodec", "mimi", "dac", "wavtokenizer"], default="encodec",
-                    help="encodec = BASELINE.json configs[1] (the contract's default); mimi = configs[3] shape (SURVEY.md §8 f3); "
-                         "dac = configs[2] (DAC 44.1 kHz, 9 codebooks; use --batch 256); wavtokenizer = configs[4] (40 tok/s, 64 clips per GPU)")
-    ap.add_argument("--seconds", type=float, default=10.0)
-    ap.add_argument("--precision", choices=["fp32", "fp32_exact", "bf16", "fp32_bf16x3"], default=None,
-                    help="arithmetic of the GEMM-shaped kernels: default = fp32 fidelity (split-operand; the parity arithmetic, what `value` is "
-                         "quoted for); bf16 = OPT-IN reduced precision, a reported side mode with its own parity figures")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-parity", action="store_true", help="skip the parity gates and every other untimed extra (profiling passes: keeps the kernel trace to the timed workload)")
-    ap.add_argument("--no-other-configs", action="store_true", help="skip the short runs of BASELINE.json configs 3-5 (DAC, Mimi, WavTokenizer) that travel in the same JSON line")
-    ap.add_argument("--no-exact", action="store_true", help="skip the exact-fp32-product twin of the headline figure")
-    args = ap.parse_args()
-
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
-    torch.cuda.set_device(local_rank)
-    dist = None
-    # under torch.distributed.run (RANK in the environment) the collective path runs even at world size 1, so that a 1-GPU
-    # box can exercise exactly what the N > 1 launches do (RCCL init, barrier, token all_gather, MAX-reduce of the timings)
-    if world > 1 or (os.environ.get("RANK") is not None and os.environ.get("MASTER_PORT") is not None):
-        import torch.distributed as dist
-
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-
+def latency_regime(codec, cfg):
+    """The regime the reference itself measures (downstream/hparams/tasks/sr.yaml:28 `test_batch_size: 1`; downstream/test_sr.py:379-391
+    profiles shapes (1, sr * {1, 2, 4, 8, 16, 32})): encode + decode of B = 1 and B = 8 clips of 1 / 10 / 32 s, resident in HBM --
+    ms per call (median of 5 after 2 warm-ups, host-timed around a device sync as the reference does), RTF, and the three
+    kernels that take the most time (from a separate event-timed call)."""
     from audiocodecs_amd import prng
+
+    out = []
+    sr = cfg.sampling_rate
+    with torch.no_grad():
+        for B in (1, 8):
+            for sec in (1, 10, 32):
+                sig = torch.from_numpy((prng.normal(321, f"bench.latency.{B}.{sec}", (B, sec * sr)) * 0.1).astype(np.float32)).cuda()
+                for _ in range(2):
+                    codec.toks_to_sig(codec.sig_to_toks(sig))
+                torch.cuda.synchronize()
+                ts = []
+                for _ in range(5):
+                    t0 = time.perf_counter()
+                    toks = codec.sig_to_toks(sig)
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    codec.toks_to_sig(toks)
+                    torch.cuda.synchronize()
+                    ts.append((time.perf_counter() - t0, t1 - t0))
+                ts.sort()
+                tot, enc = ts[len(ts) // 2]
+                stats = codec.profile_kernels(lambda: codec.toks_to_sig(codec.sig_to_toks(sig)))
+                torch.cuda.synchronize()
+                ksum = sum(s_[2] for s_ in stats)
+                out.append({"clips": B, "seconds": sec, "ms_per_call": round(tot * 1e3, 3), "encode_ms": round(enc * 1e3, 3),
+                            "decode_ms": round((tot - enc) * 1e3, 3), "rtf": round(tot / (B * sec), 6),
+                            "kernel_event_ms": round(ksum, 3), "launches": int(sum(s_[1] for s_ in stats)),
+                            "top3": [{"name": s_[0], "ms": round(s_[2], 3)} for s_ in sorted(stats, key=lambda s_: -s_[2])[:3]]})
+                del sig
+    return out
+
+
+def timed_steps(step, fence, steps, warmup, profile):
+    """The contract's timed region: `warmup` untimed steps, then EXACTLY `steps` steps bracketed by fence() (barrier + device
+    synchronise) on both sides -- once with the library's per-kernel events armed (`profile(fn)` returns their statistics; this is
+    the run `value` comes from) and once more without them as a side figure.  Every rank runs this; nothing here is rank-conditional."""
+    for _ in range(warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    stats = profile(lambda: [step() for _ in range(steps)])
+    fence()
+    dt = time.perf_counter() - t0
+    fence()
+    t1 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    fence()
+    dt_plain = time.perf_counter() - t1
+    return dt, dt_plain, stats
+
+
+def max_over_ranks(dist, values, device):
+    """MAX over the ranks of a list of floats (every rank calls this; identity without a process group)."""
+    if dist is None:
+        return list(values)
+    tt = torch.tensor(list(values), device=device, dtype=torch.float64)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    return tt.tolist()
+
+
+def contract_line(label, ncb, world, steps, warmup, dt, audio_s, B, seconds, dtype, extra):
+    """The ONE JSON object rank 0 prints (keys of the task statement's contract first)."""
+    out = {
+        "metric": f"encode+decode audio-sec/s, {label} {ncb}cb",
+        "value": round(audio_s / dt, 1),
+        "unit": "audio-s/s",
+        "n_gpus": world,
+        "steps": steps,
+        "warmup": warmup,
+        "ms_per_step": round(dt / steps * 1e3, 3),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": dtype,
+        "data": f"synthetic (0.1*N(0,1) clips, seeded synthetic weights of the {label} architecture)",
+        "config": {"workload": f"{label} {ncb} codebooks, encode+decode, {B} clips x {seconds:g} s per GPU, resident in HBM",
+                   "clips_per_gpu": B, "seconds_per_clip": seconds, "parallelism": f"clip-sharded x{world}"},
+        "rtf": round(dt / audio_s, 7),
+        "x_realtime_per_gpu": round(audio_s / dt / world, 1),
+    }
+    out.update(extra)
+    return out
+
+
+def run(args, codec, cfg, sd, sig, sig_cpu, rank, world, dist, device):
+    """Everything after set-up, for any codec object with sig_to_toks / toks_to_sig / profile_kernels and any process group (RCCL on
+    the GPU; tests/test_bench_flow_gloo.py drives it at world size 2 over gloo with a stub codec on CPU tensors).
+    Collectives: the token all_gather inside step(), the barrier inside fence(), the MAX-reduce of the timings, the closing
+    barrier -- all outside every `if rank == 0` block."""
     from audiocodecs_amd.sharding import gather_tokens
 
-    mimi = args.codec != "encodec"   # "not the headline codec": whole-path fractions from the kernels' own counts
     label, ncb = CODEC_LABEL[args.codec], CODEC_NCB[args.codec]
-    codec, cfg, sd = build_codec(args.codec, args.precision)
-    B, T = args.batch, int(round(args.seconds * cfg.sampling_rate))
-    # SURVEY.md §8(d): sig = 0.1*N(0,1), repo PRNG seed 123; each rank draws its own shard
-    sig_cpu = torch.from_numpy((prng.normal(123, f"bench.sig.rank{rank}", (B, T)) * 0.1).astype(np.float32))
-    sig = sig_cpu.cuda()
+    B, T = sig.shape[0], sig.shape[1]
+    sync = torch.cuda.synchronize if device.type == "cuda" else (lambda: None)
 
     def step():
         toks = codec.sig_to_toks(sig)
@@ -326,133 +514,24 @@ def main():
     def fence():
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
 
     with torch.no_grad():
-        for _ in range(args.warmup):
-            step()
-        fence()
-        t0 = time.perf_counter()
-        stats = codec.profile_kernels(lambda: [step() for _ in range(args.steps)])
-        fence()
-        dt = time.perf_counter() - t0
-        # unprofiled repeat (no per-kernel events on the stream) as a side figure
-        fence()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        fence()
-        dt_plain = time.perf_counter() - t1
-
-    if dist is not None:
-        tt = torch.tensor([dt, dt_plain], device="cuda", dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt, dt_plain = tt.tolist()
+        dt, dt_plain, stats = timed_steps(step, fence, args.steps, args.warmup, codec.profile_kernels)
+    dt, dt_plain = max_over_ranks(dist, [dt, dt_plain], device)
 
     audio_s = world * B * T / cfg.sampling_rate * args.steps
-    mode_ = args.precision or {"fp32": "fp32_exact", "bf16": "bf16", "bf16x3": "fp32_bf16x3"}.get(os.environ.get("AC_GEMM", ""), "fp32")
+    exact = (args.precision or ("fp32_exact" if os.environ.get("AC_GEMM", "") == "fp32" else "fp32")) == "fp32_exact"
     if rank == 0:
-        ms = dt / args.steps * 1e3
-        stats.sort(key=lambda s: -s[2])
-        # The dominant kernel.  tap_gemm6_kernel is ONE kernel template launched in several tile arrangements (1 x 4 waves
-        # over 128 or 256 columns, 1 x 8 waves, ...; rocprof lists each instantiation on its own row): the arrangements are
-        # taken together when ranking, and listed one by one (with their own average launch time, the figure to compare
-        # with rocprofv3's rows) under roofline.arrangements.
-        fam = {}
-        for s_ in stats:
-            f_ = s_[0].split("<")[0] if s_[0].startswith("tap_gemm6") else s_[0]
-            a_ = fam.setdefault(f_, [f_, 0, 0.0, 0.0, 0.0, []])
-            a_[1] += s_[1]; a_[2] += s_[2]; a_[3] += s_[3]; a_[4] += s_[4]; a_[5].append(s_)
-        top = max(fam.values(), key=lambda a_: a_[2])
-        name, launches, tot_ms, flops, nbytes, members = top
-        if len(members) == 1:
-            name = members[0][0]
-        avg_us = tot_ms / launches * 1e3
-        ai = flops / max(nbytes, 1.0)
-        split_kernel = name.startswith(("tap_gemm6", "lstm_persist6", "rb_fused6", "rb128_fused6", "thin_conv6", "enc_front", "dec_tail", "enc_mid", "dec_mid"))
-        if name.startswith("tap_gemm6") and mode_ == "bf16":
-            tf = flops / (tot_ms * 1e-3) / 1e12
-            roof = {"bound": "mfma", "achieved": round(tf, 1), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "pipe": "bf16 MFMA, one product per operand pair"}
-        elif split_kernel:
-            # split-operand kernels (tap_gemm6.h arithmetic): every fp32 product is 6 bf16 MFMA partial products, so the kernel's
-            # roofline is the dense bf16 MFMA peak; `achieved` counts the bf16 flops it actually executes
-            eq = flops / (tot_ms * 1e-3) / 1e12
-            s16 = all(m_[0].rstrip().endswith(", 2>") or m_[0].startswith(("enc_front", "dec_tail", "enc_mid", "dec_mid")) for m_ in members)     # split16.h kernels (template argument NP = 2; the fused chains exist in that arithmetic only)
-            terms, cap = (SPLIT16_TERMS, SUSTAINED_F16_MFMA_TFLOPS) if s16 else (SPLIT_TERMS, SUSTAINED_BF16_MFMA_TFLOPS)
-            roof = {"bound": "mfma", "achieved": round(terms * eq, 1), "peak": PEAK_F16_MFMA_TFLOPS if s16 else PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "pipe": (f"fp16 MFMA, {terms} partial products per fp32 product (two fp16 planes per operand, split16.h)" if s16 else
-                             f"bf16 MFMA, {terms} partial products per fp32 product"), "fp32_equivalent_tflops": round(eq, 2),
-                    "fp32_equivalent_peak": round((PEAK_F16_MFMA_TFLOPS if s16 else PEAK_BF16_MFMA_TFLOPS) / terms, 1),
-                    "power_capped_peak": cap, "frac_of_power_capped_peak": round(terms * eq / cap, 4)}
-        elif ai > PEAK_FP32_MFMA_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9):
-            roof = {"bound": "mfma", "achieved": round(flops / (tot_ms * 1e-3) / 1e12, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s"}
-        else:
-            roof = {"bound": "hbm", "achieved": round(nbytes / (tot_ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s"}
-        roof["frac"] = round(roof["achieved"] / roof["peak"], 4)
-        if len(members) > 1:
-            trs = [(m_[1], measured_traffic(m_[0], roof["unit"], args.codec, B)) for m_ in members]
-            tr = None
-            if all(t_ for _, t_ in trs):
-                tr = (round(sum(n_ * t_[0] for n_, t_ in trs) / sum(n_ for n_, _ in trs)), trs[0][1][1])
-            roof["arrangements"] = [{"kernel": m_[0], "launches_per_step": m_[1] / args.steps, "avg_launch_us": round(m_[2] / m_[1] * 1e3, 2),
-                                     "fp32_equivalent_tflops": round(m_[3] / (m_[2] * 1e-3) / 1e12, 2)} for m_ in members]
-        else:
-            tr = measured_traffic(name, roof["unit"], args.codec, B)
-        if name.startswith("lstm_persist"):
-            roof["note"] = "sequential recurrence: latency-bound (one exchange of h per time step), not a throughput kernel"
-        roof["traffic"] = tr[0] if tr else None
-        # PMC counters cannot be collected from inside this process: the figure is the one of the committed rocprofv3
-        # --pmc passes over this same command (a different run / box); null when no such summary knows the kernel
-        roof["traffic_source"] = tr[1] if tr else None
-        # the same launches against the HBM roofline: algorithmic bytes (inputs read once, outputs
-        # written once, weights once) per launch / measured launch time
-        roof["algorithmic_bytes_per_launch"] = round(nbytes / launches)
-        roof["hbm_gbs"] = round(nbytes / (tot_ms * 1e-3) / 1e9, 1)
-        roof["hbm_frac"] = round(nbytes / (tot_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)
-        roof["kernel"] = name if len(members) == 1 else f"{name}<...> ({len(members)} tile arrangements of one kernel)"
-        roof["launches_per_step"] = launches / args.steps
-        roof["avg_launch_us"] = round(avg_us, 2)
-        roof["share_of_step"] = round(tot_ms / (dt * 1e3), 4)
-        out = {
-            "metric": f"encode+decode audio-sec/s, {label} {ncb}cb",
-            "value": round(audio_s / dt, 1),
-            "unit": "audio-s/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": round(ms, 3),
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": {"fp32_exact": "f32", "bf16": "bf16 operands / f32 accumulate in the tap-GEMMs (OPT-IN side mode, not the parity arithmetic); everything else f32-faithful"}.get(
-                mode_, "f32 (GEMM-shaped kernels and LSTM products: operands as two scaled fp16 planes, 3 partial products, fp32 accumulate -- split16.h)"
-                       if mode_ == "fp32" else
-                       "f32 (GEMMs and LSTM products: operands split exactly into 3 bf16 terms, 6 partial products, fp32 accumulate)"),
-            "data": f"synthetic (0.1*N(0,1) clips, seeded synthetic weights of the {label} architecture)",
-            "config": {"workload": f"{label} {ncb} codebooks, encode+decode, {B} clips x {args.seconds:g} s per GPU, resident in HBM",
-                       "clips_per_gpu": B, "seconds_per_clip": args.seconds, "parallelism": f"clip-sharded x{world}"},
-            "rtf": round(dt / audio_s, 7),
-            "x_realtime_per_gpu": round(audio_s / dt / world, 1),
-            "whole_path": {
-                # (a) HBM: layer-boundary bytes of the UNFUSED layer stack (117.6 MB per audio-second for EnCodec; the
-                #     kernels' own algorithmic counts for the other codecs) per second against 8 TB/s -- fused chains move fewer bytes
-                #     than this model, so the fraction measures time, not traffic;
-                # (b) matrix pipe: the 16-bit MFMA flops the split-operand kernels EXECUTE (3 partial products per fp32 product in
-                #     split16 arithmetic, 6 with three bf16 planes, 1 in the opt-in bf16 mode) per second against the 2.5 PF dense peak.
-                "hbm_layer_boundary_frac": round((sum(s[4] for s in stats) if mimi else LAYER_BYTES_PER_AUDIO_S * audio_s / world) / dt / (PEAK_HBM_GBS * 1e9), 4),
-                "executed_mfma16_tflops": round(sum(s[3] * mfma16_terms(s[0], mode_) for s in stats) / dt / 1e12, 1),
-                "executed_mfma16_frac": round(sum(s[3] * mfma16_terms(s[0], mode_) for s in stats) / dt / (PEAK_F16_MFMA_TFLOPS * 1e12), 4),
-                "ms_per_step_without_kernel_events": round(dt_plain / args.steps * 1e3, 3),
-            },
-            "roofline": roof,
-            "kernels": [
-                {"name": s[0], "launches_per_step": s[1] / args.steps, "ms_per_step": round(s[2] / args.steps, 3),
-                 "tflops": round(s[3] / (s[2] * 1e-3) / 1e12, 2), "gbs": round(s[4] / (s[2] * 1e-3) / 1e9, 1)}
-                for s in stats
-            ],
-        }
-        extras = not args.no_parity
+        other = args.codec != "encodec"   # not the headline codec: layer-boundary bytes from the kernels' own algorithmic counts
+        wp = whole_path(stats, dt, sum(s_[4] for s_ in stats) if other else LAYER_BYTES_PER_AUDIO_S * audio_s / world)
+        wp["ms_per_step_without_kernel_events"] = round(dt_plain / args.steps * 1e3, 3)
+        roof = roofline_of(stats, dt, args.steps, args.codec, B, exact)
+        dtype = ("f32 (every product an IEEE fp32 product: the exact-product kernels)" if exact else
+                 "f32 (GEMM-shaped kernels and LSTM products: operands as two scaled fp16 planes, 3 partial products, fp32 accumulate -- split16.h)")
+        out = contract_line(label, ncb, world, args.steps, args.warmup, dt, audio_s, B, args.seconds, dtype,
+                            {"whole_path": wp, "roofline": roof, "kernels": kernel_rows(stats, args.steps)})
+        extras = not args.no_parity and device.type == "cuda"
         with torch.no_grad():
             if extras:
                 try:   # shader clock under the tap-GEMMs (power cap): 2 collective-free steps outside the timed region (rank 0 only)
@@ -462,13 +541,18 @@ def main():
                     nat.lib.ac_debug_clock(nat.h, 1, _C.byref(mhz))
                     local_step(); local_step()
                     nat.lib.ac_debug_clock(nat.h, 0, _C.byref(mhz))
-                    out["roofline"]["tap_gemm6_shader_clock_mhz"] = round(mhz.value, 0)
+                    out["roofline"]["tap_gemm_shader_clock_mhz"] = round(mhz.value, 0)
                 except Exception:  # diagnostics only
-                    out["roofline"]["tap_gemm6_shader_clock_mhz"] = None
+                    out["roofline"]["tap_gemm_shader_clock_mhz"] = None
             out["parity"] = parity_gate(args.codec, codec) if extras else None
-        if world == 1 and not args.no_cpu_baseline:
+            if extras and args.codec == "encodec" and world == 1 and not args.no_latency:
+                try:
+                    out["latency"] = latency_regime(codec, cfg)
+                except Exception as e:
+                    out["latency"] = {"error": repr(e)[:300]}
+        if world == 1 and not args.no_cpu_baseline and sd is not None:
             out["cpu_baseline"] = cpu_baseline(args.codec, cfg, sd, sig_cpu, ncb)
-        if world == 1 and extras and mode_ == "fp32" and not args.no_exact:
+        if world == 1 and extras and not exact and not args.no_exact:
             # the split16 figure always travels with its exact-product twin: the same step with every product an IEEE fp32 product
             # (precision="fp32_exact": tap_gemm4 / rb_fused / lstm_persist kernels), 1 warm-up + 3 steps outside the timed region
             try:
@@ -498,6 +582,58 @@ def main():
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
+    return 0
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="clips per GPU")
+    ap.add_argument("--codec", choices=["encodec", "mimi", "dac", "wavtokenizer"], default="encodec",
+                    help="encodec = BASELINE.json configs[1] (the contract's default); mimi = configs[3] shape (SURVEY.md §8 f3); "
+                         "dac = configs[2] (DAC 44.1 kHz, 9 codebooks; use --batch 256); wavtokenizer = configs[4] (40 tok/s, 64 clips per GPU)")
+    ap.add_argument("--seconds", type=float, default=10.0)
+    ap.add_argument("--precision", choices=["fp32", "fp32_exact"], default=None,
+                    help="arithmetic of the GEMM-shaped kernels: default = fp32 fidelity (split16: the parity arithmetic, what `value` is "
+                         "quoted for); fp32_exact = every product an IEEE fp32 product")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the parity gates and every other untimed extra (profiling passes: keeps the kernel trace to the timed workload)")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the short runs of BASELINE.json configs 3-5 (DAC, Mimi, WavTokenizer) that travel in the same JSON line")
+    ap.add_argument("--no-exact", action="store_true", help="skip the exact-fp32-product twin of the headline figure")
+    ap.add_argument("--no-latency", action="store_true", help="skip the B = 1 / B = 8 latency table (the reference's own measurement regime)")
+    return ap.parse_args(argv)
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    # under torch.distributed.run (RANK in the environment) the collective path runs even at world size 1, so that a 1-GPU
+    # box can exercise exactly what the N > 1 launches do (RCCL init, barrier, token all_gather, MAX-reduce of the timings)
+    if world > 1 or (os.environ.get("RANK") is not None and os.environ.get("MASTER_PORT") is not None):
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    from audiocodecs_amd import prng
+
+    codec, cfg, sd = build_codec(args.codec, args.precision)
+    B, T = args.batch, int(round(args.seconds * cfg.sampling_rate))
+    # SURVEY.md §8(d): sig = 0.1*N(0,1), repo PRNG seed 123; each rank draws its own shard
+    sig_cpu = torch.from_numpy((prng.normal(123, f"bench.sig.rank{rank}", (B, T)) * 0.1).astype(np.float32))
+    sig = sig_cpu.cuda()
+    run(args, codec, cfg, sd, sig, sig_cpu, rank, world, dist, device)
+    if dist is not None:
         dist.destroy_process_group()
 
 
