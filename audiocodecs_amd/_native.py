@@ -165,6 +165,7 @@ EXPORTS = {
     "ac_debug_trace": (_i, [_vp, C.POINTER(C.c_ulonglong), _i]),
     "ac_debug_split_row": (_i, [_vp, _i, _vp, _vp]),
     "ac_debug_capture": (_i, [_vp, _vp, _sz]),
+    "ac_debug_set": (_i, [_vp, C.c_char_p, _i]),
     "ac_debug_captured": (_sz, [_vp]),
     "ac_lstm_status": (_i, [_vp]),
     "ac_poll_status": (_i, [_vp, _vp]),
@@ -172,7 +173,7 @@ EXPORTS = {
     "ac_destroy": (None, [_vp]),
 }
 
-PRECISIONS = {"fp32": 0, "fp32_exact": 1, "bf16": 2, "fp32_bf16x3": 3}   # AC_PRECISION_*
+PRECISIONS = {"fp32": 0, "fp32_exact": 1}   # AC_PRECISION_*
 
 
 def check_precision(precision):
@@ -182,12 +183,22 @@ def check_precision(precision):
 
 
 def set_precision(L, h, precision) -> None:
-    """precision: None (library default / AC_GEMM), "fp32" (split-operand, fp32 fidelity), "fp32_exact", "bf16" (opt-in)."""
+    """precision: None (library default / AC_GEMM), "fp32" (split16: fp32 fidelity on the fp16 matrix pipe), "fp32_exact" (IEEE fp32 products)."""
     if precision is None:
         return
     if precision not in PRECISIONS:
         raise ValueError(f"`precision` ({precision}) must be one of {list(PRECISIONS)}")
     check(L.ac_set_precision(h, PRECISIONS[precision]), h, "ac_set_precision")
+
+
+def debug_set(codec, key: str, value: int) -> None:
+    """Developer / test switch on every live handle of a wrapper (include/audiocodecs_amd.h ac_debug_set).  Handles are created
+    lazily per device: call the wrapper (or `codec._native_for(tensor)`) first.  Switches start from the environment variables of
+    the same meaning, which the library reads once per handle at ac_finalize."""
+    if not codec._natives:
+        raise NativeError("debug_set: the wrapper has no handle yet (call it, or _native_for(tensor), first)")
+    for nat in codec._natives.values():
+        check(nat.lib.ac_debug_set(nat.h, key.encode(), int(value)), nat.h, "ac_debug_set")
 
 
 _lib = None

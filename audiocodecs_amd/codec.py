@@ -54,12 +54,14 @@ class Codec(torch.nn.Module, ABC):
 
     def _polled(self, out):
         """strict mode: surface device-side failures of the call that just ran (ac_poll_status synchronises the stream)."""
-        if self.strict and out.is_cuda:
-            nat = getattr(self, "_natives", {}).get(out.device.index)
+        first = out[0] if isinstance(out, (tuple, list)) and out else out      # (a wrapper method may return several tensors)
+        if self.strict and isinstance(first, torch.Tensor) and first.is_cuda:
+            out_dev = first.device
+            nat = getattr(self, "_natives", {}).get(out_dev.index)
             if nat is not None:
                 from . import _native
 
-                with torch.cuda.device(out.device):
+                with torch.cuda.device(out_dev):
                     stream = torch.cuda.current_stream().cuda_stream
                     _native.check(nat.lib.ac_poll_status(nat.h, stream), nat.h, "ac_poll_status")
         return out

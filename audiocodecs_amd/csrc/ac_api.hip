@@ -8,7 +8,7 @@
 // ---------------------------------------------------------------------------------------------
 extern "C" {
 
-int ac_version(void) { return 310; }   // 310: split16 arithmetic (AC_PRECISION_FP32_BF16X3 beside it), ac_debug_split_row
+int ac_version(void) { return 400; }   // 400: split16 and exact-fp32 arithmetic only (the bf16x3 / bf16 modes are gone)
 
 int ac_create(const ac_config* cfg, ac_handle** out) {
     if (!cfg || !out) return AC_EINVAL;
@@ -61,10 +61,41 @@ int ac_load_weights(ac_handle* h, const char* name, const void* host_ptr, size_t
 
 
 
+// the developer switches of ac_handle::dev, read from the environment exactly once per handle (here, from ac_finalize)
+static void latch_dev_switches(ac_handle* h) {
+    auto num = [](const char* name, int dflt) { const char* v = std::getenv(name); return v && *v ? std::atoi(v) : dflt; };
+    const char* e = std::getenv("AC_TAP_EPI");
+    h->dev.tap_epi_staged = e && std::strcmp(e, "staged") == 0;
+    h->dev.tap_dil = num("AC_TAP_DIL", 1);
+    h->dev.tap_stagger = num("AC_TAP_STAGGER", 0);
+    h->dev.tap_pick = num("AC_TAP_PICK", -1);
+    h->dev.rb6_dbg = num("AC_RB6_DBG", 0);
+    h->dev.front_seg = std::max(0, num("AC_FRONT_SEG", 0));
+    h->dev.tail_seg = std::max(0, num("AC_TAIL_SEG", 0));
+    h->dev.front_ldspad = std::max(0, num("AC_FRONT_LDSPAD", 0));
+    h->dev.lstm_dbg = num("AC_LSTM_DBG", 0);
+    h->dev.lstm_fuse_in = num("AC_LSTM_FUSE_IN", 1);
+    const char* r = std::getenv("AC_RVQ");
+    h->dev.rvq_exact = r && std::strcmp(r, "fp32") == 0;
+    h->dev.prof_detail = num("AC_PROF_DETAIL", 0);
+}
+
+int ac_debug_set(ac_handle* h, const char* key, int value) {
+    if (!h || !key) return AC_EINVAL;
+    struct { const char* k; int* v; } tab[] = {
+        {"tap_epi_staged", &h->dev.tap_epi_staged}, {"tap_dil", &h->dev.tap_dil}, {"tap_stagger", &h->dev.tap_stagger}, {"tap_pick", &h->dev.tap_pick},
+        {"rb6_dbg", &h->dev.rb6_dbg}, {"front_seg", &h->dev.front_seg}, {"tail_seg", &h->dev.tail_seg}, {"front_ldspad", &h->dev.front_ldspad},
+        {"lstm_dbg", &h->dev.lstm_dbg}, {"lstm_fuse_in", &h->dev.lstm_fuse_in}, {"rvq_exact", &h->dev.rvq_exact}, {"prof_detail", &h->dev.prof_detail},
+    };
+    for (auto& t : tab)
+        if (std::strcmp(t.k, key) == 0) { *t.v = value; return AC_OK; }
+    return fail(h, AC_EINVAL, "ac_debug_set: unknown switch '%s'", key);
+}
+
 int ac_set_precision(ac_handle* h, int precision) {
     if (!h) return AC_EINVAL;
     if (h->finalized) return fail(h, AC_ESTATE, "ac_set_precision must precede ac_finalize (weights are packed for one arithmetic)");
-    if (precision < AC_PRECISION_FP32 || precision > AC_PRECISION_FP32_BF16X3) return fail(h, AC_EINVAL, "unknown precision %d", precision);
+    if (precision != AC_PRECISION_FP32 && precision != AC_PRECISION_FP32_EXACT) return fail(h, AC_EINVAL, "unknown precision %d", precision);
     h->precision = precision;
     return AC_OK;
 }
@@ -72,18 +103,16 @@ int ac_set_precision(ac_handle* h, int precision) {
 int ac_finalize(ac_handle* h) {
     if (!h) return AC_EINVAL;
     if (h->finalized) return fail(h, AC_ESTATE, "handle already finalized");
-    {   // arithmetic of the GEMM-shaped kernels: ac_set_precision, else the environment variable AC_GEMM (fp32 | bf16)
+    {   // arithmetic of the GEMM-shaped kernels: ac_set_precision, else the environment variable AC_GEMM (fp32)
         int pr = h->precision;
         if (pr < 0) {
             const char* gm = std::getenv("AC_GEMM");
-            pr = gm && std::strcmp(gm, "fp32") == 0 ? AC_PRECISION_FP32_EXACT : gm && std::strcmp(gm, "bf16") == 0 ? AC_PRECISION_BF16 :
-                 gm && std::strcmp(gm, "bf16x3") == 0 ? AC_PRECISION_FP32_BF16X3 : AC_PRECISION_FP32;
+            pr = gm && std::strcmp(gm, "fp32") == 0 ? AC_PRECISION_FP32_EXACT : AC_PRECISION_FP32;
         }
         const char* fz = std::getenv("AC_FUSE");
         h->fuse_chains = !(fz && fz[0] == '0');
+        latch_dev_switches(h);
         h->gemm_fp32 = pr == AC_PRECISION_FP32_EXACT;
-        h->gemm_bf16 = pr == AC_PRECISION_BF16;
-        h->split16 = pr == AC_PRECISION_FP32;
     }
     if (h->arch == ARCH_MIMI) {
         Packer pk{h};
@@ -577,8 +606,7 @@ size_t ac_debug_captured(const ac_handle* h) { return h ? h->dbg_used : 0; }
 int ac_profile_begin(ac_handle* h) {
     if (!h) return AC_EINVAL;
     h->prof = true;
-    const char* det = std::getenv("AC_PROF_DETAIL");
-    h->prof_detail = det && det[0] == '1';
+    h->prof_detail = h->dev.prof_detail != 0;
     h->recs.clear();
     h->ev_used = 0;
     return AC_OK;

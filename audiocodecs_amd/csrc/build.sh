@@ -4,13 +4,17 @@
 # -fno-slp-vectorize: the SLP vectoriser turns the stem's scalar fp32 FMAs (enc_front.h) into v_pk_fma_f32 with op_sel
 # broadcasts, and THAT code returned wrong values in lanes 48..63 of one FMA group per ~100 chunks whenever a second wave shared the
 # SIMD (run-to-run different; never with one wave per SIMD, never without the packed FMAs -- profiles/r3_pk_fma_hazard.md).
-# The flag costs the other kernels nothing measurable (19.2 -> 19.5 ms per step, inside the box-to-box spread).
+# The flag costs the other kernels nothing measurable (19.2 -> 19.5 ms per step, inside the box-to-box spread).  The stem itself no
+# longer depends on it (fma_pinned, split16.h) and check_isa.sh disassembles the result: a packed fp32 FMA or scratch in the fused
+# chains fails the build.
+# -fno-strict-aliasing: the fused chains view one LDS region through differently typed pointers (fp16 planes, fp32 rows, dec_tail.h /
+# enc_front.h); the hand-overs carry compiler fences, and with this flag correctness does not rest on their placement.
 set -euo pipefail
 here="$(cd "$(dirname "$0")" && pwd)"
 out="${AC_OUT:-$here/../libaudiocodecs_amd.so}"     # AC_OUT / AC_OBJ: developer builds beside the product (timing variants)
 obj="${AC_OBJ:-$here/build}"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -fPIC -Wall -Wno-unused-function -I"$here/../../include" "$@")
+FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -fno-strict-aliasing -fPIC -Wall -Wno-unused-function -I"$here/../../include" "$@")
 mkdir -p "$obj"
 pids=()
 for tu in core mimi_path dac_path wavtok_path ac_api; do
@@ -20,3 +24,4 @@ done
 for p in "${pids[@]}"; do wait "$p"; done
 "$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$out" "$obj"/core.o "$obj"/mimi_path.o "$obj"/dac_path.o "$obj"/wavtok_path.o "$obj"/ac_api.o
 echo "built $out"
+bash "$here/check_isa.sh" "$out"

@@ -1,0 +1,36 @@
+#!/bin/bash
+# ISA checks on the built library (called by build.sh; fails the build).  Usage: check_isa.sh <libaudiocodecs_amd.so>
+#  1. no v_pk_fma_f32 in enc_front_kernel / dec_tail_kernel: packed fp32 FMAs with op_sel broadcasts behind LDS reads returned wrong
+#     values in lanes 48..63 when a second wave shared the SIMD (profiles/r3_pk_fma_hazard.md; mechanism not established).  The stem's
+#     FMAs are pinned in source (fma_pinned, split16.h) and the library is built with -fno-slp-vectorize; this check is what notices
+#     when a compiler upgrade or an extra flag brings them back.
+#  2. no scratch in dec_tail_kernel / enc_front_kernel: a kernel that uses scratch cannot be replayed from a hipGraph once the runtime
+#     has resized its scratch buffer.
+set -euo pipefail
+so="$1"
+objdump=/opt/rocm/lib/llvm/bin/llvm-objdump
+readelf=/opt/rocm/lib/llvm/bin/llvm-readelf
+tmp="$(mktemp -d)"
+trap 'rm -rf "$tmp"' EXIT
+cp "$so" "$tmp/lib.so"
+(cd "$tmp" && "$objdump" --offloading lib.so >/dev/null 2>&1)     # writes lib.so.N.hipv4-amdgcn-amd-amdhsa--gfx950 beside the copy
+bad=0
+found=0
+for co in "$tmp"/lib.so.*gfx950; do
+    [ -e "$co" ] || continue
+    "$objdump" -d "$co" > "$tmp/dis.s"
+    for k in enc_front_kernel dec_tail_kernel; do
+        n=$(awk -v k="$k" '/^[0-9a-f]+ <.*>:/{name=$2} /v_pk_fma_f32/{if (index(name, k)) c++} END{print c+0}' "$tmp/dis.s")
+        if grep -q "<.*$k.*>:" "$tmp/dis.s"; then found=$((found+1)); fi
+        if [ "$n" != "0" ]; then echo "check_isa: $n v_pk_fma_f32 in $k (profiles/r3_pk_fma_hazard.md)"; bad=1; fi
+    done
+    # .private_segment_fixed_size of the two fused chains from the code object's metadata notes
+    "$readelf" --notes "$co" > "$tmp/notes.txt" 2>/dev/null || true
+    for k in enc_front_kernel dec_tail_kernel; do
+        s=$(awk -v k="$k" '/\.name:/{nm=$2} /\.private_segment_fixed_size:/{ps=$2} /\.symbol:/{if (index($2, k)) print ps}' "$tmp/notes.txt" | head -1)
+        if [ -n "${s:-}" ] && [ "$s" != "0" ]; then echo "check_isa: $k uses $s bytes of scratch"; bad=1; fi
+    done
+done
+if [ "$found" -lt 2 ]; then echo "check_isa: enc_front_kernel / dec_tail_kernel not found in $so"; exit 1; fi
+[ "$bad" = "0" ] && echo "check_isa: ok (no packed fp32 FMAs, no scratch in the fused chains)"
+exit $bad

@@ -59,8 +59,8 @@ struct LstmPlan {
     std::vector<size_t> hh_off;     // W_hh per layer, MFMA B-fragment order
     std::vector<size_t> ihpk_off;   // W_ih per layer, same order (used by the in-step projection of layers >= 1)
     size_t persist_off = 0;         // register images of W_hh0, W_ih1, W_hh1 for lstm_persist_kernel (D = 512, 2 layers)
-    size_t persist6_off = 0;        // the same as three bf16 planes for lstm_persist6_kernel (float offset into the blob)
-    size_t persist16_inv = 0;       // split16.h: persist6_off holds two fp16 planes of the scaled rows; [2 layers][4D] 2^-s
+    size_t persist16_off = 0;       // lstm_persist16_kernel's register images: two fp16 planes of the scaled rows (float offset into the blob)
+    size_t persist16_inv = 0;       // [2 layers][4D] 2^-s of those rows (0: exact-product arithmetic, no images)
     bool has_persist = false;
 };
 
@@ -166,6 +166,22 @@ struct ac_handle {
     size_t cb16 = 0, cb16_inv = 0;   // rvq16.h: split16 images of the codebooks + their 2^-s (0: not packed -- other arithmetic or shape)
     // bounds of the fused thin-channel chains (enc_front.h): |stem out| <= sb0 + sb1 amax(sig); |block out| <= fb0 + fb1h H + fb1x X
     struct ChainBounds { float sb0 = 0.f, sb1 = 0.f, fb0 = 0.f, fb1h = 0.f, fb1x = 0.f; bool ok = false; } enc_front, dec_tail;   // dec_tail: sb0 / sb1 are the transposed conv's
+    // Developer / test switches.  Latched from the environment ONCE, at ac_finalize (latch_dev_switches, ac_api.hip); afterwards only
+    // ac_debug_set changes them -- no compute entry point reads the environment (round-3 advisor finding: hundreds of getenv calls per
+    // step, racing with a test's setenv, and a stray variable in a user's shell silently changing which kernel runs mid-process).
+    struct DevSwitches {
+        int tap_epi_staged = 0;     // AC_TAP_EPI=staged   : every tap-GEMM through the LDS-staged epilogue (A/B against the direct one)
+        int tap_dil = 1;            // AC_TAP_DIL=0        : dilated taps reload the slab per tap instead of the wide-slab instantiation
+        int tap_stagger = 0;        // AC_TAP_STAGGER=n    : random start delays (timing experiment)
+        int tap_pick = -1;          // AC_TAP_PICK=0|1|2|3 : force a tile arrangement for N % 256 == 0 layers
+        int rb6_dbg = 0;            // AC_RB6_DBG          : timing variants of the fused blocks (wrong results)
+        int front_seg = 0, tail_seg = 0;   // AC_FRONT_SEG / AC_TAIL_SEG: chunks per stream of the fused chains (0: from the batch size)
+        int front_ldspad = 0;       // AC_FRONT_LDSPAD     : extra dynamic LDS (forces one workgroup per CU)
+        int lstm_dbg = 0;           // AC_LSTM_DBG         : fault injection / traces of the persistent LSTM
+        int lstm_fuse_in = 1;       // AC_LSTM_FUSE_IN=0   : layer-0 input projection as a separate GEMM
+        int rvq_exact = 0;          // AC_RVQ=fp32         : exact-product codebook search
+        int prof_detail = 0;        // AC_PROF_DETAIL=1    : one profile record per tap-GEMM shape
+    } dev;
     bool fuse_chains = true;        // AC_FUSE=0 at ac_finalize: the layers of the fused chains as separate kernels (A/B runs, cross-check tests)
     // test hook: copy every layer output (standard [B][L][C] layout) into a caller buffer
     float* dbg = nullptr;
@@ -179,9 +195,7 @@ struct ac_handle {
     bool noncausal = false;                // WavTokenizer's SEANet encoder: centred padding (right = total/2, left = total - right)
     bool has_enc = true, has_dec = true;   // a half the caller's mode never runs may be left out (encodec.py:67-71)
     bool gemm_fp32 = false;         // AC_PRECISION_FP32_EXACT (or AC_GEMM=fp32): exact-product kernels only
-    bool gemm_bf16 = false;         // AC_PRECISION_BF16 (or AC_GEMM=bf16): opt-in, operands rounded to bf16 in the tap-GEMMs
-    bool split16 = true;            // fp32-fidelity arithmetic of the matrix kernels: two fp16 planes, 3 products (split16.h);
-                                    // false (AC_PRECISION_FP32_BF16X3 / AC_SPLIT=bf16x3): three bf16 planes, 6 products
+                                    // (false: split16.h -- fp32-fidelity arithmetic of the matrix kernels, two fp16 planes, 3 products)
     std::map<size_t, size_t> winv_of;   // split16 images: float offset of a packed fp32 matrix -> offset of its per-row 2^-s
     // amax slots (split16.h): [slot][amax_B] words, handed out in launch order, cleared at the start of every pass
     unsigned* amax_buf = nullptr;
@@ -349,9 +363,7 @@ struct Packer {
         o[1] = f16_rn(vs - f16_f32(o[0]));
         o[2] = 0;
     }
-    bool use16() const { return h->split16 && !h->gemm_bf16 && !h->gemm_fp32; }
-    // the LSTM stays fp32-faithful in the opt-in bf16 mode: split16 there too (three bf16 planes only in AC_PRECISION_FP32_BF16X3)
-    bool lstm16() const { return !h->gemm_fp32 && (h->split16 || h->gemm_bf16); }
+    bool use16() const { return !h->gemm_fp32; }
     // tap_gemm6 NP = 2 image: [n-tile of 32][k-step of 16][plane 2][lane 64][8 fp16] of the scaled rows + winv[N]
     void pack16(const PackedGemm& g) {
         const size_t n_el = (size_t)g.N * g.Ktot;
@@ -381,61 +393,7 @@ struct Packer {
     }
     void pack6(const PackedGemm& g) {
         if ((g.N % 64 && g.N % 96) || g.Ktot % 32 || h->w6_of.count(g.w_off)) return;
-        if (use16()) return pack16(g);
-        const size_t n_el = (size_t)g.N * g.Ktot;
-        const size_t off = reserve((3 * n_el + 1) / 2);
-        std::vector<uint16_t> planes(3 * n_el);
-        const int ksteps = g.Ktot / 16;
-        for (int nt = 0; nt < g.N / 32; ++nt)
-            for (int s = 0; s < ksteps; ++s)
-                for (int l = 0; l < 64; ++l)
-                    for (int e = 0; e < 8; ++e) {
-                        const float v = blob[g.w_off + (size_t)(nt * 32 + (l & 31)) * g.Ktot + s * 16 + 8 * (l >> 5) + e];
-                        uint32_t b;
-                        std::memcpy(&b, &v, 4);
-                        const uint32_t bh = b & 0xffff0000u;
-                        float fh;
-                        std::memcpy(&fh, &bh, 4);
-                        const float r1 = v - fh;
-                        uint32_t b1;
-                        std::memcpy(&b1, &r1, 4);
-                        const uint32_t bm = b1 & 0xffff0000u;
-                        float fm;
-                        std::memcpy(&fm, &bm, 4);
-                        const float r2 = r1 - fm;
-                        uint32_t b2;
-                        std::memcpy(&b2, &r2, 4);
-                        const size_t base = (((size_t)nt * ksteps + s) * 3) * 512 + (size_t)l * 8 + e;
-                        if (h->gemm_bf16) {   // opt-in bf16 mode: plane 0 = round-to-nearest-even(w), the others unused
-                            planes[base] = bf16_rn(v);
-                            continue;
-                        }
-                        planes[base] = (uint16_t)(bh >> 16);
-                        planes[base + 512] = (uint16_t)(bm >> 16);
-                        planes[base + 1024] = (uint16_t)(b2 >> 16);
-                    }
-        std::memcpy(&blob[off], planes.data(), planes.size() * 2);
-        h->w6_of[g.w_off] = off;
-    }
-    // exact truncation split of one weight into three bf16 terms (tap_gemm6.h)
-    static void split3h(float v, uint16_t (&o)[3]) {
-        uint32_t b;
-        std::memcpy(&b, &v, 4);
-        const uint32_t bh = b & 0xffff0000u;
-        float fh;
-        std::memcpy(&fh, &bh, 4);
-        const float r1 = v - fh;
-        uint32_t b1;
-        std::memcpy(&b1, &r1, 4);
-        const uint32_t bm = b1 & 0xffff0000u;
-        float fm;
-        std::memcpy(&fm, &bm, 4);
-        const float r2 = r1 - fm;
-        uint32_t b2;
-        std::memcpy(&b2, &r2, 4);
-        o[0] = (uint16_t)(bh >> 16);
-        o[1] = (uint16_t)(bm >> 16);
-        o[2] = (uint16_t)(b2 >> 16);
+        if (use16()) pack16(g);
     }
     // v_mfma_f32_16x16x32_bf16 operand fragments of a row-major [N][Ksrc] matrix in the blob:
     //   [n-tile of 16][k-step of 32][plane 3][lane 64][8 bf16],  lane (n = lane & 15, k = 8 * (lane >> 4) + e);
@@ -467,25 +425,7 @@ struct Packer {
             if (winv_off) *winv_off = ioff;
             return off;
         }
-        const size_t off = reserve((3 * n_el + 1) / 2);
-        std::vector<uint16_t> planes(3 * n_el);
-        for (int nt = 0; nt < N / 16; ++nt)
-            for (int s = 0; s < ksteps; ++s)
-                for (int l = 0; l < 64; ++l)
-                    for (int e = 0; e < 8; ++e) {
-                        const int k = kmap[s * 32 + 8 * (l >> 4) + e];
-                        uint16_t t[3] = {0, 0, 0};
-                        if (k >= 0) {
-                            if (h->gemm_bf16) t[0] = bf16_rn(blob[src_off + (size_t)(nt * 16 + (l & 15)) * Ksrc + k]);   // opt-in bf16 mode: one rounded plane
-                            else split3h(blob[src_off + (size_t)(nt * 16 + (l & 15)) * Ksrc + k], t);
-                        }
-                        const size_t base = (((size_t)nt * ksteps + s) * 3) * 512 + (size_t)l * 8 + e;
-                        planes[base] = t[0];
-                        planes[base + 512] = t[1];
-                        planes[base + 1024] = t[2];
-                    }
-        std::memcpy(&blob[off], planes.data(), planes.size() * 2);
-        return off;
+        return 0;   // exact-product arithmetic: no fragment images
     }
     // thin_conv6.h image of a [64][128] layer
     void pack_t6(const PackedGemm& g) {
@@ -679,11 +619,11 @@ struct Packer {
                                         blob[lp.persist_off + m * mat + ((((size_t)idx * 4 + w) * 4 + n) * 8 + ks) * 256 + lane * 4 + e] =
                                             (*mats[m])[(size_t)(n * D + idx * 16 + (lane & 15)) * D + (w * 8 + ks) * 16 + 4 * (lane >> 4) + e];
             const std::vector<float>* mats6[4] = {mats[0], mats[1], mats[2], get(prefix + ".weight_ih_l0", (size_t)4 * D * D)};
-            if (lstm16()) {
+            if (use16()) {
                 // lstm_persist16_kernel: [hh0, ih1, hh1, ih0][32 slices][4 waves][4 gates][4 k-steps of 32][2 planes][64 lanes][8 fp16] of the
                 // scaled rows; the two matrices of a layer share the accumulator, so their rows share the scale
                 const size_t mat16 = (size_t)LP_SLICES * 4 * 4 * 4 * 2 * 512;
-                lp.persist6_off = reserve((4 * mat16 + 1) / 2);
+                lp.persist16_off = reserve((4 * mat16 + 1) / 2);
                 lp.persist16_inv = reserve((size_t)2 * 4 * D);
                 std::vector<int> sc((size_t)2 * 4 * D);
                 const int layer_of[4] = {0, 1, 1, 0};
@@ -715,40 +655,7 @@ struct Packer {
                                             pl16[base] = t[0];
                                             pl16[base + 512] = t[1];
                                         }
-                std::memcpy(&blob[lp.persist6_off], pl16.data(), pl16.size() * 2);
-            } else {
-            // lstm_persist6_kernel: [hh0, ih1, hh1, ih0][32 slices][4 waves][4 gates][4 k-steps of 32][3 planes][64 lanes][8 bf16]
-            const size_t mat6 = (size_t)LP_SLICES * 4 * 4 * 4 * 3 * 512;
-            lp.persist6_off = reserve((4 * mat6 + 1) / 2);
-            std::vector<uint16_t> pl6(4 * mat6);
-            for (int m = 0; m < 4; ++m)
-                for (int idx = 0; idx < LP_SLICES; ++idx)
-                    for (int w = 0; w < 4; ++w)
-                        for (int n = 0; n < 4; ++n)
-                            for (int ks = 0; ks < 4; ++ks)
-                                for (int lane = 0; lane < 64; ++lane)
-                                    for (int e = 0; e < 8; ++e) {
-                                        const float v = (*mats6[m])[(size_t)(n * D + idx * 16 + (lane & 15)) * D + w * 128 + ks * 32 + 8 * (lane >> 4) + e];
-                                        uint32_t b;
-                                        std::memcpy(&b, &v, 4);
-                                        const uint32_t bh = b & 0xffff0000u;
-                                        float fh;
-                                        std::memcpy(&fh, &bh, 4);
-                                        const float r1 = v - fh;
-                                        uint32_t b1;
-                                        std::memcpy(&b1, &r1, 4);
-                                        const uint32_t bm = b1 & 0xffff0000u;
-                                        float fm;
-                                        std::memcpy(&fm, &bm, 4);
-                                        const float r2 = r1 - fm;
-                                        uint32_t b2;
-                                        std::memcpy(&b2, &r2, 4);
-                                        const size_t base = m * mat6 + (((((size_t)idx * 4 + w) * 4 + n) * 4 + ks) * 3) * 512 + (size_t)lane * 8 + e;
-                                        pl6[base] = (uint16_t)(bh >> 16);
-                                        pl6[base + 512] = (uint16_t)(bm >> 16);
-                                        pl6[base + 1024] = (uint16_t)(b2 >> 16);
-                                    }
-            std::memcpy(&blob[lp.persist6_off], pl6.data(), pl6.size() * 2);
+                std::memcpy(&blob[lp.persist16_off], pl16.data(), pl16.size() * 2);
             }
             lp.has_persist = true;
         }

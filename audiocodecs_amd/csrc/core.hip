@@ -3,7 +3,6 @@
 #include "split16_kernels.h"
 #include "lstm.h"
 #include "lstm_persist.h"
-#include "lstm_persist6.h"
 #include "lstm_persist16.h"
 #include "rvq.h"
 #include "rvq16.h"
@@ -21,7 +20,7 @@ namespace acimpl {
 
 
 int fail(ac_handle* h, int code, const char* fmt, ...) {
-    char buf[512];
+    char buf[1024];
     va_list ap;
     va_start(ap, fmt);
     vsnprintf(buf, sizeof buf, fmt, ap);
@@ -113,7 +112,7 @@ void pool_bind(ac_handle* h, void* mem, int pool_B, size_t rows) {
 // start of a pass over B clips: all slots of the bound pool back to zero (one memset of AMAX_SLOTS x B lines on the caller's stream)
 int amax_begin(ac_handle* h, hipStream_t st, int B) {
     h->amax_next = 0;
-    if (!(h->split16 || h->gemm_bf16) || h->gemm_fp32 || !h->amax_buf) return AC_OK;
+    if (h->gemm_fp32 || !h->amax_buf) return AC_OK;
     if (B > h->amax_B) return fail(h, AC_ENOMEM, "workspace pool holds amax slots for %d clips, the pass has %d", h->amax_B, B);
     HIPCHK(h, hipMemsetAsync(h->amax_buf, 0, (size_t)AMAX_SLOTS * h->amax_B * AMAX_STRIDE * 4, st));
     return AC_OK;
@@ -121,7 +120,7 @@ int amax_begin(ac_handle* h, hipStream_t st, int B) {
 
 // a fresh slot for a producer's output (null when the arithmetic does not use them)
 unsigned* amax_new(ac_handle* h) {
-    if (!(h->split16 || h->gemm_bf16) || h->gemm_fp32 || !h->amax_buf || h->amax_next >= AMAX_SLOTS) return nullptr;
+    if (h->gemm_fp32 || !h->amax_buf || h->amax_next >= AMAX_SLOTS) return nullptr;
     return h->amax_buf + (size_t)(h->amax_next++) * h->amax_B * AMAX_STRIDE;
 }
 
@@ -270,10 +269,12 @@ int run_tap(ac_handle* h, hipStream_t st, TapGemmParams& p) {
     p.amax_rows = 0;
     if (w6) {
         p.clk = h->clk_dev;
-        if (const char* ts = std::getenv("AC_TRACE_SHAPE")) {      // developer (T6_TRACE builds): clock / stamps of ONE layer shape "M,N,K"
+#ifdef T6_TRACE   // developer trace builds only: clock / stamps of ONE layer shape "M,N,K"
+        if (const char* ts = std::getenv("AC_TRACE_SHAPE")) {
             int tm = 0, tn = 0, tk = 0;
             if (std::sscanf(ts, "%d,%d,%d", &tm, &tn, &tk) == 3 && !((tm == 0 || tm == p.M) && tn == p.N && tk == (int)kk)) p.clk = nullptr;   // (M = 0: any M)
         }
+#endif
         auto iv = h->winv_of.find((size_t)(p.w - h->blob));
         // (row mode only on the caller's request -- the linear layers over merged token matrices: a conv that merely happens to
         // run with one clip must scale like the same conv in a batch, or a clip's result would depend on the batch size)
@@ -303,17 +304,15 @@ int run_tap(ac_handle* h, hipStream_t st, TapGemmParams& p) {
             p.winv = h->blob + iv->second;
             p.amax_out = amax_new(h);
             // plain conv outputs store straight from the accumulators (tap_gemm6.h); AC_TAP_EPI=staged: the LDS-staged epilogue
-            const char* epi_s = std::getenv("AC_TAP_EPI");            // (read per launch: a test flips it)
-            const bool staged_env = epi_s && std::strcmp(epi_s, "staged") == 0;
+            const bool staged_env = h->dev.tap_epi_staged != 0;       // (ac_debug_set "tap_epi_staged": a test flips it)
             // (ELU flavour without a residual, Snake flavour with or without one: the combinations the four codecs produce)
-            p.epi_direct = !staged_env && !h->gemm_bf16 && !p.gelu && !p.scale && !p.tanh_out && p.y_off == 0 && p.y_len == 0 &&
+            p.epi_direct = !staged_env && !p.gelu && !p.scale && !p.tanh_out && p.y_off == 0 && p.y_len == 0 &&
                            (!p.res || (p.alpha && (long long)p.M * p.res_rs * 4 < 0x7fffffffLL && p.res_rs * 4 < (1 << 20))) && (!p.alpha || p.y_elu) &&
                            (p.n_valid == 0 || p.n_valid == p.N) && (p.alpha ? p.N < 128 && p.N % 32 == 0 : p.N % 128 == 0) &&      // (measured: Snake / residual layers of 128+ channels are faster through the LDS-staged 16-byte rows)
                            (long long)p.M * p.y_rs * 4 < 0x7fffffffLL && p.y_rs * 4 < (1 << 20);
         }
-        { static const int stag = std::getenv("AC_TAP_STAGGER") ? std::atoi(std::getenv("AC_TAP_STAGGER")) : 0; p.stagger = stag; }
-        const char* dil_s = std::getenv("AC_TAP_DIL");            // developer / tests: AC_TAP_DIL=0 -> slab reload per tap (read per launch: a test flips it)
-        const bool dil_env = !(dil_s && std::atoi(dil_s) == 0);
+        p.stagger = h->dev.tap_stagger;
+        const bool dil_env = h->dev.tap_dil != 0;                 // developer / tests: 0 -> slab reload per tap
         const bool dil_slab = dil_env && p.nseg == 1 && p.seg[0].dil != 1 && p.seg[0].s == 1 && (p.seg[0].J - 1) * p.seg[0].dil <= T6_DIL_HALO;
 #define TAP6_LAUNCH(WGM, WGN, WMT, WN, NP)                                                                              \
     do {                                                                                                                \
@@ -327,16 +326,14 @@ int run_tap(ac_handle* h, hipStream_t st, TapGemmParams& p) {
         p.mtiles = cdiv(p.M, Cfg6::BM);                                                                                 \
         p.ntiles = p.N / Cfg6::BN;                                                                                      \
         const long long blocks = (long long)p.B * p.mtiles * p.ntiles;                                                  \
-        if (h->gemm_bf16) TAP6_LAUNCH(WGM, WGN, WMT, WN, 1);                                                            \
-        else if (p.winv && dil_slab && (WN >= 2 || (WGM == 1 && WGN == 4 && kk >= 2048))) {                                  \
+        if (p.winv && dil_slab && (WN >= 2 || (WGM == 1 && WGN == 4 && kk >= 2048))) {                                  \
             /* dilated taps out of one wide slab (tap_gemm6.h: T6_DIL_HALO); measured per arrangement on DAC's layers: the 128 x 32  \
                tile loses its third workgroup per CU to the larger slab and gains only for long contractions, 64 x 32 tiles lose */ \
             using Cfg6D = Tap6Cfg<WGM, WGN, WMT, WN, T6_DIL_HALO>;                                                      \
             if ((rc = ensure_lds(h, reinterpret_cast<const void*>(tap_gemm6_kernel<WGM, WGN, WMT, WN, 2, T6_DIL_HALO>), Cfg6D::lds_for(2)))) return rc; \
             ProfScope ps(h, st, (std::string("tap_gemm6_kernel<" #WGM ", " #WGN ", " #WMT ", " #WN ", 2, dil>") + shape).c_str(), flops, bytes); \
             hipLaunchKernelGGL((tap_gemm6_kernel<WGM, WGN, WMT, WN, 2, T6_DIL_HALO>), dim3((unsigned)blocks), dim3(Cfg6D::NT), Cfg6D::lds_for(2), st, p, w6); \
-        } else if (p.winv) TAP6_LAUNCH(WGM, WGN, WMT, WN, 2);                                                           \
-        else TAP6_LAUNCH(WGM, WGN, WMT, WN, 3);                                                                         \
+        } else TAP6_LAUNCH(WGM, WGN, WMT, WN, 2);                                                                       \
     } while (0)
         // Tile / wave arrangement (measured, profiles/r2_tapgemm_variants.md).  The weight fragments come L2 -> registers and the
         // activation slab is shared through LDS, so the CU's vector-memory path and the LDS pipe are what an arrangement must
@@ -356,8 +353,7 @@ int run_tap(ac_handle* h, hipStream_t st, TapGemmParams& p) {
             //  4.71 ms at 128 columns, 5.43 ms with 1 x 8 waves)
             const double s8 = (kk >= 2048 ? (p.winv ? 1.00 : 1.12) : (p.winv ? 0.85 : 0.95)) * fill(wg256, 256.0);
             pick = s256 >= s128 && s256 >= s8 ? 1 : (s8 > s128 ? 2 : 0);
-            static const char* force = std::getenv("AC_TAP_PICK");     // developer override: 0 / 1 / 2
-            if (force && force[0] >= '0' && force[0] <= '2') pick = force[0] - '0';
+            if (h->dev.tap_pick >= 0 && h->dev.tap_pick <= 2) pick = h->dev.tap_pick;     // developer override
         }
         if (pick == 1) TAP6_CASE(1, 4, 4, 2);
         else if (pick == 2) TAP6_CASE(1, 8, 4, 1);
@@ -410,11 +406,9 @@ int try_thin6(ac_handle* h, hipStream_t st, const PackedGemm& g, const Act& x, i
     }
     const long long total = (long long)B * p.ntiles;
     const int grid = (int)std::min<long long>(total, 4 * 256);   // persistent, four workgroups per CU
-    ProfScope ps(h, st, h->gemm_bf16 ? "thin_conv6_kernel<1>" : s16 ? "thin_conv6_kernel<2>" : "thin_conv6_kernel<3>", 2.0 * B * p.M * 64.0 * 128.0,
+    ProfScope ps(h, st, "thin_conv6_kernel<2>", 2.0 * B * p.M * 64.0 * 128.0,
                  (double)B * p.M * 256.0 * (1 + (out.raw ? 1 : 0) + (out.elu ? 1 : 0)));
-    if (h->gemm_bf16) hipLaunchKernelGGL(thin_conv6_kernel<1>, dim3(grid), dim3(256), T6_LDS, st, p);
-    else if (s16) hipLaunchKernelGGL(thin_conv6_kernel<2>, dim3(grid), dim3(256), T6_LDS, st, p);
-    else hipLaunchKernelGGL(thin_conv6_kernel<3>, dim3(grid), dim3(256), T6_LDS, st, p);
+    hipLaunchKernelGGL(thin_conv6_kernel<2>, dim3(grid), dim3(256), T6_LDS, st, p);
     return AC_OK;
 }
 
@@ -531,7 +525,7 @@ int launch_rb_fused(ac_handle* h, hipStream_t st, const ResBlockPlan& rb, const 
 // split-operand version of the fused block (rb_fused6.h); reads the raw rows only and activates them itself
 // split16.h operands of a fused block launch; false when the block's images are bf16 planes
 bool rb_split16(ac_handle* h, hipStream_t st, const ResBlockPlan& rb, const Act2& x, int B, RbFused6Params& p, const unsigned** amax_out) {
-    if (!h->split16 || h->gemm_bf16 || h->gemm_fp32 || !rb.winv3_off) return false;
+    if (h->gemm_fp32 || !rb.winv3_off) return false;
     p.amax_in = amax_of(h, st, x.raw.p, x.raw.bs, x.raw.ts, x.raw.L, x.raw.C, B, x.raw.amax_n == B ? x.raw.amax : nullptr);
     p.winv3 = h->blob + rb.winv3_off;
     p.winvf = h->blob + rb.winvf_off;
@@ -560,22 +554,19 @@ int launch_rb_fused6(ac_handle* h, hipStream_t st, const ResBlockPlan& rb, const
     p.Lp = x.raw.L > p.lpad ? x.raw.L : p.lpad + 1;
     p.ntiles = cdiv(x.raw.L, Cfg::BM);
     p.pad = pad;
-    if (const char* d = std::getenv("AC_RB6_DBG")) p.dbg = std::atoi(d);
-    const bool s16 = rb_split16(h, st, rb, x, B, p, amax_out);
-    if (s16 && !p.amax_in) return fail(h, AC_ESTATE, "out of amax slots (split16.h)");
-    const size_t lds6 = s16 ? Cfg::lds_bytes16 : Cfg::lds_bytes;
-    if (int rc = ensure_lds(h, h->gemm_bf16 ? reinterpret_cast<const void*>(rb_fused6_kernel<C, SC, 1>) : s16 ? reinterpret_cast<const void*>(rb_fused6_kernel<C, SC, 2>) : reinterpret_cast<const void*>(rb_fused6_kernel<C, SC, 3>), lds6)) return rc;
+    p.dbg = h->dev.rb6_dbg;
+    if (!rb_split16(h, st, rb, x, B, p, amax_out)) return fail(h, AC_ESTATE, "fused residual block without split16 images");
+    if (!p.amax_in) return fail(h, AC_ESTATE, "out of amax slots (split16.h)");
+    const size_t lds6 = Cfg::lds_bytes16;
+    if (int rc = ensure_lds(h, reinterpret_cast<const void*>(rb_fused6_kernel<C, SC, 2>), lds6)) return rc;
     const long long total = (long long)B * p.ntiles;
-    const int per_cu = s16 ? rb6_occupancy<C, SC, 2>() : rb6_occupancy<C, SC, 3>();
+    const int per_cu = rb6_occupancy<C, SC, 2>();
     const int grid = (int)std::min<long long>(total, (long long)per_cu * 256);   // persistent
     const double L = x.raw.L;
-    const std::string np6 = h->gemm_bf16 ? ", 1>" : s16 ? ", 2>" : ", 3>";
-    ProfScope ps(h, st, ((!SC ? "rb_fused6_kernel<64, false" : C == 32 ? "rb_fused6_kernel<32, true" : "rb_fused6_kernel<64, true") + np6).c_str(),
+    ProfScope ps(h, st, !SC ? "rb_fused6_kernel<64, false, 2>" : C == 32 ? "rb_fused6_kernel<32, true, 2>" : "rb_fused6_kernel<64, true, 2>",
                  2.0 * B * L * ((double)(C / 2) * 3 * C + (double)C * (C / 2 + (SC ? C : 0))),
                  (double)B * L * C * 4.0 * (1 + (out.raw ? 1 : 0) + (out.elu ? 1 : 0)));
-    if (h->gemm_bf16) hipLaunchKernelGGL((rb_fused6_kernel<C, SC, 1>), dim3(grid), dim3(256), Cfg::lds_bytes, st, p);
-    else if (s16) hipLaunchKernelGGL((rb_fused6_kernel<C, SC, 2>), dim3(grid), dim3(256), lds6, st, p);
-    else hipLaunchKernelGGL((rb_fused6_kernel<C, SC, 3>), dim3(grid), dim3(256), Cfg::lds_bytes, st, p);
+    hipLaunchKernelGGL((rb_fused6_kernel<C, SC, 2>), dim3(grid), dim3(256), lds6, st, p);
     return AC_OK;
 }
 
@@ -598,19 +589,16 @@ int launch_rb128_fused6(ac_handle* h, hipStream_t st, const ResBlockPlan& rb, co
     p.Lp = x.raw.L > p.lpad ? x.raw.L : p.lpad + 1;
     p.ntiles = cdiv(x.raw.L, Cfg::BM);
     p.pad = pad;
-    const bool s16 = rb_split16(h, st, rb, x, B, p, amax_out);
-    if (s16 && !p.amax_in) return fail(h, AC_ESTATE, "out of amax slots (split16.h)");
-    if (int rc = ensure_lds(h, h->gemm_bf16 ? reinterpret_cast<const void*>(rb128_fused6_kernel<SC, 1>) : s16 ? reinterpret_cast<const void*>(rb128_fused6_kernel<SC, 2>) : reinterpret_cast<const void*>(rb128_fused6_kernel<SC, 3>), Cfg::lds_bytes)) return rc;
+    if (!rb_split16(h, st, rb, x, B, p, amax_out)) return fail(h, AC_ESTATE, "fused residual block without split16 images");
+    if (!p.amax_in) return fail(h, AC_ESTATE, "out of amax slots (split16.h)");
+    if (int rc = ensure_lds(h, reinterpret_cast<const void*>(rb128_fused6_kernel<SC, 2>), Cfg::lds_bytes)) return rc;
     const long long total = (long long)B * p.ntiles;
     const int grid = (int)std::min<long long>(total, 256);   // persistent, one workgroup per CU
     const double L = x.raw.L;
-    const std::string np6 = h->gemm_bf16 ? ", 1>" : s16 ? ", 2>" : ", 3>";
-    ProfScope ps(h, st, ((SC ? "rb128_fused6_kernel<true" : "rb128_fused6_kernel<false") + np6).c_str(),
+    ProfScope ps(h, st, SC ? "rb128_fused6_kernel<true, 2>" : "rb128_fused6_kernel<false, 2>",
                  2.0 * B * L * (64.0 * 384 + 128.0 * (64 + (SC ? 128 : 0))),
                  (double)B * L * 128 * 4.0 * (1 + (out.raw ? 1 : 0) + (out.elu ? 1 : 0)));
-    if (h->gemm_bf16) hipLaunchKernelGGL((rb128_fused6_kernel<SC, 1>), dim3(grid), dim3(512), Cfg::lds_bytes, st, p);
-    else if (s16) hipLaunchKernelGGL((rb128_fused6_kernel<SC, 2>), dim3(grid), dim3(512), Cfg::lds_bytes, st, p);
-    else hipLaunchKernelGGL((rb128_fused6_kernel<SC, 3>), dim3(grid), dim3(512), Cfg::lds_bytes, st, p);
+    hipLaunchKernelGGL((rb128_fused6_kernel<SC, 2>), dim3(grid), dim3(512), Cfg::lds_bytes, st, p);
     return AC_OK;
 }
 
@@ -751,7 +739,7 @@ int head_fwd(ac_handle* h, hipStream_t st, const Act& x, int B, float* sig) {
 // ---- fused thin-channel head of the encoder (enc_front.h): stem -> ResBlock(32) -> ELU -> Conv1d(32, 64, k4, s2)
 bool enc_front_ok(const ac_handle* h, int T) {
     const ac_config& c = h->cfg;
-    return h->fuse_chains && h->arch == ARCH_ENCODEC && !h->noncausal && h->split16 && !h->gemm_bf16 && !h->gemm_fp32 && h->enc_front.ok &&
+    return h->fuse_chains && h->arch == ARCH_ENCODEC && !h->noncausal && !h->gemm_fp32 && h->enc_front.ok &&
            c.num_filters == 32 && c.kernel_size == 7 && c.residual_kernel_size == 3 && c.compress == 2 && c.num_ratios >= 1 &&
            c.upsampling_ratios[c.num_ratios - 1] == 2 && T >= 64 && (long long)T * 128 < 0x70000000LL;
 }
@@ -782,7 +770,7 @@ int enc_front_fwd(ac_handle* h, hipStream_t st, const float* sig, const float* r
     p.M = cdiv(T, 2);
     const int nchunks = cdiv(T, EF_ROWS);
     p.seg_chunks = std::max(8, cdiv(nchunks, std::max(1, 6144 / B)));     // ~6144 streams: three rounds of 2048 resident waves
-    if (const char* sc = std::getenv("AC_FRONT_SEG")) p.seg_chunks = std::max(1, std::atoi(sc));
+    if (h->dev.front_seg > 0) p.seg_chunks = h->dev.front_seg;
     p.segs_per_clip = cdiv(nchunks, p.seg_chunks);
     // amax of the samples (one read of 4 B per sample; as 16-byte vectors where the clip pitch allows)
     const bool v4 = T % 4 == 0 && aligned16(sig);
@@ -793,7 +781,7 @@ int enc_front_fwd(ac_handle* h, hipStream_t st, const float* sig, const float* r
     p.hb0 = rb.hb0; p.hb1 = rb.hb1;
     p.fb0 = h->enc_front.fb0; p.fb1h = h->enc_front.fb1h; p.fb1x = h->enc_front.fb1x;
     size_t lds = EF_LDS;
-    if (const char* lp = std::getenv("AC_FRONT_LDSPAD")) lds += (size_t)std::atoi(lp);     // developer: force one workgroup per CU
+    lds += (size_t)h->dev.front_ldspad;     // developer: force one workgroup per CU
     if (int rc = ensure_lds(h, reinterpret_cast<const void*>(enc_front_kernel), lds)) return rc;
     const long long streams = (long long)B * p.segs_per_clip;
     {
@@ -811,7 +799,7 @@ int enc_front_fwd(ac_handle* h, hipStream_t st, const float* sig, const float* r
 // ---- fused thin-channel tail of the decoder (dec_tail.h): ConvTranspose1d(64, 32, k4, s2) -> ResBlock(32) -> ELU -> Conv1d(32, 1, k7)
 bool dec_tail_ok(const ac_handle* h, const Act& xe) {
     const ac_config& c = h->cfg;
-    return h->fuse_chains && h->arch == ARCH_ENCODEC && !h->noncausal && h->split16 && !h->gemm_bf16 && !h->gemm_fp32 && h->dec_tail.ok &&
+    return h->fuse_chains && h->arch == ARCH_ENCODEC && !h->noncausal && !h->gemm_fp32 && h->dec_tail.ok &&
            c.num_filters == 32 && c.last_kernel_size == 7 && c.residual_kernel_size == 3 && c.compress == 2 && c.num_ratios >= 1 &&
            c.upsampling_ratios[c.num_ratios - 1] == 2 && xe.p && xe.C == 64 && xe.ts == 64 && xe.bs == (long long)xe.L * 64 && aligned16(xe.p) &&
            xe.L >= 32 && (long long)xe.L * 256 < 0x70000000LL;
@@ -842,7 +830,7 @@ int dec_tail_fwd(ac_handle* h, hipStream_t st, const Act& xe, int B, float* sig,
     p.L = xe.L;
     const int nchunks = cdiv(xe.L, DT_ROWS);
     p.seg_chunks = std::max(8, cdiv(nchunks, std::max(1, 6144 / B)));
-    if (const char* sc = std::getenv("AC_TAIL_SEG")) p.seg_chunks = std::max(1, std::atoi(sc));
+    if (h->dev.tail_seg > 0) p.seg_chunks = h->dev.tail_seg;
     p.segs_per_clip = cdiv(nchunks, p.seg_chunks);
     p.amax_x = amax_of(h, st, xe.p, xe.bs, xe.ts, xe.L, xe.C, B, xe.amax_n == B ? xe.amax : nullptr);
     if (!p.amax_x) return fail(h, AC_ESTATE, "out of amax slots (split16.h)");
@@ -880,8 +868,8 @@ int lstm_fwd(ac_handle* h, hipStream_t st, const LstmPlan& lp, const Act& x, con
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(st, &cap);
     const bool persist = lp.has_persist && h->lp_ctl && h->num_cus == 256 && !h->lstm_step_only && x.ts == D && cap == hipStreamCaptureStatusNone;
-    static const bool fuse_env = !(std::getenv("AC_LSTM_FUSE_IN") && std::getenv("AC_LSTM_FUSE_IN")[0] == '0');
-    const bool fuse_in = persist && !h->gemm_fp32 && fuse_env && aligned16(x.p) && x.bs % 4 == 0;   // lstm_persist6.h computes W_ih0 * x[t] itself
+    const bool fuse_env = h->dev.lstm_fuse_in != 0;
+    const bool fuse_in = persist && !h->gemm_fp32 && fuse_env && aligned16(x.p) && x.bs % 4 == 0;   // lstm_persist16.h computes W_ih0 * x[t] itself
     // layer-0 input projection for all t: gin[t][b][4D]
     if (!fuse_in) {
         TapGemmParams p{};
@@ -911,7 +899,7 @@ int lstm_fwd(ac_handle* h, hipStream_t st, const LstmPlan& lp, const Act& x, con
         }
         int* poison = reinterpret_cast<int*>(ws.c);   // the cell-state buffer of the per-step kernels is free on this path
         if (!h->gemm_fp32) HIPCHK(h, hipMemsetAsync(poison, 0x7f, (size_t)B * sizeof(int), st));
-        ProfScope ps(h, st, h->gemm_fp32 ? "lstm_persist_kernel" : lp.persist16_inv ? (fuse_in ? "lstm_persist16_kernel<true>" : "lstm_persist16_kernel<false>") : "lstm_persist6_kernel<3>", 2.0 * T * (double)B * 4 * D * D * (nroles + (fuse_in ? 1 : 0)),
+        ProfScope ps(h, st, h->gemm_fp32 ? "lstm_persist_kernel" : fuse_in ? "lstm_persist16_kernel<true>" : "lstm_persist16_kernel<false>", 2.0 * T * (double)B * 4 * D * D * (nroles + (fuse_in ? 1 : 0)),
                      (double)T * ((double)B * 4 * D * 4 + 3.0 * B * D * 4) + 12.0 * D * D * 4, chunks);
         auto tail = [&](int c0, int nb, const int* pz) {
             LstmTailParams tp{};
@@ -947,18 +935,14 @@ int lstm_fwd(ac_handle* h, hipStream_t st, const LstmPlan& lp, const Act& x, con
             q.T = T;
             q.group0 = c0 / 16;
             q.clip0 = c0;
-            const char* ld = std::getenv("AC_LSTM_DBG");
-            q.dbg = ld ? std::atoi(ld) : 0;
-            if (!h->gemm_fp32) {   // split-operand products on the bf16 pipe (lstm_persist6.h): h travels as bf16 plane blocks
-                LstmPersist6Params q6{};
+            q.dbg = h->dev.lstm_dbg;
+            if (!h->gemm_fp32) {   // split16 products on the fp16 pipe (lstm_persist16.h): h travels as fp16 plane blocks
+                LstmPersist16Params q6{};
                 q6.base = q;
-                const bool l16 = lp.persist16_inv != 0;     // split16.h planes
-                q6.base.h_ts = (long long)((B + 31) / 32 * 2) * (l16 ? LP16_GROUP_BYTES : LP6_GROUP_BYTES);
-                if (l16) {
-                    q6.winv = h->blob + lp.persist16_inv;
-                    q6.amax_x = fuse_in ? x_amax : nullptr;
-                }
-                q6.w_pk6 = reinterpret_cast<const __bf16*>(h->blob + lp.persist6_off);
+                q6.base.h_ts = (long long)((B + 31) / 32 * 2) * LP16_GROUP_BYTES;
+                q6.winv = h->blob + lp.persist16_inv;
+                q6.amax_x = fuse_in ? x_amax : nullptr;
+                q6.w_pk6 = reinterpret_cast<const __bf16*>(h->blob + lp.persist16_off);
                 q6.bias0 = h->blob + lp.ih[0].b_off;
                 q6.fuse_in = fuse_in ? 1 : 0;
                 q6.poison = poison;
@@ -968,13 +952,12 @@ int lstm_fwd(ac_handle* h, hipStream_t st, const LstmPlan& lp, const Act& x, con
                 const size_t hbytes = (size_t)T * (size_t)q6.base.h_ts;
                 HIPCHK(h, hipMemsetAsync(ws.hseq0, 0xFF, hbytes, st));
                 HIPCHK(h, hipMemsetAsync(ws.hseq1, 0xFF, hbytes, st));
-                if (l16) HIPCHK(h, hipMemsetAsync(ws.gin1, 0xFF, hbytes, st));
+                HIPCHK(h, hipMemsetAsync(ws.gin1, 0xFF, hbytes, st));
                 void* args6[] = {&q6};
-                const void* kfn = l16 ? (fuse_in ? reinterpret_cast<const void*>(lstm_persist16_kernel<true>) : reinterpret_cast<const void*>(lstm_persist16_kernel<false>))
-                                      : reinterpret_cast<const void*>(lstm_persist6_kernel<3>);
-                HIPCHK(h, hipLaunchCooperativeKernel(kfn, dim3(256), dim3(l16 ? 512 : 256), args6, 0, st));
+                const void* kfn = fuse_in ? reinterpret_cast<const void*>(lstm_persist16_kernel<true>) : reinterpret_cast<const void*>(lstm_persist16_kernel<false>);
+                HIPCHK(h, hipLaunchCooperativeKernel(kfn, dim3(256), dim3(512), args6, 0, st));
                 tail(c0, q.B, poison);
-                if (q.dbg & 32) {   // developer trace: 100 MHz real-time stamps of steps 100 .. 103 (lstm_persist6.h)
+                if (q.dbg & 32) {   // developer trace: 100 MHz real-time stamps of steps 100 .. 103 (lstm_persist16.h)
                     HIPCHK(h, hipStreamSynchronize(st));
                     std::vector<unsigned long long> tr(8 * 64);
                     HIPCHK(h, hipMemcpy(tr.data(), h->lp_ctl + LP_CTL_FLAGS, tr.size() * 8, hipMemcpyDeviceToHost));
@@ -1083,7 +1066,7 @@ int rvq_encode_fwd(ac_handle* h, hipStream_t st, const float* feats, int F, int 
     // frames per wave: 48 once there are enough frames to fill every SIMD (1024) with one wave
     const int MS = (HV <= 8 && F >= 1024 * 32) ? 3 : 1;
     const dim3 grid(cdiv(F, 16 * MS)), block(64);
-    static const bool exact_env = std::getenv("AC_RVQ") && std::strcmp(std::getenv("AC_RVQ"), "fp32") == 0;   // developer A/B switch
+    const bool exact_env = h->dev.rvq_exact != 0;   // developer A/B switch
     if (h->cb16 && HV == 8 && !exact_env) {   // split16 products on the fp16 matrix pipe (rvq16.h)
         RvqEnc16Params q{};
         q.base = p;
@@ -1167,7 +1150,7 @@ Workspace plan_ws(const ac_handle* h, int B, int T_in /*samples, encoder*/, int 
     }
     mx = std::max(mx, (size_t)N * std::max(h->D, c.hidden_size));
     w.act_floats = align_up(mx * B, 64);
-    w.hseq = align_up((size_t)N * ((B + 31) / 32 * 32) * h->D * 3 / 2, 64);   // clips padded to the 32-clip workgroup tile; x1.5: bf16 plane blocks (lstm_persist6.h)
+    w.hseq = align_up((size_t)N * ((B + 31) / 32 * 32) * h->D * 3 / 2, 64);   // clips padded to the 32-clip workgroup tile; x1.5: room of the removed three-plane layout kept (workspace sizes unchanged); lstm_persist16.h's fp16 plane blocks need x1
     w.gin = std::max(align_up((size_t)N * B * 4 * h->D, 64), w.hseq);          // gin1 doubles as layer 0's local h copy on the persistent path
     w.c = align_up((size_t)2 * B * h->D, 64);
     w.total_bytes = (NACT * w.act_floats + 2 * w.gin + 2 * w.hseq + w.c) * sizeof(float) + 256;
@@ -1198,21 +1181,24 @@ int check_ready(ac_handle* h) {
     if (!h) return AC_EINVAL;
     if (!h->finalized) return fail(h, AC_ESTATE, "ac_finalize has not been called");
     if (h->sticky) {
+        // EVERY pending class is reported and cleared by this one call (round-3 advisor finding: with one class per call a bad-token
+        // count that was pending beside an LSTM failure surfaced in a later, unrelated call -- what strict mode exists to prevent)
         volatile unsigned* s = h->sticky;
-        if (s[ST_LSTM_TIMEOUT] || s[ST_LSTM_PLACEMENT]) {
-            const unsigned a = s[ST_LSTM_TIMEOUT], b = s[ST_LSTM_PLACEMENT];
+        const unsigned a = s[ST_LSTM_TIMEOUT], b = s[ST_LSTM_PLACEMENT], t = s[ST_BAD_TOKEN];
+        if (a || b || t) {
             s[ST_LSTM_TIMEOUT] = 0;
             s[ST_LSTM_PLACEMENT] = 0;
-            h->lstm_step_only = true;   // self-heal: the per-step kernels need no co-residency
-            return fail(h, AC_EHIP,
-                        "an EARLIER call's persistent LSTM launch failed (%u bounded waits expired, %u launches without 32 workgroups on "
-                        "every XCD -- is the GPU shared?): that call's outputs were set to NaN; the handle now uses the per-step LSTM "
-                        "kernels, repeat the call", a, b);
-        }
-        if (s[ST_BAD_TOKEN]) {
-            const unsigned a = s[ST_BAD_TOKEN];
             s[ST_BAD_TOKEN] = 0;
-            return fail(h, AC_EINVAL, "an EARLIER ac_decode / ac_dequantize call got %u token ids outside [0, codebook_size): those frames were set to NaN", a);
+            char lstm[400] = "", tok[200] = "";
+            if (a || b) {
+                h->lstm_step_only = true;   // self-heal: the per-step kernels need no co-residency
+                std::snprintf(lstm, sizeof lstm,
+                              "an EARLIER call's persistent LSTM launch failed (%u bounded waits expired, %u launches without 32 workgroups on "
+                              "every XCD -- is the GPU shared?): that call's outputs were set to NaN; the handle now uses the per-step LSTM "
+                              "kernels, repeat the call", a, b);
+            }
+            if (t) std::snprintf(tok, sizeof tok, "an EARLIER ac_decode / ac_dequantize call got %u token ids outside [0, codebook_size): those frames were set to NaN", t);
+            return fail(h, (a || b) ? AC_EHIP : AC_EINVAL, "%s%s%s", lstm, (a || b) && t ? "; ALSO: " : "", tok);
         }
     }
     return AC_OK;

@@ -198,8 +198,8 @@ __global__ __launch_bounds__(64 * EF_WAVES, 2) void enc_front_kernel(const EncFr
             for (int j = 0; j < 7; ++j) {
                 const float xv = sg[r + 2 + j];              // sample t0 + r - 6 + j  (window index 0 <-> t0 - 8)
                 const f32x4 w = *reinterpret_cast<const f32x4*>(smem + EF_W0 + j * 32 + 4 * g);
-                acc.x = fmaf(w.x, xv, acc.x); acc.y = fmaf(w.y, xv, acc.y);
-                acc.z = fmaf(w.z, xv, acc.z); acc.w = fmaf(w.w, xv, acc.w);
+                acc.x = fma_pinned(w.x, xv, acc.x); acc.y = fma_pinned(w.y, xv, acc.y);      // (pinned: never v_pk_fma_f32, split16.h)
+                acc.z = fma_pinned(w.z, xv, acc.z); acc.w = fma_pinned(w.w, xv, acc.w);
             }
             split16_store4s(elu4(acc), sx, R1, EF_R1_PLANE, (4 + r) * EF_XP + 4 * g);
             split16_store4s(acc, sb, Xr, EF_Q_PLANE, r * EF_QP + 4 * g);
@@ -294,9 +294,10 @@ __global__ __launch_bounds__(64 * EF_WAVES, 2) void enc_front_kernel(const EncFr
 #pragma unroll
                 for (int c = 0; c < 4; ++c) acc[c] = ef_mfma(wd[ks][c][0], xh, acc[c]);
             }
-            // Every accumulator is READ by the VALU on every path (also in a warm-up chunk, whose rows are not stored): a matrix
-            // instruction whose result nothing waits for is still in flight when the next chunk's stem reuses its destination
-            // registers, and lands on top of them (seen as two wrong stem rows in lanes 48..63, only with a second wave on the SIMD)
+            // Every accumulator is read by the VALU on every path (also in a warm-up chunk, whose rows are not stored).  This was the first
+            // suspect for the two wrong stem rows in lanes 48..63 (a late matrix write landing on reused registers) and is NOT the
+            // cause: with the accumulators always consumed the wrong rows stayed (profiles/r3_pk_fma_hazard.md, fourth table row);
+            // they went away with the packed FMAs of the stem (fma_pinned above, -fno-slp-vectorize).  Kept because it is harmless.
             const int m = (t0 >> 1) + li;
             const bool st = emit && m < p.M;
             float* yr = p.y + yb_off + (long long)m * 64 + 4 * kq;

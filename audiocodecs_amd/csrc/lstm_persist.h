@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void lstm_persist_kernel(const LstmPersistPara
     const int x = s_x & 7, slot = s_slot;
     const int g = x >> 1;                                     // clip group of this launch
     const int G = (p.B + 15) >> 4;
-    if (slot >= 32) {   // placement broken (see lstm_persist6.h)
+    if (slot >= 32) {   // placement broken (see lstm_persist16.h)
         if (tid == 0) __hip_atomic_store(tmo, 2u, LP_RLX);
         return;
     }

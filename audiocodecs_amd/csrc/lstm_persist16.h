@@ -1,5 +1,5 @@
-// lstm_persist16: the persistent 2-layer LSTM (lstm_persist.h: mathematics, control words, bounded waits, tail kernel;
-// lstm_persist6.h: self-validating exchange) in split16.h arithmetic -- two fp16 planes per operand, 3 partial products --
+// lstm_persist16: the persistent 2-layer LSTM (lstm_persist.h: mathematics, control words, bounded waits, tail kernel)
+// with a self-validating exchange of h (below), in split16.h arithmetic -- two fp16 planes per operand, 3 partial products --
 // re-scheduled around what the round-2 traces of the 4-wave kernel showed (tools/ubench/xcd_exchange2.hip, AC_LSTM_DBG=32):
 //   * EIGHT waves per workgroup (one workgroup per CU, two waves per SIMD): a wave owns an EIGHTH of K for the workgroup's 64 gate
 //     columns, so its share of the two weight matrices of its layer is 128 registers and everything fits the 256 architectural
@@ -21,10 +21,39 @@
 // when the gates saturate, and fp16(2.0) has bit 14 set: hi is capped at the largest fp16 below 2, lo takes the rest; the rows of
 // [W_ih | W_hh] of a layer share one power-of-two scale per gate row; the fused layer-0 projection scales x[t] by its clip's amax
 // scale and rescales the result to the recurrent product's units (exact).  A slice block is [2 planes][16 clips][16 units] fp16.
+// (Rounds 1-3 carried a 4-wave ancestor with three bf16 planes per operand, lstm_persist6.h; removed in round 4 with that arithmetic.)
 #pragma once
-#include "lstm_persist6.h"
+#include "lstm_persist.h"
+#include "tap_gemm6.h"
+#include "rb_fused6.h"
+#include <type_traits>
 
 namespace ac {
+
+// A slice's block of h for one time step and 16-clip group: [2 planes][16 clips][16 units] fp16 (1024 B), so a consumer lane
+// (clip i, kq) fetches the 8 units 32 ks + 8 kq .. of a k-step with one 16-byte load per plane from slice 2 ks + kq / 2.
+// SELF-VALIDATING exchange: the host fills the h buffers with 0xFF bytes before the launch; every published fp16 term has
+// |v| < 2, i.e. bit 14 (the exponent's top bit) clear, the fill pattern has it set.  A consumer therefore needs no flag: it
+// loads the operand and looks at bit 14 of every element -- the data says itself whether it has arrived, in whatever order the
+// memory system performs the loads.  One round trip instead of flag poll + dependent load; spins are bounded by the timeout word.
+constexpr int LP16_SLICE_BYTES = 2 * 16 * 16 * 2;    // 1024
+constexpr long long LP16_GROUP_BYTES = (long long)LP_SLICES * LP16_SLICE_BYTES;
+
+struct LstmPersist16Params {
+    LstmPersistParams base;     // hseq0 / hseq1 are byte buffers of fp16 plane blocks here; h_ts = bytes per time step
+    const __bf16* w_pk6;        // [hh0, ih1, hh1, ih0][32 slices][4 waves][4 gates][4 k-steps of 32][2 planes][64 lanes][8 fp16] register images
+    const float* bias0;         // fuse_in: b_ih0 + b_hh0 [4D]
+    int fuse_in;                // 1: the layer-0 slices compute W_ih0 * x[t] themselves (x = base.skip, fp32 [B][T][D]) instead of
+                                //    reading a pre-computed gin0 -- the [T*B][4D] projection GEMM and its HBM round trip disappear;
+                                //    layer 0 has the slack (its step is shorter than layer 1's, which bounds the kernel)
+    int* poison;                // [all clips] first time step at which a clip's state went non-finite (INT_MAX-like fill
+                                //    = never): see the publish step and lstm_tail_kernel
+    // per gate row 2^-s of layer 0's [W_ih0 | W_hh0] and of layer 1's [W_ih1 | W_hh1] rows ([2][4D]: the two matrices of a layer
+    // share the accumulator, so their rows share the scale); amax slot of x (indexed by clip, fuse_in only)
+    const float* winv;
+    const unsigned* amax_x;
+    void* hseq0_local;          // layer 0's own copy of h0 (same layout as hseq0)
+};
 
 #ifndef LP16_HEXP
 #define LP16_HEXP 1                                  // h travels as 2^LP16_HEXP h (0: unscaled)
@@ -35,10 +64,10 @@ constexpr float LP16_HSCALE = LP16_HEXP ? 2.0f : 1.0f, LP16_HINV = LP16_HEXP ? 0
 #endif
 constexpr int LP16_BATCH = LP16_BATCH_N;                        // steps of h0 per hand-over to layer 1
 
-// FUSE: compile-time copy of LstmPersist6Params::fuse_in (a run-time branch around the gin loads would make the compiler wait
+// FUSE: compile-time copy of LstmPersist16Params::fuse_in (a run-time branch around the gin loads would make the compiler wait
 // for ALL outstanding memory operations in front of the gate arithmetic)
 template <bool FUSE>
-__global__ __launch_bounds__(512) void lstm_persist16_kernel(const LstmPersist6Params pp) {
+__global__ __launch_bounds__(512) void lstm_persist16_kernel(const LstmPersist16Params pp) {
     const LstmPersistParams& p = pp.base;
     constexpr int D = LP_D, NP = 2;
     constexpr int SLICE_BYTES = LP16_SLICE_BYTES;
@@ -149,7 +178,7 @@ __global__ __launch_bounds__(512) void lstm_persist16_kernel(const LstmPersist6P
             }
         return __all((bad & 0x40004000u) == 0u);
     };
-    // SELF-VALIDATING exchange (lstm_persist6.h): the h buffers start as 0xFF bytes; spins are bounded by the timeout word
+    // SELF-VALIDATING exchange (above): the h buffers start as 0xFF bytes; spins are bounded by the timeout word
     auto load_valid = [&](const char* seq, int t, bf16x8 (&a)[2][2]) -> bool {
         for (unsigned spins = 0;; ++spins) {
             load_a(seq, t, a);
@@ -297,7 +326,7 @@ __global__ __launch_bounds__(512) void lstm_persist16_kernel(const LstmPersist6P
             hn = og * tanh_rcp(cstate);
             LP16_TRC(6);
             // ---- publish h[t] (no flag, no wait).  A non-finite state must not look like "not yet written": publish a finite
-            // stand-in and record the step; lstm_tail_kernel turns this clip's outputs from that step on into NaN (lstm_persist6.h)
+            // stand-in and record the step; lstm_tail_kernel turns this clip's outputs from that step on into NaN (above)
             const bool nonfinite = !(fabsf(hn) < 2.0f);
             if (nonfinite && live) atomicMin(pp.poison + erow, t);
             const float hp = nonfinite ? 0.f : hn;

@@ -95,7 +95,7 @@ int layernorm_fwd(ac_handle* h, hipStream_t st, const float* x, size_t w_off, si
     LayerNormParams p{x, h->blob + w_off, h->blob + b_off, y, rows, H, eps, nullptr};
     if (rows_out) {                       // row words for the linear layer that reads y (split16.h row mode); every row is written
         *rows_out = nullptr;
-        if (!h->gemm_fp32 && !h->gemm_bf16 && rows <= 0x7fffffffLL) p.rowmax = rowmax_new(h, st, rows, false);
+        if (!h->gemm_fp32 && rows <= 0x7fffffffLL) p.rowmax = rowmax_new(h, st, rows, false);
         *rows_out = p.rowmax;
     }
     ProfScope ps(h, st, "layernorm_kernel", 8.0 * rows * H, 8.0 * rows * H);

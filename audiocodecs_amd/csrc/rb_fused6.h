@@ -71,58 +71,27 @@ struct Rb6Cfg {
     static constexpr int XE_ROWS = BM + 2;
     static constexpr int XE_PLANE = XE_ROWS * XP, XR_PLANE = SC ? BM * XP : 0, H_PLANE = BM * HP;
     static constexpr int SLOTS = (XE_ROWS * (C / 4) + 255) / 256;
-    static constexpr size_t lds_bytes = (size_t)3 * (XE_PLANE + XR_PLANE + H_PLANE) * 2;
     static constexpr size_t lds_bytes16 = (size_t)2 * (XE_PLANE + XR_PLANE + H_PLANE) * 2;   // split16.h: two planes
 };
 
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 
-// exact truncation split, value bits left in the upper half of each word
-__device__ __forceinline__ void split3(float v, unsigned& h, unsigned& m, unsigned& l) {
-    h = __float_as_uint(v) & 0xffff0000u;
-    const float r1 = v - __uint_as_float(h);
-    m = __float_as_uint(r1) & 0xffff0000u;
-    l = __float_as_uint(r1 - __uint_as_float(m));
-}
-
-// 4 fp32 -> 4 bf16 per plane, stored as 8 bytes at element offset `o` of each plane.  NP = 1 (the opt-in bf16 mode,
-// ac_set_precision): ONE plane, rounded to nearest-even -- no split.
-template <int NP = 3>
+// 4 fp32 -> 4 fp16 per plane (split16.h: scaled value = hi + lo), stored as 8 bytes at element offset `o` of each plane.
+// (NP: the number of operand planes.  Rounds 1-3 also instantiated 3 bf16 planes / 6 products and a rounded single plane; only
+//  split16 remains, the template argument stays in the kernel names the profiles carry.)
+template <int NP = 2>
 __device__ __forceinline__ void split_store4(const f32x4 v, __bf16* p0, int plane, int o, float scale = 1.f) {
-    if (NP == 2) {   // split16.h
-        split16_store4s(v, scale, p0, plane, o);
-        return;
-    }
-    if (NP == 1) {
-        typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
-        *reinterpret_cast<bf16x4_t*>(p0 + o) = __builtin_convertvector(v, bf16x4_t);
-        return;
-    }
-    unsigned h[4], m[4], l[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) split3(v[i], h[i], m[i], l[i]);
-    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-    *reinterpret_cast<u32x2*>(p0 + o) = u32x2{(h[0] >> 16) | h[1], (h[2] >> 16) | h[3]};
-    *reinterpret_cast<u32x2*>(p0 + plane + o) = u32x2{(m[0] >> 16) | m[1], (m[2] >> 16) | m[3]};
-    *reinterpret_cast<u32x2*>(p0 + 2 * plane + o) = u32x2{(l[0] >> 16) | (l[1] & 0xffff0000u), (l[2] >> 16) | (l[3] & 0xffff0000u)};
+    static_assert(NP == 2, "split16 arithmetic only");
+    split16_store4s(v, scale, p0, plane, o);
 }
 
-// acc (+)= W x^T over one k-step: 6 partial products, small terms first (NP = 1: the single bf16 product).  w / x: [plane]
-template <int NP = 3>
+// acc (+)= W x^T over one k-step: lo hi, hi lo, hi hi on the fp16 pipe (small terms first).  w / x: [plane]
+template <int NP = 2>
 __device__ __forceinline__ f32x4 mma6(const bf16x8 (&w)[3], const bf16x8 (&x)[3], f32x4 v) {
-    if (NP == 1) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[0], x[0], v, 0, 0, 0);
-    if (NP == 2) {   // split16.h: lo hi, hi lo, hi hi on the fp16 pipe
-        v = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w[1]), __builtin_bit_cast(f16x8, x[0]), v, 0, 0, 0);
-        v = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w[0]), __builtin_bit_cast(f16x8, x[1]), v, 0, 0, 0);
-        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w[0]), __builtin_bit_cast(f16x8, x[0]), v, 0, 0, 0);
-    }
-    v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[2], x[0], v, 0, 0, 0);   // l h
-    v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[0], x[2], v, 0, 0, 0);   // h l
-    v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[1], x[1], v, 0, 0, 0);   // m m
-    v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[1], x[0], v, 0, 0, 0);   // m h
-    v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[0], x[1], v, 0, 0, 0);   // h m
-    v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[0], x[0], v, 0, 0, 0);   // h h
-    return v;
+    static_assert(NP == 2, "split16 arithmetic only");
+    v = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w[1]), __builtin_bit_cast(f16x8, x[0]), v, 0, 0, 0);
+    v = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w[0]), __builtin_bit_cast(f16x8, x[1]), v, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w[0]), __builtin_bit_cast(f16x8, x[0]), v, 0, 0, 0);
 }
 
 // split16: two LDS planes and two thirds of the weight registers leave room for one more workgroup per CU where the kernel
@@ -130,7 +99,7 @@ __device__ __forceinline__ f32x4 mma6(const bf16x8 (&w)[3], const bf16x8 (&x)[3]
 // 12 / 43 registers at the higher occupancy and run 1.2-1.8x slower
 template <int C, bool SC, int NP>
 constexpr int rb6_occupancy() { return (C == 64 ? 2 : 3) + ((NP == 2 && C == 64 && !SC) ? 1 : 0); }
-template <int C, bool SC, int NP = 3>
+template <int C, bool SC, int NP = 2>
 __global__ __launch_bounds__(256, (rb6_occupancy<C, SC, NP>())) void rb_fused6_kernel(const RbFused6Params p) {
     using Cfg = Rb6Cfg<C, SC>;
     constexpr int BM = Cfg::BM, HC = Cfg::HC, XP = Cfg::XP, HP = Cfg::HP;

@@ -28,7 +28,7 @@ struct Rb128Cfg {
     static constexpr size_t lds_bytes = (size_t)3 * (XE_PLANE + XR_PLANE + H_PLANE) * 2 + (size_t)BM * PSP * 4;
 };
 
-template <bool SC, int NP = 3>
+template <bool SC, int NP = 2>
 __global__ __launch_bounds__(512, 1) void rb128_fused6_kernel(const RbFused6Params p) {
     using Cfg = Rb128Cfg<SC>;
     constexpr int C = Cfg::C, BM = Cfg::BM, NT = Cfg::NT, XP = Cfg::XP, HP = Cfg::HP, TT = Cfg::TT;

@@ -72,6 +72,15 @@ __device__ __forceinline__ void amax_flush(unsigned mx, unsigned* slot) {
     if ((threadIdx.x & 63) == 0 && mx > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, mx);
 }
 
+// acc = a * b + acc as ONE v_fma_f32 that no vectoriser can pack.  The fused encoder front's stem returned wrong, run-to-run different
+// values when SLP vectorisation turned its scalar FMAs into v_pk_fma_f32 with op_sel broadcasts (profiles/r3_pk_fma_hazard.md: only
+// with a second wave on the SIMD, mechanism not established).  -fno-slp-vectorize (build.sh) keeps the rest of the library free of them;
+// the stem does not depend on the flag, and csrc/check_isa.sh fails the build if a packed FMA appears in the fused chains.
+__device__ __forceinline__ float fma_pinned(float a, float b, float acc) {
+    asm("v_fma_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+    return acc;
+}
+
 // 4 fp32 values x scale -> hi / lo fp16 planes, 8 bytes each at element offset `o` (planes `plane` elements apart):
 //   hi = fp16(v s),  lo = fp16(fma(v, s, -hi))   -- v_fma_mixlo/mixhi_f16 does the fma on the fp16 `hi` and the rounding of the
 // result in ONE instruction: two instructions per value in all (v_pk_mul, v_cvt_pk, 2 x v_fma_mix per pair)

@@ -1,21 +1,19 @@
-// tap_gemm6: the tap-GEMM (tap_gemm.h: conv -> GEMM mapping, padding rules, epilogue terms) on the bf16 matrix
-// pipe with fp32 fidelity -- "split-operand" arithmetic:
-//     every fp32 operand is written EXACTLY as hi + mid + lo, three bf16 terms of 8 significand bits (truncation
-//     split), and a product a*b is accumulated in fp32 from 6 of its 9 partial products a_i*b_j (each exact):
-//     hh, hm, mh, mm, hl, lh; the dropped ml, lm, ll are below 2^-23 of the product -- the size of ONE fp32 rounding.
-//     Measured (tools/ubench/bf16x_gemm.hip, K = 1024): rms error 5.08e-7 of the rms value, an fp32 fma chain has
-//     5.56e-7 on the same data.  v_mfma_f32_32x32x16_bf16 runs 16x the fp32 MFMA rate, so 6 terms cost 0.375x of
-//     the fp32-MFMA time: the kernel's roofline moves from 157 to 417 fp32-equivalent TFLOP/s.
-// The probe also showed what binds such a kernel: LDS bandwidth (three planes of fragments).  Hence
+// tap_gemm6: the tap-GEMM (tap_gemm.h: conv -> GEMM mapping, padding rules, epilogue terms) on the fp16 matrix pipe with
+// fp32 fidelity -- split16.h arithmetic: every fp32 operand, scaled by a power of two, is written as hi + lo, two fp16 terms,
+// and a product is accumulated in fp32 from 3 of its 4 exact partial products (lo hi, hi lo, hi hi).
+// v_mfma_f32_32x32x16_f16 runs 16x the fp32 MFMA rate, so 3 terms cost 0.19x of the fp32-MFMA time: the kernel's roofline moves
+// from 157 to 833 fp32-equivalent TFLOP/s.  What binds such a kernel is operand traffic (LDS, L1).  Hence
 //   * the weight operand never touches LDS: it is split and packed OFFLINE in MFMA B-fragment order
-//       wp[n-tile of 32][k-step of 16][plane 3][lane 64][8 bf16]        (a wave-load = 1 KB contiguous per plane)
+//       wp[n-tile of 32][k-step of 16][plane 2][lane 64][8 fp16] of the SCALED rows  (a wave-load = 1 KB contiguous per plane)
 //     and loaded from L2 straight into registers one k-step ahead;
 //   * the activation operand is loaded exactly like in tap_gemm4 (buffer loads with per-slot constant offsets,
-//     clip-edge rules) and split ONCE, while it is staged into a double-buffered LDS slab of three bf16 planes.
-// Workgroup = 4 waves as WGM x WGN, wave tile 32*WMT x 32*WN, BM = 128, KC = 32 (two k-steps) per stage:
-//   <2,2,2,2> BN = 128;  <2,2,2,1> BN = 64;  <4,1,1,3> BN = 96 (the 96 / 192-wide DAC layers).
+//     clip-edge rules) and split ONCE, while it is staged into a double-buffered LDS slab of two fp16 planes.
+// Workgroup = 4 or 8 waves as WGM x WGN, wave tile 32*WMT x 32*WN, BM = 128, KC = 32 (two k-steps) per stage:
+//   <1,4,4,1> BN = 128;  <1,4,4,2> BN = 256;  <1,8,4,1> BN = 256;  <2,2,2,3> BN = 192, <4,1,1,3> BN = 96 (DAC), <2,2,2,1> BN = 64.
 // Requirements beyond tap_gemm4's: N % 32 == 0 and every segment's kofs % 32 == 0 (k-steps align with stages).
-// The exact-product kernel tap_gemm4 stays selectable (environment AC_GEMM=fp32) and serves every other shape.
+// The exact-product kernel tap_gemm4 stays selectable (AC_PRECISION_FP32_EXACT / AC_GEMM=fp32) and serves every other shape.
+// (Rounds 1-3 also instantiated NP = 3 -- three bf16 planes, 6 products -- and NP = 1, a rounded-bf16 side mode; both removed in
+//  round 4.  The template argument NP = 2 stays: it is part of the kernel names the committed profiles carry.)
 #pragma once
 #include "tap_gemm4.h"
 #include "split16.h"
@@ -51,11 +49,11 @@ struct Tap6Cfg {
     // the epilogue stages EH 32-row tiles of the workgroup's rows at a time (WGM = 1: two of the four -- half the staging tile)
     static constexpr int EH = WGM == 1 && WMT == 4 ? 2 : WMT;
     static constexpr size_t epi_bytes = (size_t)32 * WGM * EH * CP * 4;
-    static constexpr size_t lds_for(int np) {               // np = 2 (split16.h): two planes in the slab
-        const size_t main_bytes = (size_t)2 * (np == 2 ? 2 : 3) * PLANE * 2;
+    static constexpr size_t lds_for(int np) {               // two buffers x two planes (np = 2, split16.h)
+        const size_t main_bytes = (size_t)2 * np * PLANE * 2;
         return main_bytes > epi_bytes ? main_bytes : epi_bytes;
     }
-    static constexpr size_t lds_bytes = lds_for(3);
+    static constexpr size_t lds_bytes = lds_for(2);
 };
 // workgroups per CU the kernel is compiled for: the 128 x 32 wave tile in split16 arithmetic runs the lean main loop (one
 // fragment set) and fits three -- the epilogue of a workgroup (as long as its output takes to reach HBM) is then covered by two
@@ -65,14 +63,11 @@ constexpr int tap6_occupancy() {
     return WGM * WGN == 8 ? 1 : (NP == 2 && ((WMT * WN == 4 && WGM == 1) || (WGM == 2 && WGN == 2 && WMT == 2 && WN == 1)) ? 3 : 2);   // (64 x 32 wave tiles, N % 64: 156 VGPRs as they are)
 }
 
-// NP = 3: split-operand arithmetic (three bf16 planes per operand, 6 partial products): fp32 fidelity -- the default.
-// NP = 1: the opt-in bf16 mode (ac_set_precision(AC_PRECISION_BF16)): operands ROUNDED to bf16 (nearest-even), one product,
-//         fp32 accumulate; the weight image then holds round(w) in plane 0.  Never the parity path.
-// NP = 2: split16.h -- two fp16 planes per operand, 3 partial products, per-clip / per-output-channel power-of-two scales:
-//         the same fp32 fidelity at half the MFMAs and two thirds of the operand bytes.  Weight image
-//         [n-tile of 32][k-step of 16][plane 2][lane 64][8 fp16] of the SCALED rows; needs seg[].amax and winv.
-template <int WGM, int WGN, int WMT, int WN, int NP = 3, int HALO = 7>
+// NP = 2: split16.h -- two fp16 planes per operand, 3 partial products, per-clip / per-output-channel power-of-two scales.
+// Weight image [n-tile of 32][k-step of 16][plane 2][lane 64][8 fp16] of the SCALED rows; needs seg[].amax and winv.
+template <int WGM, int WGN, int WMT, int WN, int NP = 2, int HALO = 7>
 __global__ __launch_bounds__(64 * WGM * WGN, (tap6_occupancy<WGM, WGN, WMT, WN, NP>())) void tap_gemm6_kernel(const TapGemmParams p, const __bf16* __restrict__ wp) {
+    static_assert(NP == 2, "split16 arithmetic only");
     using Cfg = Tap6Cfg<WGM, WGN, WMT, WN, HALO>;
     constexpr int BM = Cfg::BM, BN = Cfg::BN, NT = Cfg::NT, A_SLOTS = Cfg::A_SLOTS, PLANE = Cfg::PLANE;
     unsigned long long clk_t0 = 0, clk_r0 = 0;
@@ -84,7 +79,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (tap6_occupancy<WGM, WGN, WMT, WN, 
     }
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __bf16* As0 = reinterpret_cast<__bf16*>(smem);            // [2 buffers][NPL planes][A_ROWS][T6_PITCH]
-    constexpr int NPL = NP == 2 ? 2 : 3;
+    constexpr int NPL = 2;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -217,44 +212,18 @@ __global__ __launch_bounds__(64 * WGM * WGN, (tap6_occupancy<WGM, WGN, WMT, WN, 
 #pragma unroll
         for (int i = 0; i < A_SLOTS; ++i) ra[i] = bufload16(a_rs, voff[i], soff);
     };
-    // split 4 fp32 into the three bf16 planes (exact: v = hi + mid + lo) and store them
+    // split 4 fp32 into the two fp16 planes (split16.h: scaled value = hi + lo) and store them
     auto store_a = [&](__bf16* dst) {
 #pragma unroll
         for (int i = 0; i < A_SLOTS; ++i)
             if (a_lds[i] >= 0) {
                 const f32x4 v = (a_zero & (1u << i)) ? f32x4{0.f, 0.f, 0.f, 0.f} : ra[i];
-                if (NP == 1) {   // bf16 mode: round to nearest even, one plane
-                    typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
-                    *reinterpret_cast<bf16x4_t*>(dst + a_lds[i]) = __builtin_convertvector(v, bf16x4_t);
-                    continue;
-                }
-                if (NP == 2) {   // split16.h: scaled value = hi + lo in fp16
-                    split16_store4s(v, a_rsc[i], dst, PLANE, a_lds[i]);
-                    continue;
-                }
-                unsigned h[4], m[4], l[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-#ifdef T6_NOSPLIT   // developer timing variant (wrong results): what would the kernel do if the split were free?
-                    h[e] = m[e] = l[e] = __float_as_uint(v[e]);
-#else
-                    const unsigned bh = __float_as_uint(v[e]) & 0xffff0000u;
-                    const float r1 = v[e] - __uint_as_float(bh);
-                    const unsigned bm = __float_as_uint(r1) & 0xffff0000u;
-                    h[e] = bh; m[e] = bm; l[e] = __float_as_uint(r1 - __uint_as_float(bm));
-#endif
-                }
-                unsigned* dh = reinterpret_cast<unsigned*>(dst + a_lds[i]);
-                unsigned* dm = reinterpret_cast<unsigned*>(dst + PLANE + a_lds[i]);
-                unsigned* dl = reinterpret_cast<unsigned*>(dst + 2 * PLANE + a_lds[i]);
-                dh[0] = (h[0] >> 16) | h[1]; dh[1] = (h[2] >> 16) | h[3];
-                dm[0] = (m[0] >> 16) | m[1]; dm[1] = (m[2] >> 16) | m[3];
-                dl[0] = (l[0] >> 16) | (l[1] & 0xffff0000u); dl[1] = (l[2] >> 16) | (l[3] & 0xffff0000u);
+                split16_store4s(v, a_rsc[i], dst, PLANE, a_lds[i]);
             }
     };
     // B fragments of this wave's WN column tiles for ONE k-step: [plane][c]; k-step index inside the packed rows
     const int ksteps = p.Ktot >> 4;
-    constexpr int WPL = NP == 2 ? 2 : 3;    // planes in the weight image
+    constexpr int WPL = 2;    // planes in the weight image
     const __bf16* wbase = wp + ((long long)((n0 + wn * 32 * WN) >> 5) * ksteps) * (WPL * 64 * 8) + lane * 8;
     auto load_b = [&](int s_, bf16x8 (&bf)[3][WN]) {
 #pragma unroll
@@ -300,24 +269,10 @@ __global__ __launch_bounds__(64 * WGM * WGN, (tap6_occupancy<WGM, WGN, WMT, WN, 
 #pragma unroll
             for (int c = 0; c < WN; ++c) {
                 f32x16 v = acc[a][c];
-                if (NP == 1) {
-                    acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][a], bf[0][c], v, 0, 0, 0);
-                    continue;
-                }
-                if (NP == 2) {   // lo hi, hi lo, hi hi
-                    v = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[1][a]), __builtin_bit_cast(f16x8, bf[0][c]), v, 0, 0, 0);
-                    v = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[0][a]), __builtin_bit_cast(f16x8, bf[1][c]), v, 0, 0, 0);
-                    acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[0][a]), __builtin_bit_cast(f16x8, bf[0][c]), v, 0, 0, 0);
-                    continue;
-                }
-                // smallest partial products first: hl, lh, mm, hm, mh, hh
-                v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][a], bf[2][c], v, 0, 0, 0);
-                v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][a], bf[0][c], v, 0, 0, 0);
-                v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][a], bf[1][c], v, 0, 0, 0);
-                v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][a], bf[1][c], v, 0, 0, 0);
-                v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][a], bf[0][c], v, 0, 0, 0);
-                v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][a], bf[0][c], v, 0, 0, 0);
-                acc[a][c] = v;
+                // lo hi, hi lo, hi hi (small terms first)
+                v = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[1][a]), __builtin_bit_cast(f16x8, bf[0][c]), v, 0, 0, 0);
+                v = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[0][a]), __builtin_bit_cast(f16x8, bf[1][c]), v, 0, 0, 0);
+                acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[0][a]), __builtin_bit_cast(f16x8, bf[0][c]), v, 0, 0, 0);
             }
     };
 #ifdef T6_TRACE

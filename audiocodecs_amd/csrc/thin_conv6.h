@@ -39,7 +39,7 @@ constexpr int T6_PLANE = T6_ROWS * T6_XP;
 constexpr int T6_SLOTS = (T6_ROWS * 16 + 255) / 256;        // float4 slots per thread
 constexpr size_t T6_LDS = (size_t)3 * T6_PLANE * 2;
 
-template <int NP = 3>
+template <int NP = 2>
 __global__ __launch_bounds__(256, 4) void thin_conv6_kernel(const ThinConv6Params p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __bf16* Xs = reinterpret_cast<__bf16*>(smem);           // [3][T6_ROWS][T6_XP]: slab row r = super-row m0 - 1 + r

@@ -282,7 +282,7 @@ int wavtok_decoder_fwd(ac_handle* h, hipStream_t st, const float* feats, int B, 
         const unsigned* t_rows = nullptr;
         {
             DwLnParams p{x, h->blob + L.dww, h->blob + L.dwb, h->blob + L.sc, h->blob + L.sh, t, B, N, C, 1e-6f, nullptr};
-            if (!h->gemm_fp32 && !h->gemm_bf16) p.rowmax = rowmax_new(h, st, rows, false);   // row words for p1 (split16.h row mode)
+            if (!h->gemm_fp32) p.rowmax = rowmax_new(h, st, rows, false);   // row words for p1 (split16.h row mode)
             t_rows = p.rowmax;
             ProfScope ps(h, st, "dwconv_ln_kernel", 2.0 * rows * C * 7, 8.0 * rows * C);
             hipLaunchKernelGGL(dwconv_ln_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, p);

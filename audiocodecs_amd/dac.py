@@ -144,7 +144,7 @@ class DAC(Codec):
         self.num_codebooks = num_codebooks
         self.vocab_size = 1024  # dac.py:52
         self.latent = latent
-        self.precision = _native.check_precision(precision)   # see Encodec: None / "fp32" (parity arithmetic), "fp32_exact", "bf16" (opt-in)
+        self.precision = _native.check_precision(precision)   # see Encodec: None / "fp32" (parity arithmetic), "fp32_exact"
         tag = int(orig_sample_rate / 1000)  # dac.py:55
         if config is None:
             if tag not in _BY_TAG:

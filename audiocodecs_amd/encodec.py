@@ -107,8 +107,8 @@ class Encodec(Codec):
         `safetensors.torch.load_file(model.safetensors)` of facebook/encodec_24khz, or
         `checkpoint.synthetic_state_dict(cfg, seed)`).  When omitted the pretrained checkpoint is
         fetched through huggingface_hub like the reference does (needs network or a warm cache).
-        `precision`: None / "fp32" = fp32 fidelity (the parity arithmetic, default); "fp32_exact" = exact fp32 products;
-        "bf16" = OPT-IN reduced precision for the tap-GEMMs (include/audiocodecs_amd.h ac_set_precision) -- not a parity mode."""
+        `precision`: None / "fp32" = fp32 fidelity on the fp16 matrix pipe (split16: the parity arithmetic, default);
+        "fp32_exact" = exact fp32 products (include/audiocodecs_amd.h ac_set_precision)."""
         super().__init__(sample_rate, orig_sample_rate, mode)
         self.strict = bool(strict)   # codec.py: poll the handle after every call
         self.precision = _native.check_precision(precision)

@@ -100,7 +100,7 @@ class Mimi(Codec):
         self.vocab_size = config.codebook_size  # 2048 (mimi.py:40)
         self.latent = latent
         self.config = config
-        self.precision = _native.check_precision(precision)   # see Encodec: None / "fp32" (parity arithmetic), "fp32_exact", "bf16" (opt-in)
+        self.precision = _native.check_precision(precision)   # see Encodec: None / "fp32" (parity arithmetic), "fp32_exact"
         if state_dict is None:
             state_dict = self._fetch_pretrained()
         self._sd = {k: v for k, v in state_dict.items()}

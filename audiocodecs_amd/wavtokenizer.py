@@ -117,7 +117,7 @@ class WavTokenizer(Codec):
         self.num_codebooks = 1
         self.vocab_size = arch.codebook_size  # 4096 (wavtokenizer.py:70)
         self.arch = arch
-        self.precision = _native.check_precision(precision)   # see Encodec: None / "fp32" (parity arithmetic), "fp32_exact", "bf16" (opt-in)
+        self.precision = _native.check_precision(precision)   # see Encodec: None / "fp32" (parity arithmetic), "fp32_exact"
         if state_dict is None:
             state_dict = self._fetch_pretrained(source, checkpoint)
         # Upstream's from_pretrained0802 keeps the generator only; a Lightning checkpoint also carries the discriminators and the

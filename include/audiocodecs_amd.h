@@ -212,20 +212,12 @@ int ac_load_weights(ac_handle* h, const char* name, const void* host_ptr, size_t
  *                            power-of-two scales per clip (activations: largest magnitude reported by the producing kernel), per
  *                            row (linear layers over merged token matrices) and per output channel (weights) -- the arithmetic
  *                            every parity claim is made for;
- *   AC_PRECISION_FP32_BF16X3 the round-1/2 arithmetic: three bf16 planes (exact truncation split), 6 partial products; same
- *                            fidelity, no scales, ~1.3x slower; same as AC_GEMM=bf16x3;
  *   AC_PRECISION_FP32_EXACT  exact fp32 products (v_mfma_f32_16x16x4_f32) everywhere; same as AC_GEMM=fp32;
- *   AC_PRECISION_BF16        OPT-IN, not a parity mode (BASELINE.json configs[1] says "bf16"): the
- *                            tap-GEMMs, the fused residual blocks and the [64][128] layers -- i.e. every conv of the SEANet
- *                            stacks incl. the T >= 120 000 stages, and the dense layers of the transformers / backbone --
- *                            round both operands to bf16 (nearest-even) and do ONE product per pair with fp32 accumulate;
- *                            activations stay fp32 in HBM; LSTM (split16), stem / head, codebook search stay fp32-faithful.  Reported
- *                            with its own token-mismatch rate and waveform error (bench.py --precision bf16); = AC_GEMM=bf16.
- * Without this call the environment variable AC_GEMM (fp32 | bf16 | bf16x3) decides, default AC_PRECISION_FP32. */
+ * (Rounds 1-3 also carried a three-bf16-plane arithmetic and an opt-in rounded-bf16 side mode; both were removed in round 4: neither
+ * had a user, and the side mode kept fp32 activations in HBM -- no parity and no bandwidth saving.  Values 2 and 3 are rejected.)
+ * Without this call the environment variable AC_GEMM=fp32 selects the exact-product kernels, default AC_PRECISION_FP32. */
 #define AC_PRECISION_FP32 0
 #define AC_PRECISION_FP32_EXACT 1
-#define AC_PRECISION_BF16 2
-#define AC_PRECISION_FP32_BF16X3 3
 int ac_set_precision(ac_handle* h, int precision);
 
 /* Check that every tensor of the configuration arrived, fold/pack them into the kernels' layouts
@@ -329,6 +321,11 @@ int ac_profile_end(ac_handle* h, ac_kernel_stat* out, int cap);
  * ac_debug_captured returns the floats appended so far (may exceed cap_floats: nothing is written
  * past the capacity).  Disarm with ac_debug_capture(h, NULL, 0). */
 int ac_debug_capture(ac_handle* h, float* buf_dev, size_t cap_floats);
+/* Developer / test switches of a handle (A/B paths, fault injection, timing variants): "tap_epi_staged", "tap_dil", "tap_stagger",
+ * "tap_pick", "rb6_dbg", "front_seg", "tail_seg", "front_ldspad", "lstm_dbg", "lstm_fuse_in", "rvq_exact", "prof_detail".  Their
+ * initial values come from the environment variables of the same meaning (AC_TAP_EPI, AC_TAP_DIL, ...), read ONCE, at ac_finalize; no
+ * compute entry point reads the environment.  Not part of the product interface. */
+int ac_debug_set(ac_handle* h, const char* key, int value);
 size_t ac_debug_captured(const ac_handle* h);
 
 /* Test hook: the constants of the BOUNDS that stand in for an amax where a tensor exists only inside a fused kernel

@@ -180,9 +180,10 @@ def test_errors_and_codebook_clamp(codecs, dac_checkpoints):
 def test_dilated_taps_from_one_slab_equal_the_reload_per_tap_path(dac_checkpoints, monkeypatch):
     """csrc/tap_gemm6.h T6_DIL_HALO: the dilated k7 convs of the residual units read their seven taps from one wide A slab per
     chunk (the instantiation run_tap picks where it measured faster) instead of reloading the slab per tap.  Both walk
-    (chunk, tap) in the same order, so tokens AND waveform must be bit-equal between the two (AC_TAP_DIL=0 = reload path),
+    (chunk, tap) in the same order, so tokens AND waveform must be bit-equal between the two (ac_debug_set tap_dil = 0: reload path),
     also at lengths that put clip edges inside the halo."""
     from audiocodecs_amd import DAC
+    from audiocodecs_amd._native import debug_set
 
     cfg, sd = dac_checkpoints("full", 0)
     codec = DAC(44100, 44100, num_codebooks=9, state_dict=sd, config=cfg).eval()
@@ -192,12 +193,12 @@ def test_dilated_taps_from_one_slab_equal_the_reload_per_tap_path(dac_checkpoint
         assert any(", dil>" in n for n in names), names              # the wide-slab instantiation is what runs by default (decoder: 96 / 192 / 384 / 768 channels)
         toks, rec = codec.sig_to_toks(sig), None
         rec = codec.toks_to_sig(toks)
-        monkeypatch.setenv("AC_TAP_DIL", "0")
+        debug_set(codec, "tap_dil", 0)
         names0 = {s[0] for s in codec.profile_kernels(lambda: codec.toks_to_sig(codec.sig_to_toks(sig)))}
         assert not any(", dil>" in n for n in names0), names0
         toks0 = codec.sig_to_toks(sig)
         rec0 = codec.toks_to_sig(toks)
-        monkeypatch.delenv("AC_TAP_DIL")
+        debug_set(codec, "tap_dil", 1)
         assert torch.equal(toks, toks0), (B, T)
         assert torch.equal(rec, rec0), (B, T)
 
@@ -206,9 +207,10 @@ def test_dilated_taps_from_one_slab_equal_the_reload_per_tap_path(dac_checkpoint
 def test_direct_epilogue_equals_the_staged_one(codec_name, dac_checkpoints, checkpoints, monkeypatch):
     """csrc/tap_gemm6.h: conv outputs leave the accumulators either through the direct epilogue (one 4-byte store per value;
     plain / ELU flavours of 128-column layers, and -- with residual / Snake copies -- DAC's layers under 128 channels) or
-    through LDS-staged 16-byte rows (AC_TAP_EPI=staged forces it everywhere).  The same operations in the same order per
+    through LDS-staged 16-byte rows (ac_debug_set tap_epi_staged = 1 forces it everywhere).  The same operations in the same order per
     element: tokens and waveform must be bit-equal, edge tiles included."""
     from audiocodecs_amd import DAC, Encodec
+    from audiocodecs_amd._native import debug_set
 
     if codec_name == "dac":
         cfg, sd = dac_checkpoints("full", 0)
@@ -222,9 +224,9 @@ def test_direct_epilogue_equals_the_staged_one(codec_name, dac_checkpoints, chec
         sig = noise(6160 + T, B, T).cuda()
         toks = codec.sig_to_toks(sig)
         rec = codec.toks_to_sig(toks)
-        monkeypatch.setenv("AC_TAP_EPI", "staged")
+        debug_set(codec, "tap_epi_staged", 1)
         toks0 = codec.sig_to_toks(sig)
         rec0 = codec.toks_to_sig(toks)
-        monkeypatch.delenv("AC_TAP_EPI")
+        debug_set(codec, "tap_epi_staged", 0)
         assert torch.equal(toks, toks0), (codec_name, B, T)
         assert torch.equal(rec, rec0), (codec_name, B, T)

@@ -213,7 +213,7 @@ def test_rest_of_codec_api(codecs, checkpoints):
 
 def test_error_behaviour(codecs, checkpoints):
     from audiocodecs_amd import Encodec
-    from audiocodecs_amd._native import NativeError
+    from audiocodecs_amd._native import NativeError, debug_set
 
     cfg, sd = checkpoints("tiny", 0)
     with pytest.raises(ValueError):
@@ -254,7 +254,7 @@ def test_persistent_and_per_step_lstm_agree(checkpoints, monkeypatch):
 
 
 def test_split_operand_and_exact_product_kernels_agree(checkpoints, golden, monkeypatch):
-    """Default: GEMMs / LSTM products in split-operand arithmetic on the bf16 pipe (tap_gemm6.h, lstm_persist6.h).
+    """Default: GEMMs / LSTM products in split16 arithmetic on the fp16 pipe (tap_gemm6.h, lstm_persist16.h).
     AC_GEMM=fp32: exact fp32 products (tap_gemm4.h, lstm_persist.h).  Same function up to fp32-level rounding, and the
     exact-product build also reproduces the reference's tokens."""
     from audiocodecs_amd import Encodec
@@ -363,7 +363,7 @@ def test_nan_clip_does_not_stall_or_poison_other_clips(codecs):
 def test_out_of_range_token_ids_are_reported(codecs):
     """F.embedding raises on an id outside the codebook.  No entry point synchronises, so the decode kernel sets the
     frame to NaN and the NEXT call on the handle fails with AC_EINVAL (once); afterwards the handle works again."""
-    from audiocodecs_amd._native import NativeError
+    from audiocodecs_amd._native import NativeError, debug_set
 
     codec = codecs("full", 0)
     toks = torch.randint(0, 1024, (2, 6, 8), device="cuda")
@@ -382,7 +382,7 @@ def test_mode_drops_the_unused_half(checkpoints):
     """encodec.py:67-71: mode="encode" deletes the decoder, mode="decode" the encoder.  Here the unused half is never
     packed or uploaded; calling it reports the missing half instead of running on absent weights."""
     from audiocodecs_amd import Encodec
-    from audiocodecs_amd._native import NativeError
+    from audiocodecs_amd._native import NativeError, debug_set
 
     cfg, sd = checkpoints("full", 0)
     both = Encodec(24000, num_codebooks=8, state_dict=sd, config=cfg).eval()
@@ -404,17 +404,18 @@ def test_failed_persistent_launch_is_reported_and_healed(checkpoints, monkeypatc
     a sticky word; the NEXT call on the handle returns AC_EHIP once and the handle switches to the per-step kernels, after
     which it produces the same tokens as a healthy handle."""
     from audiocodecs_amd import Encodec
-    from audiocodecs_amd._native import NativeError
+    from audiocodecs_amd._native import NativeError, debug_set
 
     cfg, sd = checkpoints("full", 0)
     good = Encodec(24000, num_codebooks=8, state_dict=sd, config=cfg).eval()
     codec = Encodec(24000, num_codebooks=8, state_dict=sd, config=cfg).eval()
     sig = noise(8282, 3, 16000).cuda()
     want = good.sig_to_toks(sig)
-    monkeypatch.setenv("AC_LSTM_DBG", "16")
+    codec._native_for(sig)
+    debug_set(codec, "lstm_dbg", 16)         # fault injection: the next persistent launch reports a broken placement
     feats = codec.sig_to_feats(sig)          # the call itself cannot know: nothing synchronises
     torch.cuda.synchronize()
-    monkeypatch.delenv("AC_LSTM_DBG")
+    debug_set(codec, "lstm_dbg", 0)
     assert bool(torch.isnan(feats).all())    # ... but its outputs are NaN, not garbage
     nat = next(iter(codec._natives.values()))
     assert nat.lib.ac_lstm_status(nat.h) < 0
@@ -430,17 +431,18 @@ def test_strict_mode_raises_in_the_call_that_failed(checkpoints, monkeypatch):
     (ac_poll_status: synchronises the stream, reports and clears the sticky words), so the call whose persistent LSTM launch
     failed raises -- not an unrelated later one -- and the next call runs on the healed handle without an exception."""
     from audiocodecs_amd import Encodec
-    from audiocodecs_amd._native import NativeError
+    from audiocodecs_amd._native import NativeError, debug_set
 
     cfg, sd = checkpoints("full", 0)
     good = Encodec(24000, num_codebooks=8, state_dict=sd, config=cfg).eval()
     codec = Encodec(24000, num_codebooks=8, state_dict=sd, config=cfg, strict=True).eval()
     sig = noise(8283, 2, 16000).cuda()
     want = good.sig_to_toks(sig)
-    monkeypatch.setenv("AC_LSTM_DBG", "16")
+    codec._native_for(sig)
+    debug_set(codec, "lstm_dbg", 16)
     with pytest.raises(NativeError, match="persistent LSTM launch failed"):
         codec.sig_to_feats(sig)
-    monkeypatch.delenv("AC_LSTM_DBG")
+    debug_set(codec, "lstm_dbg", 0)
     toks = codec.sig_to_toks(sig)            # no leftover error: the poll cleared it; per-step kernels from now on
     assert float((toks == want).float().mean()) > 0.999
     bad = toks.clone()
@@ -449,3 +451,30 @@ def test_strict_mode_raises_in_the_call_that_failed(checkpoints, monkeypatch):
         codec.toks_to_sig(bad)
     rec = codec.toks_to_sig(toks)            # unaffected
     assert bool(torch.isfinite(rec).all())
+
+
+def test_one_poll_reports_and_clears_every_pending_failure(checkpoints):
+    """Round-3 advisor finding: ac_poll_status reported one sticky class per call, so a bad-token count pending beside an LSTM
+    failure surfaced in a later, unrelated call.  Both are raised in ONE message now and nothing is left behind."""
+    from audiocodecs_amd import Encodec
+    from audiocodecs_amd._native import NativeError, check, debug_set
+
+    cfg, sd = checkpoints("full", 0)
+    codec = Encodec(24000, num_codebooks=8, state_dict=sd, config=cfg).eval()
+    sig = noise(8284, 4, 120000).cuda()
+    toks = codec.sig_to_toks(sig)
+    bad = toks.clone()
+    bad[1, 7, 3] = 4096
+    torch.cuda.synchronize()
+    debug_set(codec, "lstm_dbg", 16)
+    codec.toks_to_sig(bad)                   # enqueued: the bad-token word is raised when the gather kernel runs ...
+    codec.sig_to_feats(sig)                  # ... after this call's entry check (milliseconds of decode are queued ahead); its LSTM launch fails
+    debug_set(codec, "lstm_dbg", 0)
+    nat = next(iter(codec._natives.values()))
+    stream = torch.cuda.current_stream().cuda_stream
+    with pytest.raises(NativeError) as ei:
+        check(nat.lib.ac_poll_status(nat.h, stream), nat.h, "ac_poll_status")
+    msg = str(ei.value)
+    assert "persistent LSTM launch failed" in msg and "token ids outside" in msg, msg
+    check(nat.lib.ac_poll_status(nat.h, stream), nat.h, "ac_poll_status")      # nothing left behind
+    assert bool(codec.toks_to_sig(codec.sig_to_toks(sig)).isfinite().all())      # healed handle, per-step LSTM kernels

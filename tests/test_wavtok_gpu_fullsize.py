@@ -29,6 +29,11 @@ def test_full_batch_properties(wavtok_checkpoints):
     assert rec.shape == (B, T) and bool(torch.isfinite(rec).all())
     assert torch.equal(codec.toks_to_sig(toks[5:6]), rec[5:6])
     assert torch.equal(rec, codec.toks_to_sig(toks))
+    # FLOAT outputs repeat bit for bit (round-3 advisor: the packed-FMA fault of the EnCodec front was visible only in such a test)
+    feats = codec.sig_to_feats(sig)
+    for _ in range(3):
+        assert torch.equal(codec.sig_to_feats(sig), feats)
+        assert torch.equal(codec.toks_to_sig(toks), rec)
     nat = next(iter(codec._natives.values()))
     assert nat.lib.ac_lstm_status(nat.h) == 1                               # the persistent LSTM ran, no failed launch
     W, W64 = O.cast_weights(sd), O.cast_weights(sd, torch.float64)
