@@ -467,8 +467,7 @@ def test_one_poll_reports_and_clears_every_pending_failure(checkpoints):
     bad[1, 7, 3] = 4096
     torch.cuda.synchronize()
     debug_set(codec, "lstm_dbg", 16)
-    codec.toks_to_sig(bad)                   # enqueued: the bad-token word is raised when the gather kernel runs ...
-    codec.sig_to_feats(sig)                  # ... after this call's entry check (milliseconds of decode are queued ahead); its LSTM launch fails
+    codec.toks_to_sig(bad)                   # ONE call raises two classes: out-of-range ids in the gather AND its persistent LSTM launch fails
     debug_set(codec, "lstm_dbg", 0)
     nat = next(iter(codec._natives.values()))
     stream = torch.cuda.current_stream().cuda_stream
