@@ -69,6 +69,8 @@ static void latch_dev_switches(ac_handle* h) {
     h->dev.tap_dil = num("AC_TAP_DIL", 1);
     h->dev.tap_stagger = num("AC_TAP_STAGGER", 0);
     h->dev.tap_pick = num("AC_TAP_PICK", -1);
+    h->dev.tap8 = num("AC_TAP8", -1);
+    h->dev.tap8_form = num("AC_TAP8_FORM", 0);
     h->dev.rb6_dbg = num("AC_RB6_DBG", 0);
     h->dev.front_seg = std::max(0, num("AC_FRONT_SEG", 0));
     h->dev.tail_seg = std::max(0, num("AC_TAIL_SEG", 0));
@@ -83,7 +85,7 @@ static void latch_dev_switches(ac_handle* h) {
 int ac_debug_set(ac_handle* h, const char* key, int value) {
     if (!h || !key) return AC_EINVAL;
     struct { const char* k; int* v; } tab[] = {
-        {"tap_epi_staged", &h->dev.tap_epi_staged}, {"tap_dil", &h->dev.tap_dil}, {"tap_stagger", &h->dev.tap_stagger}, {"tap_pick", &h->dev.tap_pick},
+        {"tap_epi_staged", &h->dev.tap_epi_staged}, {"tap_dil", &h->dev.tap_dil}, {"tap_stagger", &h->dev.tap_stagger}, {"tap_pick", &h->dev.tap_pick}, {"tap8", &h->dev.tap8}, {"tap8_form", &h->dev.tap8_form},
         {"rb6_dbg", &h->dev.rb6_dbg}, {"front_seg", &h->dev.front_seg}, {"tail_seg", &h->dev.tail_seg}, {"front_ldspad", &h->dev.front_ldspad},
         {"lstm_dbg", &h->dev.lstm_dbg}, {"lstm_fuse_in", &h->dev.lstm_fuse_in}, {"rvq_exact", &h->dev.rvq_exact}, {"prof_detail", &h->dev.prof_detail},
     };

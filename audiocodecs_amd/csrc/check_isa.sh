@@ -4,6 +4,10 @@
 #     values in lanes 48..63 when a second wave shared the SIMD (profiles/r3_pk_fma_hazard.md; mechanism not established).  The stem's
 #     FMAs are pinned in source (fma_pinned, split16.h) and the library is built with -fno-slp-vectorize; this check is what notices
 #     when a compiler upgrade or an extra flag brings them back.
+#  1b. in NO kernel a packed fp32 instruction (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32) with an `op_sel:[..1..]` operand, i.e. one that
+#     feeds the HIGH half of a source pair to the low result lane: that is the form that faults (tools/ubench/pk_fma_lds.hip,
+#     profiles/r4_pk_fma_repro.md: wrong values in lanes 48..63 whenever MFMAs run on the SIMD and a second wave shares it; the
+#     low-half broadcasts `op_sel_hi:[..0..]` the library's scale multiplies compile to never fault).
 #  2. no scratch in dec_tail_kernel / enc_front_kernel: a kernel that uses scratch cannot be replayed from a hipGraph once the runtime
 #     has resized its scratch buffer.
 set -euo pipefail
@@ -24,6 +28,12 @@ for co in "$tmp"/lib.so.*gfx950; do
         if grep -q "<.*$k.*>:" "$tmp/dis.s"; then found=$((found+1)); fi
         if [ "$n" != "0" ]; then echo "check_isa: $n v_pk_fma_f32 in $k (profiles/r3_pk_fma_hazard.md)"; bad=1; fi
     done
+    n=$(grep -E "v_pk_(fma|mul|add)_f32" "$tmp/dis.s" | grep -c "op_sel:\[" || true)
+    if [ "$n" != "0" ]; then
+        echo "check_isa: $n packed fp32 instructions select the HIGH half of a source (op_sel) -- profiles/r4_pk_fma_repro.md:"
+        awk '/^[0-9a-f]+ <.*>:/{name=$2} /v_pk_(fma|mul|add)_f32/ && /op_sel:\[/{c[name]++} END{for (k in c) print "   ", c[k], k}' "$tmp/dis.s"
+        bad=1
+    fi
     # .private_segment_fixed_size of the two fused chains from the code object's metadata notes
     "$readelf" --notes "$co" > "$tmp/notes.txt" 2>/dev/null || true
     for k in enc_front_kernel dec_tail_kernel; do
@@ -32,5 +42,5 @@ for co in "$tmp"/lib.so.*gfx950; do
     done
 done
 if [ "$found" -lt 2 ]; then echo "check_isa: enc_front_kernel / dec_tail_kernel not found in $so"; exit 1; fi
-[ "$bad" = "0" ] && echo "check_isa: ok (no packed fp32 FMAs, no scratch in the fused chains)"
+[ "$bad" = "0" ] && echo "check_isa: ok (no packed fp32 FMAs / scratch in the fused chains, no high-half-selecting packed fp32 instruction anywhere)"
 exit $bad

@@ -8,6 +8,7 @@
 #include "rvq16.h"
 #include "tap_gemm4.h"
 #include "tap_gemm6.h"
+#include "tap_gemm8.h"
 #include "thin.h"
 #include "rb_fused.h"
 #include "rb_fused6.h"
@@ -335,6 +336,56 @@ int run_tap(ac_handle* h, hipStream_t st, TapGemmParams& p) {
             hipLaunchKernelGGL((tap_gemm6_kernel<WGM, WGN, WMT, WN, 2, T6_DIL_HALO>), dim3((unsigned)blocks), dim3(Cfg6D::NT), Cfg6D::lds_for(2), st, p, w6); \
         } else TAP6_LAUNCH(WGM, WGN, WMT, WN, 2);                                                                       \
     } while (0)
+        // tap_gemm8.h: the 256-row, 8-wave kernel with the weight stage through an LDS-DMA ring and activation chunks requested two
+        // chunks ahead -- one segment, taps inside one slab, N % 128 == 0 (the same arithmetic in the same order: bit-identical outputs)
+        {
+            const TapSeg& s0 = p.seg[0];
+            const bool can8 = p.winv && p.nseg == 1 && (s0.J - 1) * s0.dil <= 7 && !(s0.dil != 1 && s0.s != 1) && p.N % 128 == 0 && (s0.s * s0.cin) % 32 == 0 &&
+                              (!p.epi_direct || p.N % 128 == 0);
+            const int want8 = h->dev.tap8;       // 0: never, 1: wherever the shape allows (developer A/B), -1: cost model
+            bool use8 = false;
+            if (can8 && want8 != 0) {
+                // tile forms (8 waves each): 1 = 256 x 256 (2 x 4 waves of 128 x 64), 3 = 128 x 256 (2 x 4 waves of 64 x 64) where 256-row
+                // tiles would leave CUs idle or rows empty (M = 750: three tiles per clip; M = 125), 2 = 256 x 128 (4 x 2 waves of 64 x 64) for
+                // N % 256 != 0.  Score = rate relative to form 1 (EnCodec / Mimi / DAC layers, profiles/r4_tapgemm8.md) x how evenly the
+                // workgroups fill the 256 CUs x the share of tile rows that exist.
+                auto fill8 = [&](int bm, int bn) {
+                    const double w = (double)p.B * cdiv(p.M, bm) * (p.N / bn) / 256.0;
+                    return w / std::ceil(w) * ((double)p.M / ((double)cdiv(p.M, bm) * bm));
+                };
+                const double sc1 = p.N % 256 == 0 ? 1.00 * fill8(256, 256) : 0.0;
+                const double sc3 = p.N % 256 == 0 ? 0.90 * fill8(128, 256) : 0.0;
+                const double sc2 = (kk >= 3072 ? 0.95 : 0.70) * fill8(256, 128);      // (loses to tap_gemm6's three workgroups per CU except on long contractions)
+                int form = sc1 >= sc2 && sc1 >= sc3 ? 1 : (sc3 >= sc2 ? 3 : 2);
+                if (h->dev.tap8_form >= 1 && h->dev.tap8_form <= 3 && (h->dev.tap8_form == 2 || p.N % 256 == 0)) form = h->dev.tap8_form;
+                const double best = form == 1 ? sc1 : form == 2 ? sc2 : sc3;
+                use8 = want8 >= 1 || best >= 0.80;
+                if (use8) {
+#define TAP8_LAUNCH_K(WGM, WGN, WMT, WN, RM, J1)                                                                         \
+    do {                                                                                                                \
+        if ((rc = ensure_lds(h, reinterpret_cast<const void*>(tap_gemm8_kernel<WGM, WGN, WMT, WN, RM, J1>), Cfg8::lds_bytes))) return rc; \
+        hipLaunchKernelGGL((tap_gemm8_kernel<WGM, WGN, WMT, WN, RM, J1>), dim3((unsigned)blocks), dim3(Cfg8::NT), Cfg8::lds_bytes, st, p, w6); \
+    } while (0)
+#define TAP8_LAUNCH(WGM, WGN, WMT, WN)                                                                                   \
+    do {                                                                                                                \
+        using Cfg8 = Tap8Cfg<WGM, WGN, WMT, WN>;                                                                        \
+        p.mtiles = cdiv(p.M, Cfg8::BM);                                                                                 \
+        p.ntiles = p.N / Cfg8::BN;                                                                                      \
+        const long long blocks = (long long)p.B * p.mtiles * p.ntiles;                                                  \
+        ProfScope ps(h, st, (std::string("tap_gemm8_kernel<" #WGM ", " #WGN ", " #WMT ", " #WN ", 2>") + shape).c_str(), flops, bytes); \
+        if (s0.J == 1) { if (p.amax_rows) TAP8_LAUNCH_K(WGM, WGN, WMT, WN, true, true); else TAP8_LAUNCH_K(WGM, WGN, WMT, WN, false, true); } \
+        else           { if (p.amax_rows) TAP8_LAUNCH_K(WGM, WGN, WMT, WN, true, false); else TAP8_LAUNCH_K(WGM, WGN, WMT, WN, false, false); } \
+    } while (0)
+                    if (form == 1) TAP8_LAUNCH(2, 4, 4, 2);
+                    else if (form == 3) TAP8_LAUNCH(2, 4, 2, 2);
+                    else TAP8_LAUNCH(4, 2, 2, 2);
+#undef TAP8_LAUNCH_K
+#undef TAP8_LAUNCH
+                    HIPCHK(h, hipGetLastError());
+                    return AC_OK;
+                }
+            }
+        }
         // Tile / wave arrangement (measured, profiles/r2_tapgemm_variants.md).  The weight fragments come L2 -> registers and the
         // activation slab is shared through LDS, so the CU's vector-memory path and the LDS pipe are what an arrangement must
         // spare:  1 x 4 waves of 128 x 32 (distinct weight fragments per wave) beats 2 x 2 waves of 64 x 64 by 5-7 %;
@@ -353,9 +404,12 @@ int run_tap(ac_handle* h, hipStream_t st, TapGemmParams& p) {
             //  4.71 ms at 128 columns, 5.43 ms with 1 x 8 waves)
             const double s8 = (kk >= 2048 ? (p.winv ? 1.00 : 1.12) : (p.winv ? 0.85 : 0.95)) * fill(wg256, 256.0);
             pick = s256 >= s128 && s256 >= s8 ? 1 : (s8 > s128 ? 2 : 0);
-            if (h->dev.tap_pick >= 0 && h->dev.tap_pick <= 2) pick = h->dev.tap_pick;     // developer override
+            if (h->dev.tap_pick >= 0 && h->dev.tap_pick <= 3) pick = h->dev.tap_pick;     // developer override
         }
-        if (pick == 1) TAP6_CASE(1, 4, 4, 2);
+        if (h->dev.tap_pick == 4 && p.N % 128 == 0) pick = 4;
+        if (pick == 3) TAP6_CASE(2, 4, 4, 2);          // experiment: 256 x 256, 8 waves of 128 x 64, one workgroup per CU
+        else if (pick == 4) TAP6_CASE(2, 4, 4, 1);     // experiment: 256 x 128, 8 waves of 128 x 32
+        else if (pick == 1) TAP6_CASE(1, 4, 4, 2);
         else if (pick == 2) TAP6_CASE(1, 8, 4, 1);
         else if (p.N % 128 == 0) TAP6_CASE(1, 4, 4, 1);
         else if (p.N % 192 == 0) TAP6_CASE(2, 2, 2, 3);   // DAC's 192-wide layers: a weight fragment is loaded by two waves, not four

@@ -65,329 +65,22 @@ constexpr int tap6_occupancy() {
 
 // NP = 2: split16.h -- two fp16 planes per operand, 3 partial products, per-clip / per-output-channel power-of-two scales.
 // Weight image [n-tile of 32][k-step of 16][plane 2][lane 64][8 fp16] of the SCALED rows; needs seg[].amax and winv.
-template <int WGM, int WGN, int WMT, int WN, int NP = 2, int HALO = 7>
-__global__ __launch_bounds__(64 * WGM * WGN, (tap6_occupancy<WGM, WGN, WMT, WN, NP>())) void tap_gemm6_kernel(const TapGemmParams p, const __bf16* __restrict__ wp) {
-    static_assert(NP == 2, "split16 arithmetic only");
+#ifdef T6_TRACE   // developer build: phase stamps of wave 1 of one workgroup (p.clk[4..15])
+#define T6_PHASE(k) do { if (t6_ph) p.clk[4 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#endif
+// ---- the epilogue of a tile (shared by tap_gemm6_kernel and tap_gemm8_kernel): accumulators -> bias, 2^-s, activation flavours,
+// residual / LayerScale / GELU / tanh terms, amax words -> HBM.  `smem` is the workgroup's whole dynamic LDS (the staged form reuses it
+// as its staging tile after a workgroup barrier).
+template <int WGM, int WGN, int WMT, int WN, int HALO>
+__device__ __forceinline__ void tap6_epilogue(const TapGemmParams& p, f32x16 (&acc)[WMT][WN], float* smem, const int b, const int m0, const int n0,
+                                              const float a_inv, const bool rowmode, const unsigned long long clk_t0, const unsigned long long clk_r0, const bool t6_ph) {
     using Cfg = Tap6Cfg<WGM, WGN, WMT, WN, HALO>;
-    constexpr int BM = Cfg::BM, BN = Cfg::BN, NT = Cfg::NT, A_SLOTS = Cfg::A_SLOTS, PLANE = Cfg::PLANE;
-    unsigned long long clk_t0 = 0, clk_r0 = 0;
-    if (p.clk) { clk_t0 = __builtin_amdgcn_s_memtime(); clk_r0 = __builtin_amdgcn_s_memrealtime(); }
-    if (p.stagger && (int)blockIdx.x < 256 * tap6_occupancy<WGM, WGN, WMT, WN, NP>()) {
-        const unsigned long long wait = (unsigned long long)((blockIdx.x * 0x9E3779B1u) >> 24) * (unsigned)p.stagger >> 8;
-        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-        while (__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(32);
-    }
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    __bf16* As0 = reinterpret_cast<__bf16*>(smem);            // [2 buffers][NPL planes][A_ROWS][T6_PITCH]
-    constexpr int NPL = 2;
-
+    constexpr int NP = 2, BM = Cfg::BM, BN = Cfg::BN, NT = Cfg::NT;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WGN, wn = wave % WGN;
-    const int i32 = lane & 31, kh = lane >> 5;                // MFMA operand: row / column i32, k = 8*kh .. 8*kh + 7
-
-    int id;
-    {   // XCD-aware tile order (tap_gemm4.h)
-        const int total = gridDim.x, q = total >> 3, r = total & 7, xcd = blockIdx.x & 7, pos = blockIdx.x >> 3;
-        id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;
-    }
-    const int nt = id % p.ntiles; id /= p.ntiles;
-    const int mt = id % p.mtiles;
-    const int b = id / p.mtiles;
-    const int m0 = mt * BM, n0 = nt * BN;
-#ifdef T6_TRACE   // developer build: phase stamps of wave 1 of one workgroup (p.clk[4..15]), stage stamps below
-    const bool t6_ph = p.clk && mt == p.mtiles / 2 && nt == 0 && b == p.B / 2 && tid == 64;      // an interior tile
-#define T6_PHASE(k) do { if (t6_ph) p.clk[4 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
-    if (t6_ph) p.clk[4] = clk_t0;
-    T6_PHASE(1);
-#endif
-
-    f32x16 acc[WMT][WN];
-#pragma unroll
-    for (int a = 0; a < WMT; ++a)
-#pragma unroll
-        for (int c = 0; c < WN; ++c)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
-
-    int a_lds[A_SLOTS], a_boff[A_SLOTS];
-#pragma unroll
-    for (int i = 0; i < A_SLOTS; ++i) {
-        const int e = tid + i * NT;
-        a_lds[i] = (e / (KC / 4)) < Cfg::A_ROWS ? (e / (KC / 4)) * T6_PITCH + 4 * (e % (KC / 4)) : -1;
-    }
-
-    // ---- segment state (wave-uniform); identical to tap_gemm4
-    int si = 0, c0 = 0, j = 0;
-    int seg_J, seg_Cw, seg_kofs;
-    int seg_tapoff = 0;
-    bool seg_reload = false;
-    int seg_rowstep = 1;                // slab rows between the taps of a segment (its dilation when the taps share one slab)
-    bool seg_interior;
-    unsigned a_zero = 0;
-    __amdgpu_buffer_rsrc_t a_rs;
-    auto enter_segment = [&](int s_) {
-        const TapSeg& sg = p.seg[s_];
-        seg_J = sg.J;
-        seg_Cw = sg.s * sg.cin;
-        seg_kofs = sg.kofs;
-        seg_reload = sg.dil != 1 && (sg.s != 1 || (sg.J - 1) * sg.dil > HALO);     // dilated taps that fit the slab read it like any others
-        seg_rowstep = seg_reload ? 1 : sg.dil;
-        const long long lo = (long long)m0 * sg.s - sg.pad;
-        const long long hi = (long long)(m0 + BM - 1 + (sg.J - 1) * sg.dil) * sg.s + (sg.s - 1) - sg.pad;
-        const bool inside = lo >= 0 && hi < sg.L;
-        seg_interior = inside || (sg.s == 1 && !seg_reload);
-        a_zero = 0;
-        const int tsf = sg.s == 1 ? (int)sg.ts : sg.cin;
-        seg_tapoff = sg.dil * sg.s * tsf * 4;
-        a_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(sg.x + (long long)b * sg.bs), 0,
-                                                 (int)(((long long)(sg.L - 1) * sg.ts + sg.cin) * 4), 0x00020000);
-        const int R = seg_reload ? BM : BM + (sg.J - 1) * sg.dil;
-#pragma unroll
-        for (int i = 0; i < A_SLOTS; ++i) {
-            const int e = tid + i * NT;
-            const int row = e / (KC / 4), q = e % (KC / 4);
-            long long t = (long long)(m0 + (row < R ? row : 0)) * sg.s - sg.pad;
-            if (!inside) {
-                if (sg.s == 1 && !seg_reload) {
-                    const long long jj = row < R ? src_index(sg, (int)t) : 0;
-                    if (jj < 0) a_zero |= 1u << i;
-                    t = jj < 0 ? 0 : jj;
-                } else {
-                    t = 0;
-                }
-            }
-            a_boff[i] = (int)((t * tsf + 4 * q) * 4);
-        }
-    };
-    // split16: one power-of-two scale for the clip's activation operand(s) (both segments share the accumulator)
-    // (row mode: one scale per ROW of the merged row matrix instead -- a_rsc[slot])
-    float a_scale = 1.f, a_inv = 1.f;
-    float a_rsc[A_SLOTS];
-    const bool rowmode = NP == 2 && p.amax_rows;
-    if (NP == 2) {
-        if (!rowmode) {
-            unsigned am = *amax_at(p.seg[0].amax, b);
-            if (p.nseg > 1) { const unsigned a1 = *amax_at(p.seg[1].amax, b); am = a1 > am ? a1 : am; }
-            const int se = s16_exponent(am);
-            a_scale = s16_pow2(se);
-            a_inv = s16_pow2(-se);
-        }
-#pragma unroll
-        for (int i = 0; i < A_SLOTS; ++i) {
-            a_rsc[i] = a_scale;
-            if (rowmode) {
-                const int m = m0 + (tid + i * NT) / (KC / 4);
-                a_rsc[i] = s16_pow2(s16_exponent(p.seg[0].amax[m < p.M ? m : p.M - 1]));
-            }
-        }
-    }
-    f32x4 ra[A_SLOTS];
-    // Exactly A_SLOTS buffer loads, whatever the stage needs (see `stage` below for why the COUNT must not depend on the path):
-    //   interior tile : the per-slot offsets of enter_segment + one scalar offset for the chunk / tap
-    //   clip-edge tile: per-slot offsets from the padding rule (src_index); rows the rule zero-fills aim past the last record
-    //   `live` false  : the stage stays on its chunk -- every slot aims past the last record
-    // (a buffer load past num_records returns zeros without touching memory; the range check sees the VGPR offset only)
-    constexpr int A_OOB = 0x7fff0000;
-    auto load_a = [&](int s_, int c_, int j_, bool live) {
-        int voff[A_SLOTS], soff = 0;
-        if (seg_interior || !live) {
-            soff = live ? c_ * 4 + (seg_reload ? j_ * seg_tapoff : 0) : 0;
-#pragma unroll
-            for (int i = 0; i < A_SLOTS; ++i) voff[i] = live ? a_boff[i] : A_OOB;
-        } else {
-            const TapSeg& sg = p.seg[s_];
-            const int R = seg_reload ? BM : BM + (sg.J - 1) * sg.dil;
-            const int jr = seg_reload ? j_ * sg.dil : 0;
-#pragma unroll
-            for (int i = 0; i < A_SLOTS; ++i) {
-                const int e = tid + i * NT;
-                const int row = e / (KC / 4), q = e % (KC / 4);
-                const int c = c_ + 4 * q;
-                const int tp = sg.cin_shift >= 0 ? (c >> sg.cin_shift) : (c / sg.cin);
-                const long long jj = row < R ? src_index(sg, (m0 + row + jr) * sg.s + tp - sg.pad) : -1;
-                voff[i] = jj < 0 ? A_OOB : (int)((jj * sg.ts + (c - tp * sg.cin)) * 4);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < A_SLOTS; ++i) ra[i] = bufload16(a_rs, voff[i], soff);
-    };
-    // split 4 fp32 into the two fp16 planes (split16.h: scaled value = hi + lo) and store them
-    auto store_a = [&](__bf16* dst) {
-#pragma unroll
-        for (int i = 0; i < A_SLOTS; ++i)
-            if (a_lds[i] >= 0) {
-                const f32x4 v = (a_zero & (1u << i)) ? f32x4{0.f, 0.f, 0.f, 0.f} : ra[i];
-                split16_store4s(v, a_rsc[i], dst, PLANE, a_lds[i]);
-            }
-    };
-    // B fragments of this wave's WN column tiles for ONE k-step: [plane][c]; k-step index inside the packed rows
-    const int ksteps = p.Ktot >> 4;
-    constexpr int WPL = 2;    // planes in the weight image
-    const __bf16* wbase = wp + ((long long)((n0 + wn * 32 * WN) >> 5) * ksteps) * (WPL * 64 * 8) + lane * 8;
-    auto load_b = [&](int s_, bf16x8 (&bf)[3][WN]) {
-#pragma unroll
-        for (int c = 0; c < WN; ++c)
-#pragma unroll
-            for (int pl = 0; pl < NP; ++pl)
-                bf[pl][c] = *reinterpret_cast<const bf16x8*>(wbase + (((long long)c * ksteps + s_) * WPL + pl) * (64 * 8));
-    };
-
-    // ---- prologue
-#ifdef T6_TRACE
-    T6_PHASE(2);
-#endif
-    enter_segment(0);
-#ifdef T6_TRACE
-    T6_PHASE(3);
-#endif
-    load_a(0, 0, 0, true);
-    // three rotating B register sets: a stage uses (U0, U1) for its two k-steps and loads the NEXT stage's k-steps
-    // into (S, U0) -- each load is issued two k-steps before its use (one k-step is shorter than an L2 round trip)
-    bf16x8 bx[3][WN], by[3][WN], bz[3][WN];
-    load_b(seg_kofs >> 4, bx);
-    load_b((seg_kofs >> 4) + 1, by);
-#ifdef T6_TRACE
-    T6_PHASE(4);
-#endif
-    store_a(As0);
-#ifdef T6_TRACE
-    T6_PHASE(5);
-#endif
-    __syncthreads();
-    int abuf = 0;
-    const int a_frag = (wm * WMT * 32 + i32) * T6_PITCH + 8 * kh;    // + (a*32 + j)*T6_PITCH + ks*16, + plane*PLANE
-    auto read_a = [&](const __bf16* Ac, int ks, bf16x8 (&af)[3][WMT]) {
-#pragma unroll
-        for (int pl = 0; pl < NP; ++pl)
-#pragma unroll
-            for (int a = 0; a < WMT; ++a) af[pl][a] = *reinterpret_cast<const bf16x8*>(Ac + pl * PLANE + a * 32 * T6_PITCH + ks * 16);
-    };
-    auto mfma_step = [&](const bf16x8 (&af)[3][WMT], const bf16x8 (&bf)[3][WN]) {
-#pragma unroll
-        for (int a = 0; a < WMT; ++a)
-#pragma unroll
-            for (int c = 0; c < WN; ++c) {
-                f32x16 v = acc[a][c];
-                // lo hi, hi lo, hi hi (small terms first)
-                v = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[1][a]), __builtin_bit_cast(f16x8, bf[0][c]), v, 0, 0, 0);
-                v = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[0][a]), __builtin_bit_cast(f16x8, bf[1][c]), v, 0, 0, 0);
-                acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[0][a]), __builtin_bit_cast(f16x8, bf[0][c]), v, 0, 0, 0);
-            }
-    };
-#ifdef T6_TRACE
-    int t6_stage = 0;
-    const bool t6_on = p.clk && mt == p.mtiles / 2 && nt == 0 && b == p.B / 2 && lane == 0 && t6_stage < 16;
-#define T6_STAMP(k) do { if (t6_on && t6_stage < 16) p.clk[16 + (wave * 16 + t6_stage) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
-#endif
-    // LEAN (wave tile of 6-8 accumulator tiles: 128 x 64, 64 x 96): 96-128 accumulator registers leave room for ONE fragment set and TWO
-    // weight sets only -- a weight set is reloaded right after the k-step that used it (one k-step ahead of its next use), the
-    // A fragments of a k-step are read just before its MFMAs (the co-resident workgroup covers the LDS latency).
-    constexpr bool LEAN = WMT * WN >= 6 || (WGM == 1 && tap6_occupancy<WGM, WGN, WMT, WN, NP>() == 3);
-    // one stage; returns true when it was the last one.
-    // EVERY stage issues the same loads in the same order -- A_SLOTS activation loads, then a weight set after each k-step --
-    // whether or not it needs them: a stage that stays on its A chunk points the activation loads past the end of the buffer
-    // resource (they return zeros without touching memory, into registers nobody reads), the last stage reloads k-step 0.
-    // The reason is s_waitcnt: vmcnt counts loads in issue order, so "wait for this k-step's weights but not for the younger
-    // loads" can only be encoded when the number of younger loads is the same on every path into the wait.  With `if
-    // (new_chunk)` / `if (has_next)` around the loads the compiler has to assume the fewest, and round 2's kernel waited for the
-    // weight set it had JUST requested before every second k-step (vmcnt(0): one exposed L2 round trip per stage) and for the
-    // first activation load before the first MFMA of every new-chunk stage (profiles/r3_tapgemm_trace.md: s_memtime stamps + ISA).
-    auto stage = [&](bf16x8 (&u0)[3][WN], bf16x8 (&u1)[3][WN], bf16x8 (&sp)[3][WN]) -> bool {
-#ifdef T6_TRACE
-        T6_STAMP(6);
-#endif
-        int nsi = si, nc0 = c0, nj = j + 1;
-        bool new_chunk = false;
-        if (nj == seg_J) {
-            nj = 0;
-            nc0 = c0 + KC;
-            new_chunk = true;
-            if (nc0 >= seg_Cw) { nc0 = 0; nsi = si + 1; }
-        }
-        const bool has_next = nsi < p.nseg;
-        const int cur_j = seg_reload ? 0 : j * seg_rowstep;
-        int s_next = 0;
-        if (has_next) {
-            if (nsi != si) enter_segment(nsi);
-            new_chunk = new_chunk || seg_reload;
-            s_next = (seg_kofs + nj * seg_Cw + nc0) >> 4;      // first k-step of the next stage in the packed weight rows
-        } else {
-            new_chunk = false;
-        }
-        // (sched_barrier: with every load unconditional a stage is one basic block, and the scheduler would sink the loads to
-        //  their first use -- the fences keep them where the latency plan needs them)
-        load_a(nsi, nc0, nj, new_chunk);
-        if (!LEAN) load_b(s_next, sp);
-        __builtin_amdgcn_sched_barrier(0);
-        const __bf16* Ac = As0 + abuf * NPL * PLANE + a_frag + cur_j * T6_PITCH;
-#ifdef T6_TRACE   // developer build: s_memtime stamps of one workgroup's stages (tools/experiments/r3o_trace.py)
-        if (t6_on && t6_stage < 16) p.clk[16 + (wave * 16 + t6_stage) * 8 + 7] = (seg_interior ? 1 : 0) | (new_chunk ? 2 : 0) | (mt << 8);
-        T6_STAMP(0);
-#endif
-        if constexpr (LEAN) {
-            bf16x8 af[3][WMT];
-            read_a(Ac, 0, af);
-            mfma_step(af, u0);
-#ifdef T6_TRACE
-            T6_STAMP(1);
-#endif
-            __builtin_amdgcn_sched_barrier(0);
-            load_b(s_next, u0);
-            __builtin_amdgcn_sched_barrier(0);
-            read_a(Ac, 1, af);
-            mfma_step(af, u1);
-#ifdef T6_TRACE
-            T6_STAMP(2);
-#endif
-            __builtin_amdgcn_sched_barrier(0);
-            load_b(s_next + 1, u1);
-            __builtin_amdgcn_sched_barrier(0);
-        } else {
-            bf16x8 af0[3][WMT], af1[3][WMT];
-            read_a(Ac, 0, af0);
-            read_a(Ac, 1, af1);                                // the second k-step's fragments travel under the first one's MFMAs
-            mfma_step(af0, u0);
-            __builtin_amdgcn_sched_barrier(0);
-            load_b(s_next + 1, u0);
-            __builtin_amdgcn_sched_barrier(0);
-            mfma_step(af1, u1);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (!has_next) return true;
-#ifdef T6_TRACE
-        T6_STAMP(3);
-#endif
-        // One barrier per CHUNK, not per stage: a slab is written only here, after the barrier that ended the chunk which last
-        // read it, and read only after the barrier that follows these writes -- the taps of one chunk need no barrier between them.
-        if (new_chunk) {                                       // the A loads had the whole stage to arrive
-            abuf ^= 1;
-            store_a(As0 + abuf * NPL * PLANE);
-        }
-#ifdef T6_TRACE
-        T6_STAMP(4);
-#endif
-        if (new_chunk) __syncthreads();
-#ifdef T6_TRACE
-        T6_STAMP(5);
-        ++t6_stage;
-#endif
-        si = nsi; c0 = nc0; j = nj;
-        return false;
-    };
-#ifdef T6_TRACE
-    T6_PHASE(6);
-#endif
-    if constexpr (LEAN) {
-        while (!stage(bx, by, bz)) {}
-    } else {
-        for (;;) {
-            if (stage(bx, by, bz)) break;
-            if (stage(bz, bx, by)) break;
-            if (stage(by, bz, bx)) break;
-        }
-    }
-
+    const int i32 = lane & 31, kh = lane >> 5;
+    (void)t6_ph; (void)BM; (void)BN;
 #ifdef T6_TRACE
     T6_PHASE(7);
 #endif
@@ -648,6 +341,340 @@ __global__ __launch_bounds__(64 * WGM * WGN, (tap6_occupancy<WGM, WGN, WMT, WN, 
         atomicAdd(&p.clk[0], (unsigned long long)(__builtin_amdgcn_s_memtime() - clk_t0));
         atomicAdd(&p.clk[1], (unsigned long long)(__builtin_amdgcn_s_memrealtime() - clk_r0));
     }
+}
+
+template <int WGM, int WGN, int WMT, int WN, int NP = 2, int HALO = 7>
+__global__ __launch_bounds__(64 * WGM * WGN, (tap6_occupancy<WGM, WGN, WMT, WN, NP>())) void tap_gemm6_kernel(const TapGemmParams p, const __bf16* __restrict__ wp) {
+    static_assert(NP == 2, "split16 arithmetic only");
+    using Cfg = Tap6Cfg<WGM, WGN, WMT, WN, HALO>;
+    constexpr int BM = Cfg::BM, BN = Cfg::BN, NT = Cfg::NT, A_SLOTS = Cfg::A_SLOTS, PLANE = Cfg::PLANE;
+    unsigned long long clk_t0 = 0, clk_r0 = 0;
+    if (p.clk) { clk_t0 = __builtin_amdgcn_s_memtime(); clk_r0 = __builtin_amdgcn_s_memrealtime(); }
+    if (p.stagger && (int)blockIdx.x < 256 * tap6_occupancy<WGM, WGN, WMT, WN, NP>()) {
+        const unsigned long long wait = (unsigned long long)((blockIdx.x * 0x9E3779B1u) >> 24) * (unsigned)p.stagger >> 8;
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        while (__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(32);
+    }
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __bf16* As0 = reinterpret_cast<__bf16*>(smem);            // [2 buffers][NPL planes][A_ROWS][T6_PITCH]
+    constexpr int NPL = 2;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int i32 = lane & 31, kh = lane >> 5;                // MFMA operand: row / column i32, k = 8*kh .. 8*kh + 7
+
+    int id;
+    {   // XCD-aware tile order (tap_gemm4.h)
+        const int total = gridDim.x, q = total >> 3, r = total & 7, xcd = blockIdx.x & 7, pos = blockIdx.x >> 3;
+        id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;
+    }
+    const int nt = id % p.ntiles; id /= p.ntiles;
+    const int mt = id % p.mtiles;
+    const int b = id / p.mtiles;
+    const int m0 = mt * BM, n0 = nt * BN;
+#ifdef T6_TRACE   // developer build: phase stamps of wave 1 of one workgroup (p.clk[4..15]), stage stamps below
+    const bool t6_ph = p.clk && mt == p.mtiles / 2 && nt == 0 && b == p.B / 2 && tid == 64;      // an interior tile
+    if (t6_ph) p.clk[4] = clk_t0;
+    T6_PHASE(1);
+#endif
+
+    f32x16 acc[WMT][WN];
+#pragma unroll
+    for (int a = 0; a < WMT; ++a)
+#pragma unroll
+        for (int c = 0; c < WN; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
+
+    int a_lds[A_SLOTS], a_boff[A_SLOTS];
+#pragma unroll
+    for (int i = 0; i < A_SLOTS; ++i) {
+        const int e = tid + i * NT;
+        a_lds[i] = (e / (KC / 4)) < Cfg::A_ROWS ? (e / (KC / 4)) * T6_PITCH + 4 * (e % (KC / 4)) : -1;
+    }
+
+    // ---- segment state (wave-uniform); identical to tap_gemm4
+    int si = 0, c0 = 0, j = 0;
+    int seg_J, seg_Cw, seg_kofs;
+    int seg_tapoff = 0;
+    bool seg_reload = false;
+    int seg_rowstep = 1;                // slab rows between the taps of a segment (its dilation when the taps share one slab)
+    bool seg_interior;
+    unsigned a_zero = 0;
+    __amdgpu_buffer_rsrc_t a_rs;
+    auto enter_segment = [&](int s_) {
+        const TapSeg& sg = p.seg[s_];
+        seg_J = sg.J;
+        seg_Cw = sg.s * sg.cin;
+        seg_kofs = sg.kofs;
+        seg_reload = sg.dil != 1 && (sg.s != 1 || (sg.J - 1) * sg.dil > HALO);     // dilated taps that fit the slab read it like any others
+        seg_rowstep = seg_reload ? 1 : sg.dil;
+        const long long lo = (long long)m0 * sg.s - sg.pad;
+        const long long hi = (long long)(m0 + BM - 1 + (sg.J - 1) * sg.dil) * sg.s + (sg.s - 1) - sg.pad;
+        const bool inside = lo >= 0 && hi < sg.L;
+        seg_interior = inside || (sg.s == 1 && !seg_reload);
+        a_zero = 0;
+        const int tsf = sg.s == 1 ? (int)sg.ts : sg.cin;
+        seg_tapoff = sg.dil * sg.s * tsf * 4;
+        a_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(sg.x + (long long)b * sg.bs), 0,
+                                                 (int)(((long long)(sg.L - 1) * sg.ts + sg.cin) * 4), 0x00020000);
+        const int R = seg_reload ? BM : BM + (sg.J - 1) * sg.dil;
+#pragma unroll
+        for (int i = 0; i < A_SLOTS; ++i) {
+            const int e = tid + i * NT;
+            const int row = e / (KC / 4), q = e % (KC / 4);
+            long long t = (long long)(m0 + (row < R ? row : 0)) * sg.s - sg.pad;
+            if (!inside) {
+                if (sg.s == 1 && !seg_reload) {
+                    const long long jj = row < R ? src_index(sg, (int)t) : 0;
+                    if (jj < 0) a_zero |= 1u << i;
+                    t = jj < 0 ? 0 : jj;
+                } else {
+                    t = 0;
+                }
+            }
+            a_boff[i] = (int)((t * tsf + 4 * q) * 4);
+        }
+    };
+    // split16: one power-of-two scale for the clip's activation operand(s) (both segments share the accumulator)
+    // (row mode: one scale per ROW of the merged row matrix instead -- a_rsc[slot])
+    float a_scale = 1.f, a_inv = 1.f;
+    float a_rsc[A_SLOTS];
+    const bool rowmode = NP == 2 && p.amax_rows;
+    if (NP == 2) {
+        if (!rowmode) {
+            unsigned am = *amax_at(p.seg[0].amax, b);
+            if (p.nseg > 1) { const unsigned a1 = *amax_at(p.seg[1].amax, b); am = a1 > am ? a1 : am; }
+            const int se = s16_exponent(am);
+            a_scale = s16_pow2(se);
+            a_inv = s16_pow2(-se);
+        }
+#pragma unroll
+        for (int i = 0; i < A_SLOTS; ++i) {
+            a_rsc[i] = a_scale;
+            if (rowmode) {
+                const int m = m0 + (tid + i * NT) / (KC / 4);
+                a_rsc[i] = s16_pow2(s16_exponent(p.seg[0].amax[m < p.M ? m : p.M - 1]));
+            }
+        }
+    }
+    f32x4 ra[A_SLOTS];
+    // Exactly A_SLOTS buffer loads, whatever the stage needs (see `stage` below for why the COUNT must not depend on the path):
+    //   interior tile : the per-slot offsets of enter_segment + one scalar offset for the chunk / tap
+    //   clip-edge tile: per-slot offsets from the padding rule (src_index); rows the rule zero-fills aim past the last record
+    //   `live` false  : the stage stays on its chunk -- every slot aims past the last record
+    // (a buffer load past num_records returns zeros without touching memory; the range check sees the VGPR offset only)
+    constexpr int A_OOB = 0x7fff0000;
+    auto load_a = [&](int s_, int c_, int j_, bool live) {
+        int voff[A_SLOTS], soff = 0;
+        if (seg_interior || !live) {
+            // (readfirstlane: the chunk / tap offset IS wave-uniform, but the compiler could not prove it and wrapped every one of the
+            //  stage's activation loads in a waterfall loop -- v_readfirstlane, compare, saveexec, load, loop: ~8 instructions and a
+            //  serialisation point per load; round-4 ISA reading, cdna_hip_programming.md T20)
+            soff = __builtin_amdgcn_readfirstlane(live ? c_ * 4 + (seg_reload ? j_ * seg_tapoff : 0) : 0);
+#pragma unroll
+            for (int i = 0; i < A_SLOTS; ++i) voff[i] = live ? a_boff[i] : A_OOB;
+        } else {
+            const TapSeg& sg = p.seg[s_];
+            const int R = seg_reload ? BM : BM + (sg.J - 1) * sg.dil;
+            const int jr = seg_reload ? j_ * sg.dil : 0;
+#pragma unroll
+            for (int i = 0; i < A_SLOTS; ++i) {
+                const int e = tid + i * NT;
+                const int row = e / (KC / 4), q = e % (KC / 4);
+                const int c = c_ + 4 * q;
+                const int tp = sg.cin_shift >= 0 ? (c >> sg.cin_shift) : (c / sg.cin);
+                const long long jj = row < R ? src_index(sg, (m0 + row + jr) * sg.s + tp - sg.pad) : -1;
+                voff[i] = jj < 0 ? A_OOB : (int)((jj * sg.ts + (c - tp * sg.cin)) * 4);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < A_SLOTS; ++i) ra[i] = bufload16(a_rs, voff[i], soff);
+    };
+    // split 4 fp32 into the two fp16 planes (split16.h: scaled value = hi + lo) and store them
+    auto store_a = [&](__bf16* dst) {
+#pragma unroll
+        for (int i = 0; i < A_SLOTS; ++i)
+            if (a_lds[i] >= 0) {
+                const f32x4 v = (a_zero & (1u << i)) ? f32x4{0.f, 0.f, 0.f, 0.f} : ra[i];
+                split16_store4s(v, a_rsc[i], dst, PLANE, a_lds[i]);
+            }
+    };
+    // B fragments of this wave's WN column tiles for ONE k-step: [plane][c]; k-step index inside the packed rows
+    const int ksteps = p.Ktot >> 4;
+    constexpr int WPL = 2;    // planes in the weight image
+    const __bf16* wbase = wp + ((long long)((n0 + wn * 32 * WN) >> 5) * ksteps) * (WPL * 64 * 8) + lane * 8;
+    auto load_b = [&](int s_, bf16x8 (&bf)[3][WN]) {
+#pragma unroll
+        for (int c = 0; c < WN; ++c)
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl)
+                bf[pl][c] = *reinterpret_cast<const bf16x8*>(wbase + (((long long)c * ksteps + s_) * WPL + pl) * (64 * 8));
+    };
+
+    // ---- prologue
+#ifdef T6_TRACE
+    T6_PHASE(2);
+#endif
+    enter_segment(0);
+#ifdef T6_TRACE
+    T6_PHASE(3);
+#endif
+    load_a(0, 0, 0, true);
+    // three rotating B register sets: a stage uses (U0, U1) for its two k-steps and loads the NEXT stage's k-steps
+    // into (S, U0) -- each load is issued two k-steps before its use (one k-step is shorter than an L2 round trip)
+    bf16x8 bx[3][WN], by[3][WN], bz[3][WN];
+    load_b(seg_kofs >> 4, bx);
+    load_b((seg_kofs >> 4) + 1, by);
+#ifdef T6_TRACE
+    T6_PHASE(4);
+#endif
+    store_a(As0);
+#ifdef T6_TRACE
+    T6_PHASE(5);
+#endif
+    __syncthreads();
+    int abuf = 0;
+    const int a_frag = (wm * WMT * 32 + i32) * T6_PITCH + 8 * kh;    // + (a*32 + j)*T6_PITCH + ks*16, + plane*PLANE
+    auto read_a = [&](const __bf16* Ac, int ks, bf16x8 (&af)[3][WMT]) {
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+            for (int a = 0; a < WMT; ++a) af[pl][a] = *reinterpret_cast<const bf16x8*>(Ac + pl * PLANE + a * 32 * T6_PITCH + ks * 16);
+    };
+    auto mfma_step = [&](const bf16x8 (&af)[3][WMT], const bf16x8 (&bf)[3][WN]) {
+#pragma unroll
+        for (int a = 0; a < WMT; ++a)
+#pragma unroll
+            for (int c = 0; c < WN; ++c) {
+                f32x16 v = acc[a][c];
+                // lo hi, hi lo, hi hi (small terms first)
+                v = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[1][a]), __builtin_bit_cast(f16x8, bf[0][c]), v, 0, 0, 0);
+                v = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[0][a]), __builtin_bit_cast(f16x8, bf[1][c]), v, 0, 0, 0);
+                acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[0][a]), __builtin_bit_cast(f16x8, bf[0][c]), v, 0, 0, 0);
+            }
+    };
+#ifdef T6_TRACE
+    int t6_stage = 0;
+    const bool t6_on = p.clk && mt == p.mtiles / 2 && nt == 0 && b == p.B / 2 && lane == 0 && t6_stage < 16;
+#define T6_STAMP(k) do { if (t6_on && t6_stage < 16) p.clk[16 + (wave * 16 + t6_stage) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#endif
+    // LEAN (wave tile of 6-8 accumulator tiles: 128 x 64, 64 x 96): 96-128 accumulator registers leave room for ONE fragment set and TWO
+    // weight sets only -- a weight set is reloaded right after the k-step that used it (one k-step ahead of its next use), the
+    // A fragments of a k-step are read just before its MFMAs (the co-resident workgroup covers the LDS latency).
+    constexpr bool LEAN = WMT * WN >= 6 || (WGM == 1 && tap6_occupancy<WGM, WGN, WMT, WN, NP>() == 3);
+    // one stage; returns true when it was the last one.
+    // EVERY stage issues the same loads in the same order -- A_SLOTS activation loads, then a weight set after each k-step --
+    // whether or not it needs them: a stage that stays on its A chunk points the activation loads past the end of the buffer
+    // resource (they return zeros without touching memory, into registers nobody reads), the last stage reloads k-step 0.
+    // The reason is s_waitcnt: vmcnt counts loads in issue order, so "wait for this k-step's weights but not for the younger
+    // loads" can only be encoded when the number of younger loads is the same on every path into the wait.  With `if
+    // (new_chunk)` / `if (has_next)` around the loads the compiler has to assume the fewest, and round 2's kernel waited for the
+    // weight set it had JUST requested before every second k-step (vmcnt(0): one exposed L2 round trip per stage) and for the
+    // first activation load before the first MFMA of every new-chunk stage (profiles/r3_tapgemm_trace.md: s_memtime stamps + ISA).
+    auto stage = [&](bf16x8 (&u0)[3][WN], bf16x8 (&u1)[3][WN], bf16x8 (&sp)[3][WN]) -> bool {
+#ifdef T6_TRACE
+        T6_STAMP(6);
+#endif
+        int nsi = si, nc0 = c0, nj = j + 1;
+        bool new_chunk = false;
+        if (nj == seg_J) {
+            nj = 0;
+            nc0 = c0 + KC;
+            new_chunk = true;
+            if (nc0 >= seg_Cw) { nc0 = 0; nsi = si + 1; }
+        }
+        const bool has_next = nsi < p.nseg;
+        const int cur_j = seg_reload ? 0 : j * seg_rowstep;
+        int s_next = 0;
+        if (has_next) {
+            if (nsi != si) enter_segment(nsi);
+            new_chunk = new_chunk || seg_reload;
+            s_next = (seg_kofs + nj * seg_Cw + nc0) >> 4;      // first k-step of the next stage in the packed weight rows
+        } else {
+            new_chunk = false;
+        }
+        // (sched_barrier: with every load unconditional a stage is one basic block, and the scheduler would sink the loads to
+        //  their first use -- the fences keep them where the latency plan needs them)
+        load_a(nsi, nc0, nj, new_chunk);
+        if (!LEAN) load_b(s_next, sp);
+        __builtin_amdgcn_sched_barrier(0);
+        const __bf16* Ac = As0 + abuf * NPL * PLANE + a_frag + cur_j * T6_PITCH;
+#ifdef T6_TRACE   // developer build: s_memtime stamps of one workgroup's stages (tools/experiments/r3o_trace.py)
+        if (t6_on && t6_stage < 16) p.clk[16 + (wave * 16 + t6_stage) * 8 + 7] = (seg_interior ? 1 : 0) | (new_chunk ? 2 : 0) | (mt << 8);
+        T6_STAMP(0);
+#endif
+        if constexpr (LEAN) {
+            bf16x8 af[3][WMT];
+            read_a(Ac, 0, af);
+            mfma_step(af, u0);
+#ifdef T6_TRACE
+            T6_STAMP(1);
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+            load_b(s_next, u0);
+            __builtin_amdgcn_sched_barrier(0);
+            read_a(Ac, 1, af);
+            mfma_step(af, u1);
+#ifdef T6_TRACE
+            T6_STAMP(2);
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+            load_b(s_next + 1, u1);
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
+            bf16x8 af0[3][WMT], af1[3][WMT];
+            read_a(Ac, 0, af0);
+            read_a(Ac, 1, af1);                                // the second k-step's fragments travel under the first one's MFMAs
+            mfma_step(af0, u0);
+            __builtin_amdgcn_sched_barrier(0);
+            load_b(s_next + 1, u0);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_step(af1, u1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (!has_next) return true;
+#ifdef T6_TRACE
+        T6_STAMP(3);
+#endif
+        // One barrier per CHUNK, not per stage: a slab is written only here, after the barrier that ended the chunk which last
+        // read it, and read only after the barrier that follows these writes -- the taps of one chunk need no barrier between them.
+        if (new_chunk) {                                       // the A loads had the whole stage to arrive
+            abuf ^= 1;
+            store_a(As0 + abuf * NPL * PLANE);
+        }
+#ifdef T6_TRACE
+        T6_STAMP(4);
+#endif
+        if (new_chunk) __syncthreads();
+#ifdef T6_TRACE
+        T6_STAMP(5);
+        ++t6_stage;
+#endif
+        si = nsi; c0 = nc0; j = nj;
+        return false;
+    };
+#ifdef T6_TRACE
+    T6_PHASE(6);
+#endif
+    if constexpr (LEAN) {
+        while (!stage(bx, by, bz)) {}
+    } else {
+        for (;;) {
+            if (stage(bx, by, bz)) break;
+            if (stage(bz, bx, by)) break;
+            if (stage(by, bz, bx)) break;
+        }
+    }
+
+    tap6_epilogue<WGM, WGN, WMT, WN, HALO>(p, acc, smem, b, m0, n0, a_inv, rowmode, clk_t0, clk_r0,
+#ifdef T6_TRACE
+                                            t6_ph
+#else
+                                            false
+#endif
+                                            );
 }
 
 }  // namespace ac
