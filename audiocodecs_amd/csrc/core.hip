@@ -355,11 +355,14 @@ int run_tap(ac_handle* h, hipStream_t st, TapGemmParams& p) {
                 };
                 const double sc1 = p.N % 256 == 0 ? 1.00 * fill8(256, 256) : 0.0;
                 const double sc3 = p.N % 256 == 0 ? 0.90 * fill8(128, 256) : 0.0;
-                const double sc2 = (kk >= 3072 ? 0.95 : 0.70) * fill8(256, 128);      // (loses to tap_gemm6's three workgroups per CU except on long contractions)
-                int form = sc1 >= sc2 && sc1 >= sc3 ? 1 : (sc3 >= sc2 ? 3 : 2);
+                int form = sc1 >= sc3 ? 1 : 3;
+                bool model = (form == 1 ? sc1 : sc3) >= 0.80;
+                if (p.N % 256 != 0) {      // 64 x 64 wave tiles over 128 columns lose to tap_gemm6's three workgroups per CU except on long contractions
+                    form = 2;
+                    model = kk >= 3072 && fill8(256, 128) >= 0.70;
+                }
                 if (h->dev.tap8_form >= 1 && h->dev.tap8_form <= 3 && (h->dev.tap8_form == 2 || p.N % 256 == 0)) form = h->dev.tap8_form;
-                const double best = form == 1 ? sc1 : form == 2 ? sc2 : sc3;
-                use8 = want8 >= 1 || best >= 0.80;
+                use8 = want8 >= 1 || model;
                 if (use8) {
 #define TAP8_LAUNCH_K(WGM, WGN, WMT, WN, RM, J1)                                                                         \
     do {                                                                                                                \
