@@ -189,32 +189,7 @@ int ac_finalize(ac_handle* h) {
                         pk.blob[h->cb_packed + (size_t)q * C * H + (((size_t)ct * HV + v) * 64 + lane) * 4 + u] =
                             (*e)[(size_t)(ct * 16 + (lane & 15)) * H + v * 16 + 4 * (lane >> 4) + u];
     }
-    if (pk.use16() && H % 32 == 0 && H / 16 == 8) {
-        // rvq16.h: split16 image of every table, one power-of-two scale per table, halves in the lanes' own dim order:
-        //   [q][code tile 16][k-step s of 32][plane 2][lane (j, kq)][e 8]  <->  dim 16 (2s + e/4) + 4 kq + e%4 of code 16 ct + j
-        const int KS = H / 32;
-        h->cb16 = pk.reserve((size_t)Q * C * H);                  // 2 planes x 2 bytes = 4 bytes per element
-        h->cb16_inv = pk.reserve((size_t)Q);
-        std::vector<uint16_t> img((size_t)Q * C * H * 2);
-        for (int q = 0; q < Q; ++q) {
-            const float* e = &pk.blob[h->cb_plain + (size_t)q * C * H];
-            const int se = Packer::row_scale(e, (size_t)C * H);
-            pk.blob[h->cb16_inv + q] = s16_pow2(-se);
-            for (int ct = 0; ct < C / 16; ++ct)
-                for (int s = 0; s < KS; ++s)
-                    for (int lane = 0; lane < 64; ++lane)
-                        for (int e8 = 0; e8 < 8; ++e8) {
-                            const int j = lane & 15, kq = lane >> 4;
-                            const int dim = 16 * (2 * s + e8 / 4) + 4 * kq + e8 % 4;
-                            uint16_t t[3];
-                            Packer::split16h(e[(size_t)(ct * 16 + j) * H + dim], se, t);
-                            const size_t base = ((((size_t)q * (C / 16) + ct) * KS + s) * 2) * 512 + (size_t)lane * 8 + e8;
-                            img[base] = t[0];
-                            img[base + 512] = t[1];
-                        }
-        }
-        std::memcpy(&pk.blob[h->cb16], img.data(), img.size() * 2);
-    }
+    if (pk.use16() && H % 32 == 0 && H / 16 == 8) pk.pack_cb16(h->cb_plain, Q, C, H, &h->cb16, &h->cb16_inv);     // rvq16.h
     return upload_blob(h, pk, c.device);
 }
 

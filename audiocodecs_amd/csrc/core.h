@@ -78,6 +78,7 @@ struct MimiPlan {
     PackedGemm in_proj;                                // [2*Dq][H]: semantic rows, then acoustic rows
     PackedGemm out_proj;                               // [H][2*Dq]: semantic | acoustic columns
     size_t cb_plain = 0, cb_packed = 0, cb_ee = 0;     // [Q][C][Dq] in wrapper order (semantic first)
+    size_t cb16 = 0, cb16_inv = 0;                     // rvq16.h: split16 images of the tables + their 2^-s (0: exact-product arithmetic)
     size_t rope_cos = 0, rope_sin = 0;                 // [rope_T][head_dim]
     int rope_T = 0;
     int D = 0;                                         // SEANet width at the bottleneck
@@ -428,6 +429,32 @@ struct Packer {
             return off;
         }
         return 0;   // exact-product arithmetic: no fragment images
+    }
+    // rvq16.h: split16 image of Q codebook tables [C][H] at blob offset `plain`, one power-of-two scale per table, halves in the lanes'
+    // own dim order:  [q][code tile 16][k-step s of 32][plane 2][lane (j, kq)][e 8]  <->  dim 16 (2s + e/4) + 4 kq + e%4 of code 16 ct + j
+    void pack_cb16(size_t plain, int Q, int C, int H, size_t* img_off, size_t* inv_off) {
+        const int KS = H / 32;
+        *img_off = reserve((size_t)Q * C * H);                  // 2 planes x 2 bytes = 4 bytes per element
+        *inv_off = reserve((size_t)Q);
+        std::vector<uint16_t> img((size_t)Q * C * H * 2);
+        for (int q = 0; q < Q; ++q) {
+            const float* e = &blob[plain + (size_t)q * C * H];
+            const int se = row_scale(e, (size_t)C * H);
+            blob[*inv_off + q] = s16_pow2(-se);
+            for (int ct = 0; ct < C / 16; ++ct)
+                for (int s = 0; s < KS; ++s)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int e8 = 0; e8 < 8; ++e8) {
+                            const int j = lane & 15, kq = lane >> 4;
+                            const int dim = 16 * (2 * s + e8 / 4) + 4 * kq + e8 % 4;
+                            uint16_t t[3];
+                            split16h(e[(size_t)(ct * 16 + j) * H + dim], se, t);
+                            const size_t base = ((((size_t)q * (C / 16) + ct) * KS + s) * 2) * 512 + (size_t)lane * 8 + e8;
+                            img[base] = t[0];
+                            img[base + 512] = t[1];
+                        }
+        }
+        std::memcpy(&blob[*img_off], img.data(), img.size() * 2);
     }
     // thin_conv6.h image of a [64][128] layer
     void pack_t6(const PackedGemm& g) {
@@ -848,7 +875,7 @@ int decoder_fwd(ac_handle* h, hipStream_t st, const long long* toks, int B, int 
 // DEFINES a non-template kernel: one definition per library)
 int rb64_identity_fwd(ac_handle* h, hipStream_t st, const ResBlockPlan& rb, const Act2& x, Out out, int B, const unsigned** amax_out);   // rb_fused6<64, false> / rb_fused<64,64,2,false>
 int rb128_identity_fwd(ac_handle* h, hipStream_t st, const ResBlockPlan& rb, const Act2& x, Out out, int B, const unsigned** amax_out); // rb128_fused6<false>
-int rvq_encode_cdist_launch(ac_handle* h, hipStream_t st, const RvqEncParams& p, unsigned blocks);   // rvq_encode_kernel<H/16, 1, true>
+int rvq_encode_cdist_launch(ac_handle* h, hipStream_t st, const RvqEncParams& p, unsigned blocks, const _Float16* epk16 = nullptr, const float* einv = nullptr);   // rvq_encode16_kernel<16, 1, true> (images given, H = 256) or rvq_encode_kernel<H/16, 1, true>
 void rvq_decode_launch(hipStream_t st, const RvqDecParams& p, unsigned blocks);
 void amax_fill_launch(hipStream_t st, unsigned* slot, unsigned bits, int B);
 int resample_launch(const float* x, int B, int L, const float* kern, int n, int o, int taps, int width, float* y, int L_out, hipStream_t st);

@@ -1124,14 +1124,15 @@ int rvq_encode_fwd(ac_handle* h, hipStream_t st, const float* feats, int F, int 
     const int MS = (HV <= 8 && F >= 1024 * 32) ? 3 : 1;
     const dim3 grid(cdiv(F, 16 * MS)), block(64);
     const bool exact_env = h->dev.rvq_exact != 0;   // developer A/B switch
-    if (h->cb16 && HV == 8 && !exact_env) {   // split16 products on the fp16 matrix pipe (rvq16.h)
+    if (h->cb16 && (HV == 8 || (HV == 32 && K == 1)) && !exact_env) {   // split16 products on the fp16 matrix pipe (rvq16.h)
         RvqEnc16Params q{};
         q.base = p;
         q.epk16 = reinterpret_cast<const _Float16*>(h->blob + h->cb16);
         q.einv = h->blob + h->cb16_inv;
         ProfScope ps(h, st, "rvq_encode16_kernel", 2.0 * F * (double)p.C * p.H * K,
                      (double)F * p.H * 4 + (double)F * K * 8 + (double)K * p.C * p.H * 4);
-        if (MS == 3) hipLaunchKernelGGL((rvq_encode16_kernel<8, 3, false>), grid, block, 0, st, q);
+        if (HV == 32) hipLaunchKernelGGL((rvq_encode16_kernel<32, 1, false, true>), dim3(cdiv(F, 16)), block, 0, st, q);      // WavTokenizer: 4096 x 512, one stage
+        else if (MS == 3) hipLaunchKernelGGL((rvq_encode16_kernel<8, 3, false>), grid, block, 0, st, q);
         else hipLaunchKernelGGL((rvq_encode16_kernel<8, 1, false>), grid, block, 0, st, q);
         HIPCHK(h, hipGetLastError());
         return AC_OK;
@@ -1481,8 +1482,16 @@ int rb64_identity_fwd(ac_handle* h, hipStream_t st, const ResBlockPlan& rb, cons
 int rb128_identity_fwd(ac_handle* h, hipStream_t st, const ResBlockPlan& rb, const Act2& x, Out out, int B, const unsigned** amax_out) {
     return launch_rb128_fused6<false>(h, st, rb, x, out, B, PAD_ZERO, amax_out);
 }
-int rvq_encode_cdist_launch(ac_handle* h, hipStream_t st, const RvqEncParams& p, unsigned blocks) {
+int rvq_encode_cdist_launch(ac_handle* h, hipStream_t st, const RvqEncParams& p, unsigned blocks, const _Float16* epk16, const float* einv) {
     const dim3 grid(blocks), block(64);
+    if (epk16 && p.H == 256 && !h->dev.rvq_exact) {      // Mimi: 2048 x 256 tables in split16 arithmetic (rvq16.h)
+        RvqEnc16Params q{};
+        q.base = p;
+        q.epk16 = epk16;
+        q.einv = einv;
+        hipLaunchKernelGGL((rvq_encode16_kernel<16, 1, true>), grid, block, 0, st, q);
+        return AC_OK;
+    }
     switch (p.H / 16) {
         case 1: hipLaunchKernelGGL((rvq_encode_kernel<1, 1, true>), grid, block, 0, st, p); break;
         case 2: hipLaunchKernelGGL((rvq_encode_kernel<2, 1, true>), grid, block, 0, st, p); break;

@@ -195,8 +195,10 @@ int mimi_rvq_encode(ac_handle* h, hipStream_t st, const float* proj /*[F][2*Dq]*
         p.K = n;
         p.tK = K;
         p.tk0 = k0;
-        ProfScope ps(h, st, "rvq_encode_kernel", 2.0 * F * (double)C * Dq * n, (double)F * Dq * 4 + (double)F * n * 8 + (double)n * C * Dq * 4);
-        if (int rc = rvq_encode_cdist_launch(h, st, p, (unsigned)cdiv(F, 16))) return rc;
+        const bool s16 = h->mimi.cb16 && Dq == 256 && !h->dev.rvq_exact;
+        ProfScope ps(h, st, s16 ? "rvq_encode16_kernel" : "rvq_encode_kernel", 2.0 * F * (double)C * Dq * n, (double)F * Dq * 4 + (double)F * n * 8 + (double)n * C * Dq * 4);
+        if (int rc = rvq_encode_cdist_launch(h, st, p, (unsigned)cdiv(F, 16), s16 ? reinterpret_cast<const _Float16*>(h->blob + h->mimi.cb16) + (size_t)k0 * C * Dq * 2 : nullptr,
+                                             s16 ? h->blob + h->mimi.cb16_inv + k0 : nullptr)) return rc;
         HIPCHK(h, hipGetLastError());
     }
     return AC_OK;
@@ -553,6 +555,7 @@ int mimi_finalize(ac_handle* h, Packer& pk) {
                         pk.blob[m.cb_packed + (size_t)q * C * Dq + (((size_t)ct * HV + v) * 64 + lane) * 4 + u] =
                             e[(size_t)(ct * 16 + (lane & 15)) * Dq + v * 16 + 4 * (lane >> 4) + u];
     }
+    if (pk.use16() && Dq == 256) pk.pack_cb16(m.cb_plain, Q, C, Dq, &m.cb16, &m.cb16_inv);     // rvq16.h
     return AC_OK;
 }
 

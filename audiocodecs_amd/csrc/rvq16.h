@@ -27,7 +27,9 @@ struct RvqEnc16Params {
     const float* einv;       // [K] 2^-se of each table's image
 };
 
-template <int HV, int MS, bool CDIST>
+// K1: a single stage (WavTokenizer: one codebook of 4096 x 512) -- no residual update, so the 128 registers of the fp32 row are free once
+// its planes are built and the code tiles can stay double-buffered at H = 512
+template <int HV, int MS, bool CDIST, bool K1 = false>
 __global__ __launch_bounds__(64) void rvq_encode16_kernel(const RvqEnc16Params q) {
     static_assert(HV % 2 == 0, "k-steps of 32 dims");
     constexpr int KS = HV / 2;
@@ -48,7 +50,7 @@ __global__ __launch_bounds__(64) void rvq_encode16_kernel(const RvqEnc16Params q
     }
 
     const int ctiles = p.C / 16;
-    for (int k = 0; k < p.K; ++k) {
+    for (int k = 0; k < (K1 ? 1 : p.K); ++k) {
         float xxr[MS][4], m2s[MS][4];        // per accumulator row: |x|^2 and -2 * 2^-(sx + se)
         f16x8 xh[MS][KS], xl[MS][KS];
         const float einv = q.einv[k];
@@ -129,14 +131,23 @@ __global__ __launch_bounds__(64) void rvq_encode16_kernel(const RvqEnc16Params q
                     if (d > best[m][r]) { best[m][r] = d; bidx[m][r] = code; }
                 }
         };
-        f16x8 bh0[KS], bl0[KS], bh1[KS], bl1[KS];
-        float ee0, ee1 = 0.f;
-        load_tile(0, bh0, bl0, ee0);
-        for (int ct = 0; ct < ctiles; ct += 2) {
-            load_tile(ct + 1, bh1, bl1, ee1);
-            run_tile(ct, bh0, bl0, ee0);
-            if (ct + 2 < ctiles) load_tile(ct + 2, bh0, bl0, ee0);
-            run_tile(ct + 1, bh1, bl1, ee1);
+        if constexpr (HV <= 16 || K1) {    // code tiles double-buffered in registers: tile ct + 1 travels under tile ct's MFMAs
+            f16x8 bh0[KS], bl0[KS], bh1[KS], bl1[KS];
+            float ee0, ee1 = 0.f;
+            load_tile(0, bh0, bl0, ee0);
+            for (int ct = 0; ct < ctiles; ct += 2) {
+                load_tile(ct + 1, bh1, bl1, ee1);
+                run_tile(ct, bh0, bl0, ee0);
+                if (ct + 2 < ctiles) load_tile(ct + 2, bh0, bl0, ee0);
+                run_tile(ct + 1, bh1, bl1, ee1);
+            }
+        } else {                           // H = 512 with several stages: one tile set of 128 registers
+            f16x8 bh0[KS], bl0[KS];
+            float ee0;
+            for (int ct = 0; ct < ctiles; ++ct) {
+                load_tile(ct, bh0, bl0, ee0);
+                run_tile(ct, bh0, bl0, ee0);
+            }
         }
 #pragma unroll
         for (int m = 0; m < MS; ++m) {
@@ -162,7 +173,7 @@ __global__ __launch_bounds__(64) void rvq_encode16_kernel(const RvqEnc16Params q
                 const int v = __shfl(bidx[m][r], (li >> 2) * 16);
                 if ((li & 3) == r) myidx = v;
             }
-            if (k + 1 < p.K) {
+            if (!K1 && k + 1 < p.K) {
                 const float* qv_ = p.e + ((long long)k * p.C + myidx) * H + 4 * kq;
 #pragma unroll
                 for (int v = 0; v < HV; ++v) {

@@ -76,6 +76,7 @@ int wavtok_finalize(ac_handle* h, Packer& pk) {
                     for (int u = 0; u < 4; ++u)
                         pk.blob[h->cb_packed + (((size_t)ct * HV + v) * 64 + lane) * 4 + u] =
                             (*e)[(size_t)(ct * 16 + (lane & 15)) * D + v * 16 + 4 * (lane >> 4) + u];
+        if (pk.use16() && D == 512) pk.pack_cb16(h->cb_plain, 1, Cb, D, &h->cb16, &h->cb16_inv);     // rvq16.h
     }
     if (!h->has_dec) return AC_OK;
     // ---- backbone
