@@ -1,8 +1,10 @@
 // rb128_fused6: the fused residual block of rb_fused6.h for C = 128 (hidden 64), where the two weight images
 // (k3 conv [64][384], [1x1 | shortcut] [128][192]) are 295 KB as bf16 planes -- they fit the register file of a CU only
 // when EIGHT waves share them (144 VGPRs each, one workgroup of 512 threads per CU):
-//   stage A  hidden = ELU(W3 * [xe(t-2) | xe(t-1) | xe(t)] + b3):  wave (ng = w & 3, kg = w >> 2) owns hidden channels
-//            16 ng .. +15 and HALF of K (k-steps 6 kg .. 6 kg + 5); the kg = 1 partial sums travel through LDS (fp32);
+//   stage A  hidden = ELU(W3 * [xe(t-2) | xe(t-1) | xe(t)] + b3):  wave (ng = w & 3, th = w >> 2) owns hidden channels
+//            16 ng .. +15 over ALL of K for HALF of the tile's time rows (round 4: with two planes per operand the full-K
+//            weights of a wave are 96 registers -- rounds 1-3 split K over the wave pair and added the halves through LDS:
+//            one more barrier and 17 KB of fp32 traffic per tile);
 //   stage B  y = [W1 | Ws] * [hidden | x] + bf:  wave w owns output channels 16 w .. +15 and all of K.
 // Everything else as in rb_fused6.h: x is read once per 64-row tile (raw rows, ELU while staging), split once into
 // bf16 planes in LDS, transposed MFMA tiles (a lane holds 4 consecutive channels of one time row), 16-byte stores
@@ -16,43 +18,45 @@ namespace ac {
 
 template <bool SC>
 struct Rb128Cfg {
-    static constexpr int C = 128, HC = 64, BM = 64, NT = 512;
-    static constexpr int KSA = 12, KSA_W = 6;                           // k-steps of stage A, per wave
+#ifndef RB128_BM
+#define RB128_BM 64     // rows per tile.  96 measured no better where it fits (identity shortcut, Mimi: 6.32 vs 6.26 ms) and spills 31 registers with the 1x1 shortcut
+#endif
+    static constexpr int C = 128, HC = 64, BM = RB128_BM, NT = 512;
+    static constexpr int KSA = 12;                                      // k-steps of stage A
     static constexpr int KSH = 2, KSB = KSH + (SC ? 4 : 0);             // k-steps of stage B: hidden, then x
     static constexpr int TT = BM / 16;                                  // 16-row time tiles (every wave covers all of them)
     static constexpr int XP = C + 8, HP = HC + 8;
     static constexpr int XE_ROWS = BM + 2;
     static constexpr int XE_PLANE = XE_ROWS * XP, XR_PLANE = SC ? BM * XP : 0, H_PLANE = BM * HP;
-    static constexpr int PSP = HC + 4;                                  // partial-sum row pitch (floats)
     static constexpr int SLOTS = (XE_ROWS * (C / 4) + NT - 1) / NT;
-    static constexpr size_t lds_bytes = (size_t)3 * (XE_PLANE + XR_PLANE + H_PLANE) * 2 + (size_t)BM * PSP * 4;
+    static constexpr size_t lds_bytes = (size_t)2 * (XE_PLANE + XR_PLANE + H_PLANE) * 2;
+    static_assert(TT % 2 == 0 && lds_bytes <= 160 * 1024, "two time halves; one workgroup per CU");
 };
 
 template <bool SC, int NP = 2>
 __global__ __launch_bounds__(512, 1) void rb128_fused6_kernel(const RbFused6Params p) {
     using Cfg = Rb128Cfg<SC>;
     constexpr int C = Cfg::C, BM = Cfg::BM, NT = Cfg::NT, XP = Cfg::XP, HP = Cfg::HP, TT = Cfg::TT;
-    constexpr int KSA_W = Cfg::KSA_W, KSH = Cfg::KSH, KSB = Cfg::KSB, SLOTS = Cfg::SLOTS, PSP = Cfg::PSP;
+    constexpr int KSA = Cfg::KSA, KSH = Cfg::KSH, KSB = Cfg::KSB, SLOTS = Cfg::SLOTS;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    __bf16* Xe = reinterpret_cast<__bf16*>(smem);                  // [3][XE_ROWS][XP]
-    __bf16* Xr = Xe + 3 * Cfg::XE_PLANE;                           // [3][BM][XP]       (SC only)
-    __bf16* Hs = Xr + 3 * Cfg::XR_PLANE;                           // [3][BM][HP]
-    float* Ps = reinterpret_cast<float*>(Hs + 3 * Cfg::H_PLANE);   // [BM][PSP] partial sums of the upper K half
+    __bf16* Xe = reinterpret_cast<__bf16*>(smem);                  // [2][XE_ROWS][XP]
+    __bf16* Xr = Xe + 2 * Cfg::XE_PLANE;                           // [2][BM][XP]       (SC only)
+    __bf16* Hs = Xr + 2 * Cfg::XR_PLANE;                           // [2][BM][HP]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ng = wave & 3, kg = wave >> 2;
+    const int ng = wave & 3, th = wave >> 2;
     const int li = lane & 15, kq = lane >> 4;
     const int total = p.B * p.ntiles;
 
     // ---- this wave's weight fragments -> registers (once)
     constexpr int WPL = NP == 2 ? 2 : 3;                           // planes in the weight images
-    bf16x8 w3r[KSA_W][3], wfr[KSB][3];
+    bf16x8 w3r[KSA][3], wfr[KSB][3];
 #pragma unroll
-    for (int i = 0; i < KSA_W; ++i)
+    for (int i = 0; i < KSA; ++i)
 #pragma unroll
         for (int pl = 0; pl < NP; ++pl)
-            w3r[i][pl] = *reinterpret_cast<const bf16x8*>(p.w3f + ((((long long)ng * Cfg::KSA + kg * KSA_W + i) * WPL + pl) * 64 + lane) * 8);
+            w3r[i][pl] = *reinterpret_cast<const bf16x8*>(p.w3f + ((((long long)ng * KSA + i) * WPL + pl) * 64 + lane) * 8);
 #pragma unroll
     for (int ks = 0; ks < KSB; ++ks)
 #pragma unroll
@@ -111,43 +115,29 @@ __global__ __launch_bounds__(512, 1) void rb128_fused6_kernel(const RbFused6Para
         const int next = tile + gridDim.x;
         const Rb16Scale cs = sc;
         if (next < total) load_tile(next);                      // in flight during both MFMA stages
-        // ---- stage A: this wave's half of K for hidden channels 16 ng ..
+        // ---- stage A: hidden channels 16 ng .. over all of K, time tiles th * TT / 2 ..
         {
-            f32x4 acc[TT];
+            constexpr int TH = TT / 2;
+            f32x4 acc[TH];
 #pragma unroll
-            for (int a = 0; a < TT; ++a) acc[a] = (kg == 0 && NP != 2) ? b3v : zero4;
+            for (int a = 0; a < TH; ++a) acc[a] = zero4;
 #pragma unroll
-            for (int i = 0; i < KSA_W; ++i) {
-                const int ks = kg * KSA_W + i;                   // k-step of 32 over k = tap * 128 + ci
+            for (int ks = 0; ks < KSA; ++ks) {                   // k-step of 32 over k = tap * 128 + ci
                 const int j = ks >> 2, kc = ks & 3;
 #pragma unroll
-                for (int a0 = 0; a0 < TT; a0 += 2) {             // two time tiles at a time: 24 fragment registers live
-                    bf16x8 xf[2][3];
+                for (int a = 0; a < TH; ++a) {
+                    bf16x8 xf[3];
 #pragma unroll
-                    for (int a = 0; a < 2; ++a)
-#pragma unroll
-                        for (int pl = 0; pl < NP; ++pl)
-                            xf[a][pl] = *reinterpret_cast<const bf16x8*>(Xe + pl * Cfg::XE_PLANE + ((a0 + a) * 16 + li + j) * XP + kc * 32 + 8 * kq);
-#pragma unroll
-                    for (int a = 0; a < 2; ++a) acc[a0 + a] = mma6<NP>(w3r[i], xf[a], acc[a0 + a]);
+                    for (int pl = 0; pl < NP; ++pl)
+                        xf[pl] = *reinterpret_cast<const bf16x8*>(Xe + pl * Cfg::XE_PLANE + ((th * TH + a) * 16 + li + j) * XP + kc * 32 + 8 * kq);
+                    acc[a] = mma6<NP>(w3r[ks], xf, acc[a]);
                 }
             }
-            if (kg == 1) {
 #pragma unroll
-                for (int a = 0; a < TT; ++a) *reinterpret_cast<f32x4*>(&Ps[(a * 16 + li) * PSP + ng * 16 + 4 * kq]) = acc[a];
-            }
-            lds_barrier();  
-            if (kg == 0) {
-#pragma unroll
-                for (int a = 0; a < TT; ++a) {
-                    const f32x4 u = *reinterpret_cast<const f32x4*>(&Ps[(a * 16 + li) * PSP + ng * 16 + 4 * kq]);
-                    f32x4 v = f32x4{acc[a].x + u.x, acc[a].y + u.y, acc[a].z + u.z, acc[a].w + u.w};
-                    if (NP == 2) {                               // true units: exact power-of-two factors, then the bias
-                        const f32x4 iv = i3v * cs.ix;
-                        v = f32x4{__fmaf_rn(v.x, iv.x, b3v.x), __fmaf_rn(v.y, iv.y, b3v.y), __fmaf_rn(v.z, iv.z, b3v.z), __fmaf_rn(v.w, iv.w, b3v.w)};
-                    }
-                    split_store4<NP>(elu4(v), Hs, Cfg::H_PLANE, (a * 16 + li) * HP + ng * 16 + 4 * kq, cs.sb);
-                }
+            for (int a = 0; a < TH; ++a) {                       // true units: exact power-of-two factors, then the bias
+                const f32x4 iv = i3v * cs.ix;
+                const f32x4 v = f32x4{__fmaf_rn(acc[a].x, iv.x, b3v.x), __fmaf_rn(acc[a].y, iv.y, b3v.y), __fmaf_rn(acc[a].z, iv.z, b3v.z), __fmaf_rn(acc[a].w, iv.w, b3v.w)};
+                split_store4<NP>(elu4(v), Hs, Cfg::H_PLANE, ((th * TH + a) * 16 + li) * HP + ng * 16 + 4 * kq, cs.sb);
             }
         }
         lds_barrier();  

@@ -199,8 +199,10 @@ def canonical_kernel(name):
     """One spelling per instantiation: the tap-GEMM's slab-halo template argument (rocprofv3 prints `..., 2, 7>` / `..., 2, 56>`,
     the library's own records `..., 2>` / `..., 2, dil>`) becomes nothing / `dil`; everything else is family<arguments>."""
     fam, args, _ = parse_kernel(name)
-    if fam in ("tap_gemm6_kernel", "tap_gemm8_kernel") and len(args) >= 6:
+    if fam == "tap_gemm6_kernel" and len(args) >= 6:
         args = args[:5] + ([] if args[5] == "7" else ["dil"])
+    if fam == "tap_gemm8_kernel":      # rocprofv3: <WGM, WGN, WMT, WN, row mode, one tap>; the library's records: <WGM, WGN, WMT, WN, 2>
+        args = args[:4]
     return f"{fam}<{', '.join(args)}>" if args else fam
 
 
@@ -211,7 +213,9 @@ def kernel_planes(name):
     fam, args, _ = parse_kernel(name)
     if fam not in SPLIT_FAMILIES:
         return None
-    if fam in ("tap_gemm6_kernel", "tap_gemm8_kernel"):
+    if fam == "tap_gemm8_kernel":
+        return 2        # split16 only (its template arguments after the tile form are flags, not a plane count)
+    if fam == "tap_gemm6_kernel":
         return int(args[4]) if len(args) >= 5 and args[4].isdigit() else 2
     if fam in ("rb_fused6_kernel", "rb128_fused6_kernel", "thin_conv6_kernel"):
         return int(args[-1]) if args and args[-1].isdigit() else 2

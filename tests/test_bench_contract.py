@@ -86,6 +86,9 @@ def test_traffic_lookup_matches_rocprof_spelling():
     assert bench.canonical_kernel("tap_gemm6_kernel<1, 4, 4, 2, 2, 7>") == bench.canonical_kernel("tap_gemm6_kernel<1, 4, 4, 2, 2> B64 M6000 N256 K384 J3 s1")
     assert bench.canonical_kernel("void ac::tap_gemm6_kernel<1, 4, 4, 2, 2, 56>(ac::TapGemmParams, __bf16 const*)") == bench.canonical_kernel("tap_gemm6_kernel<1, 4, 4, 2, 2, dil>")
     assert bench.canonical_kernel("tap_gemm6_kernel<1, 4, 4, 2, 2, dil>") != bench.canonical_kernel("tap_gemm6_kernel<1, 4, 4, 2, 2>")
+    assert bench.canonical_kernel("void ac::tap_gemm8_kernel<2, 4, 4, 2, false, false>(ac::TapGemmParams, __bf16 const*)") == bench.canonical_kernel("tap_gemm8_kernel<2, 4, 4, 2, 2> B64 M6000 N256 K1280 J2 s5")
+    assert bench.canonical_kernel("tap_gemm8_kernel<2, 4, 4, 2, true, true>") != bench.canonical_kernel("tap_gemm8_kernel<2, 4, 2, 2, true, true>")
+    assert bench.mfma16_terms("void ac::tap_gemm8_kernel<2, 4, 4, 2, false, true>(ac::TapGemmParams, __bf16 const*)") == 3
     got = bench.measured_traffic("tap_gemm6_kernel<1, 4, 4, 2, 2>", "TFLOP/s", "encodec", 64)
     assert got is not None and got[0] > 1e9 and got[1].startswith("profiles/r")
     newest = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_traffic.json") and not any(c in f for c in ("mimi", "dac", "wavtok")))
