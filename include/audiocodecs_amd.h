@@ -30,7 +30,7 @@
  *  - activations, weights and results are fp32, accumulation is fp32, tokens are int64 like the reference's.  The
  *    large GEMMs, the fused residual blocks and the LSTM products run "split-operand" arithmetic on the fp16 matrix pipe:
  *    every fp32 operand, scaled by a power of two, is written as two fp16 terms and 3 of the 4 exact partial products
- *    are accumulated in fp32 (error equal to fp32 arithmetic, DESIGN.md section 12; ac_set_precision lists the
+ *    are accumulated in fp32 (error equal to fp32 arithmetic, DESIGN.md section 4; ac_set_precision lists the
  *    alternatives: three bf16 terms / 6 products, exact fp32 products (v_mfma_f32_16x16x4_f32), opt-in bf16).
  */
 #ifndef AUDIOCODECS_AMD_H
