@@ -174,7 +174,7 @@ struct ac_handle {
         int tap_epi_staged = 0;     // AC_TAP_EPI=staged   : every tap-GEMM through the LDS-staged epilogue (A/B against the direct one)
         int tap_dil = 1;            // AC_TAP_DIL=0        : dilated taps reload the slab per tap instead of the wide-slab instantiation
         int tap_stagger = 0;        // AC_TAP_STAGGER=n    : random start delays (timing experiment)
-        int tap_pick = -1;          // AC_TAP_PICK=0|1|2|3 : force a tile arrangement for N % 256 == 0 layers
+        int tap_pick = -1;          // AC_TAP_PICK=0|1|2   : force a tile arrangement for N % 256 == 0 layers
         int tap8 = -1;              // AC_TAP8=-1|0|1      : tap_gemm8.h by the cost model (default) / never / wherever the shape allows
         int tap8_form = 0;          // AC_TAP8_FORM=1|2|3  : force its tile form (256 x 256, 256 x 128, 128 x 256) where the shape allows
         int rb6_dbg = 0;            // AC_RB6_DBG          : timing variants of the fused blocks (wrong results)

@@ -407,12 +407,12 @@ int run_tap(ac_handle* h, hipStream_t st, TapGemmParams& p) {
             //  4.71 ms at 128 columns, 5.43 ms with 1 x 8 waves)
             const double s8 = (kk >= 2048 ? (p.winv ? 1.00 : 1.12) : (p.winv ? 0.85 : 0.95)) * fill(wg256, 256.0);
             pick = s256 >= s128 && s256 >= s8 ? 1 : (s8 > s128 ? 2 : 0);
-            if (h->dev.tap_pick >= 0 && h->dev.tap_pick <= 3) pick = h->dev.tap_pick;     // developer override
+            if (h->dev.tap_pick >= 0 && h->dev.tap_pick <= 2) pick = h->dev.tap_pick;     // developer override
         }
-        if (h->dev.tap_pick == 4 && p.N % 128 == 0) pick = 4;
-        if (pick == 3) TAP6_CASE(2, 4, 4, 2);          // experiment: 256 x 256, 8 waves of 128 x 64, one workgroup per CU
-        else if (pick == 4) TAP6_CASE(2, 4, 4, 1);     // experiment: 256 x 128, 8 waves of 128 x 32
-        else if (pick == 1) TAP6_CASE(1, 4, 4, 2);
+        // (256-row, 8-wave arrangements of THIS kernel -- <2,4,4,2>, <2,4,4,1> -- measured 7-12 % / 25-30 % slower per layer than
+        //  the picks below: one workgroup per CU and the old load pipeline; profiles/r4_tapgemm8.md.  tap_gemm8.h is that tile with a
+        //  pipeline built for it.)
+        if (pick == 1) TAP6_CASE(1, 4, 4, 2);
         else if (pick == 2) TAP6_CASE(1, 8, 4, 1);
         else if (p.N % 128 == 0) TAP6_CASE(1, 4, 4, 1);
         else if (p.N % 192 == 0) TAP6_CASE(2, 2, 2, 3);   // DAC's 192-wide layers: a weight fragment is loaded by two waves, not four

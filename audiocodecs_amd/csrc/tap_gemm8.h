@@ -41,6 +41,7 @@ struct Tap8Cfg {
     static_assert(a_bytes % 16 == 0, "ring base alignment");
     static constexpr size_t main_bytes = a_bytes + b_bytes;
     static constexpr size_t lds_bytes = main_bytes > C6::epi_bytes ? main_bytes : C6::epi_bytes;
+    static_assert(lds_bytes <= 160 * 1024, "one workgroup per CU: slabs + weight ring (or the staged epilogue's tile) within 160 KB of LDS");
 };
 
 // one 1 KiB LDS-DMA transfer: lane l's 16 bytes at gsrc land at LDS byte address lds_dst + 16 l (lds_dst wave-uniform).  Inline asm:
