@@ -777,6 +777,13 @@ int thin_head(ac_handle* h, hipStream_t st, const PackedGemm& g, int F, int k, i
     p.k = k;
     p.Lp = x.L > k - 1 ? x.L : k;
     p.pad = pad;
+    if (F % 16 == 0 && !h->dev.head_seq) {      // four lanes per sample (thin.h head4_kernel)
+        const size_t lds4 = ((size_t)(HEAD4_TT + THIN_MAXK) * (F + 4) + (size_t)THIN_MAXK * F) * sizeof(float);
+        ProfScope ps(h, st, "head4_kernel", 2.0 * B * (double)x.L * F * k, (double)B * x.L * 4.0 * (F + 1));
+        hipLaunchKernelGGL(head4_kernel, dim3(cdiv(x.L, HEAD4_TT), B), dim3(256), lds4, st, p);
+        HIPCHK(h, hipGetLastError());
+        return AC_OK;
+    }
     const size_t lds = ((size_t)(HEAD_TT + THIN_MAXK) * (F + 4) + (size_t)THIN_MAXK * F) * sizeof(float);
     if (int rc = ensure_lds(h, reinterpret_cast<const void*>(head_kernel), lds)) return rc;
     {

@@ -129,6 +129,53 @@ __global__ __launch_bounds__(256) void head_kernel(const ThinParams p) {
     p.y[(long long)b * p.T + t] = p.tanh_out ? tanhf(acc) : acc;
 }
 
+// head4_kernel (round 4): the same layer for F % 16 == 0 with FOUR lanes per output sample, each over a quarter of the channels
+// (all taps), the quarters added pairwise ((q0 + q1) + (q2 + q3)), the bias last.  head_kernel walks a sample's k F products as
+// ONE sequential fp32 chain per thread behind a 256-row staging tile: two workgroups per CU, 448 dependent FMAs per thread for
+// Mimi's 64 channels -- 2.7 TB/s on a layer that only reads (Mimi 128 x 10 s: 2.9 ms; DAC: 3 % of its step).  Here a workgroup
+// stages 64 + k - 1 rows (21 KB: seven workgroups per CU), a thread's chain is k F / 4 long; LDS pitch F + 4 floats: the 16 lanes
+// of a 16-byte read group (4 samples x 4 quarters) cover all 64 banks.  The summation ORDER differs from head_kernel's (fp32
+// rounding only; both are within the parity tolerance of the waveform, tests/test_*_gpu_parity.py).
+constexpr int HEAD4_TT = 64;    // outputs per workgroup
+
+__global__ __launch_bounds__(256) void head4_kernel(const ThinParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int F = p.F, FP = F + 4;
+    float* xs = smem;                                    // [(HEAD4_TT + pad)][FP]
+    float* ws = smem + (HEAD4_TT + THIN_MAXK) * FP;      // [k][F]
+    const int b = blockIdx.y, t0 = blockIdx.x * HEAD4_TT, tid = threadIdx.x;
+    const int pad = p.k - 1, fq = F / 4, fqq = fq / 4;
+    const float* xb = p.x + (long long)b * p.T * F;
+    for (int e = tid; e < (HEAD4_TT + pad) * fq; e += 256) {
+        const int row = e / fq, q = e % fq;
+        const int j = reflect_src(t0 - p.padl + row, p.T, p.Lp, p.pad);
+        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (j >= 0) v = *reinterpret_cast<const f32x4*>(xb + (long long)j * F + 4 * q);
+        *reinterpret_cast<f32x4*>(&xs[row * FP + 4 * q]) = v;
+    }
+    for (int e = tid; e < p.k * F; e += 256) ws[e] = p.w[e];
+    __syncthreads();
+    const int tl = tid >> 2, q = tid & 3;                // four adjacent lanes share a sample
+    float acc = 0.f;
+    for (int j = 0; j < p.k; ++j) {
+        const float* xr = &xs[(tl + j) * FP + q * fqq * 4];
+        const float* wr = &ws[j * F + q * fqq * 4];
+        for (int g = 0; g < fqq; ++g) {
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(xr + 4 * g);
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(wr + 4 * g);
+            acc = fmaf(wv.x, xv.x, acc); acc = fmaf(wv.y, xv.y, acc);
+            acc = fmaf(wv.z, xv.z, acc); acc = fmaf(wv.w, xv.w, acc);
+        }
+    }
+    acc += __shfl_xor(acc, 1);                           // q0 + q1 | q2 + q3
+    acc += __shfl_xor(acc, 2);                           // (q0 + q1) + (q2 + q3): the same value in the four lanes (fp32 + is commutative)
+    const int t = t0 + tl;
+    if (q == 0 && t < p.T) {
+        const float v = acc + p.bias[0];
+        p.y[(long long)b * p.T + t] = p.tanh_out ? tanhf(v) : v;
+    }
+}
+
 // Polyphase windowed-sinc sample-rate conversion: what torchaudio.functional.resample applies at the
 // Codec boundary (audiocodecs/codec.py:59-63,95-99): zero-pad (width, width + o), conv1d with the
 // [n phases][taps] kernel at stride o, interleave the phases, truncate.  out[i*n + ph] =

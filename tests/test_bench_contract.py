@@ -49,7 +49,7 @@ def _emitted_kernel_names():
     csrc = os.path.join(ROOT, "audiocodecs_amd", "csrc")
     for fn in os.listdir(csrc):
         if fn.endswith((".hip", ".h")):
-            for m in re.finditer(r'"((?:tap_gemm|rb_fused|rb128_fused|thin_conv|lstm_|enc_front|dec_tail|rvq_|dac_vq|stem_|head_)[A-Za-z0-9_]*(?:<[^"]*)?)"', open(os.path.join(csrc, fn)).read()):
+            for m in re.finditer(r'"((?:tap_gemm|rb_fused|rb128_fused|thin_conv|lstm_|enc_front|dec_tail|rvq_|dac_vq|stem_|head_|head4_)[A-Za-z0-9_]*(?:<[^"]*)?)"', open(os.path.join(csrc, fn)).read()):
                 names.add(m.group(1))
     return names
 
@@ -69,7 +69,7 @@ def test_every_split16_kernel_name_maps_to_three_products():
     for nm in three:
         assert bench.mfma16_terms(nm) == 3, nm
     for nm in ("tap_gemm4_kernel<2, 2, 4, 4>" + shape, "tap_gemm_kernel<2, 2, 4, 4, true>", "rb_fused_kernel<64, 64, 2>", "lstm_persist_kernel", "lstm_step_kernel",
-               "rvq_encode_kernel", "rvq_decode_kernel", "attention_kernel", "layernorm_kernel", "amax_kernel", "stem_kernel", "head_kernel", "dac_vq_encode_kernel"):
+               "rvq_encode_kernel", "rvq_decode_kernel", "attention_kernel", "layernorm_kernel", "amax_kernel", "stem_kernel", "head_kernel", "head4_kernel", "dac_vq_encode_kernel"):
         assert bench.mfma16_terms(nm) == 0, nm
     # the names found in the sources: every split-family one resolves to 3, none raises
     for nm in _emitted_kernel_names():
