@@ -1033,7 +1033,9 @@ int lstm_fwd(ac_handle* h, hipStream_t st, const LstmPlan& lp, const Act& x, con
                             for (int k = 1; k < 8; ++k) std::fprintf(stderr, " %lld", r[k] ? (long long)(r[k] - r[0]) : -1LL);
                             if (s_ < 3) std::fprintf(stderr, " next %lld ", (long long)(r[8] - r[0]));
                         }
-                        std::fprintf(stderr, " | steps that had to poll: %llu of %d\n", tr[role * 64 + 63], T);
+                        const double us3 = (double)(tr[role * 64 + 24] - tr[role * 64]) * 0.01;
+                        std::fprintf(stderr, " | steps that had to poll: %llu of %d | shader clock %.0f MHz\n", tr[role * 64 + 63], T,
+                                     us3 > 0 ? (double)(tr[role * 64 + 33] - tr[role * 64 + 32]) / us3 : 0.0);
                     }
                 }
                 continue;

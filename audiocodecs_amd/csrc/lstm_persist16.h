@@ -12,11 +12,13 @@
 //   * layer 0 -> layer 1 crosses to the neighbouring XCD.  An sc1 store is acknowledged only when written through, and the
 //     memory counter is in order, so the next recurrent load would wait for it: layer 0 keeps its last LP16_BATCH published
 //     values in LDS and writes them to hseq0 once per batch; layer 1 runs that far behind.
-//   * the CU's load path RETURNS IN ORDER: every request that takes an HBM or cross-XCD round trip (x[t+3] of the fused input
-//     projection, h0[t+2] for layer 1's projection, the skip value) is issued right BEHIND the request for the next recurrent
-//     operand and has a whole step to arrive; the recurrent request itself is issued in the middle of the projection that
-//     follows the publish (the peers publish at about the same time), so its round trip runs under the projection's MFMAs; when
-//     it comes back incomplete, the step starts with the ordinary polling load.
+//   * the CU's load path RETURNS IN ORDER and moves 64 B/clk: layer 1's cross-XCD requests (h0[t+2] for its projection, the skip
+//     value) are issued right BEHIND the request for the next recurrent operand and have a whole step to arrive; layer 0's x[t+2]
+//     (32 KB per CU and step, as much as the exchange) is requested in FRONT of the barrier and passes under the partial sums and
+//     the gate arithmetic (round 4: behind the recurrent request it shared the path with the peers' h and layer 0 bound the
+//     kernel).  The recurrent request itself is issued in the middle of the projection that follows the publish (the peers
+//     publish at about the same time), so its round trip runs under the projection's MFMAs; when it comes back incomplete, the
+//     step starts with the ordinary polling load.
 // h lies in [-1, 1]: it travels as 2 h = hi + lo with |hi| < 2 (bit 14 clear: the exchange's "has arrived" test).  1.0 itself occurs
 // when the gates saturate, and fp16(2.0) has bit 14 set: hi is capped at the largest fp16 below 2, lo takes the rest; the rows of
 // [W_ih | W_hh] of a layer share one power-of-two scale per gate row; the fused layer-0 projection scales x[t] by its clip's amax
@@ -247,7 +249,7 @@ __global__ __launch_bounds__(512) void lstm_persist16_kernel(const LstmPersist16
         for (int n = 0; n < 4; ++n)
 #pragma unroll
             for (int r = 0; r < 4; ++r) accP[n][r] *= xcr[r];
-        fetch0(t + 1 < p.T ? t + 1 : t);          // behind the recurrent request (in-order load path), into registers nothing else wants
+        (void)t;
     };
     auto project = [&](int t) -> bool {                        // layer 1, polling path
         bf16x8 a[2][2];
@@ -263,7 +265,8 @@ __global__ __launch_bounds__(512) void lstm_persist16_kernel(const LstmPersist16
     if (fuse0) {
         fetch0(0);
         convert0();
-        project0(0, 0, std::false_type{});                     // (leaves x[1] on its way)
+        project0(0, 0, std::false_type{});
+        fetch0(p.T > 1 ? 1 : 0);                               // (leaves x[1] on its way)
     }
     // layer 1's skip value: requested without a divergent branch around the load (threads without a clip read clip0's row) --
     // the join of such a branch made the compiler wait for every outstanding request in the middle of the projection
@@ -271,6 +274,8 @@ __global__ __launch_bounds__(512) void lstm_persist16_kernel(const LstmPersist16
     if (layer == 1) skip_next = skip_row[0];
     // layer 1: the operand of the projection of step t+1 (h0[t+1], written by the neighbouring XCD) is requested at the very end
     // of step t-1 (its registers are free once that step's projection has consumed them); it validates itself like every operand
+    // (round 4, measured and not kept: TWO sets, h0[t+2] requested in front of step t's barrier like layer 0's x, the time loop
+    //  unrolled by two -- 2.50 -> 2.54 us per step on the same box)
     bf16x8 ap[2][2];
     if (layer == 1) load_a(h0b, p.T > 1 ? 1 : 0, ap);
 
@@ -282,6 +287,7 @@ __global__ __launch_bounds__(512) void lstm_persist16_kernel(const LstmPersist16
     auto step = [&](int t) -> bool {
         if (trc && t >= 100 && t < 104) { trw[(t - 100) * 8 + 6] = 0; trw[(t - 100) * 8 + 7] = 0; }
         LP16_TRC(0);
+        if (trc && (t == 100 || t == 103)) trw[32 + (t == 103)] = __builtin_amdgcn_s_memtime();    // shader clock over three steps
         float gpre[4] = {bq[0], bq[1], bq[2], bq[3]};
         const float skipv = skip_next;
         if (live && layer == 0 && !FUSE) {
@@ -302,7 +308,18 @@ __global__ __launch_bounds__(512) void lstm_persist16_kernel(const LstmPersist16
             else mac(arec, wb, acc);
         }
         bool ap_ok = true;
-        if (fuse0) convert0();                                 // x[t+1] (requested at the end of the previous step) -> planes
+        if (fuse0) {
+            convert0();                                        // x[t+1] (requested a step ago) -> planes
+            // x[t+2] is requested HERE, in front of the barrier: its 32 KB per CU (as much as the exchange itself) then pass the CU's
+            // 64 B/clk load path under the partial sums, the barrier and the gate arithmetic, when nothing else wants it.  Issued
+            // behind the recurrent request in the projection (rounds 2-3) they shared the path with the peers' h: the projection
+            // took 0.9-1.0 us instead of the 0.5 us of its MFMAs and layer 0 -- not layer 1 -- bound the kernel at 16 live clips
+            // per group (2.5-2.8 us per step against 1.9 with one clip; profiles/r4_lstm_notes.md)
+            fetch0(t + 2 < p.T ? t + 2 : p.T - 1);
+        }
+        // (layer 1's skip value is waited for at the output store, behind the publish stores: s_waitcnt vmcnt(0), i.e. their acknowledgements
+        //  too.  Forcing its use HERE, where it has arrived, removes that wait; measured on one box, three alternating passes: 2.55 us per
+        //  step either way -- the stores are acknowledged by the XCD's L2 before the projection's first MFMAs are through)
         if (layer == 1) ap_ok = valid(ap) || (p.dbg & 4);      // h0[t+1] (requested at the end of the previous step) complete?
         LP16_TRC(2);
         float (&pt)[8][4][16][17] = part[t & 1];
