@@ -242,6 +242,255 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// attention16_kernel (round 4, head_dim 64): the same attention -- same grid, same key range, same mask, same online softmax --
+// with both products in split16.h arithmetic on v_mfma_f32_16x16x32_f16 (3 partial products per fp32 product, fp32 accumulate) and
+// NO score / probability tile in LDS.  attention_kernel spent 357 us per launch (Mimi 128 x 10 s, 16 launches per step) on chains of
+// 16 dependent fp32 MFMAs, one LDS word per PV MFMA, libm expf, and a global -> LDS -> barrier sequence per key tile with
+// nothing in flight behind it.  Here
+//   * both products are computed TRANSPOSED, the key-side matrix as the MFMA's A operand and the query-side one as B:
+//       S^T[key][query] = K Q^T,   O^T[dim][query] = V^T P^T
+//     so a lane owns ONE query (column li) in every accumulator: running maximum, sum, rescaling and the final division are
+//     lane-local (two shuffles across the four kq groups), and the S^T accumulators of two 16-key tiles ARE the B operand of
+//     a 32-key step of the second product -- the k order of a dot product is free as long as both operands use the same one
+//     (rvq16.h), so V^T is read from LDS in THAT order: keys 16 c0 + 4 kq + 0..3, then 16 c1 + 4 kq + 0..3;
+//   * Q is loaded straight into its B fragments (a lane's rotate_half partner is its own other k-step: dims d and d + 32);
+//   * K (after RoPE) and V^T of a 64-key tile are staged as fp16 hi / lo planes under one power-of-two scale each -- the tile's
+//     largest magnitude, found by a workgroup reduction (LDS atomic, three rotating words) -- and the NEXT tile's global loads
+//     are in flight while the current one is multiplied;
+//   * P in [0, 1] is split under the fixed scale 2^14; a tile's contribution is accumulated in its own scaled units and added
+//     to O^T with the exact factor 2^-14 / scale_V, so tiles with different V scales combine.
+// The error of a product is that of an fp32 FMA chain (split16.h); exp is v_exp_f32 after one multiply by log2(e) (ELU's
+// choice, tap_gemm.h).  Parity: tests/test_mimi_gpu_parity.py (tokens exact outside fp64 near-ties, features / waveform within tolerance).
+// ---------------------------------------------------------------------------------------------
+struct Attn16Cfg {
+    static constexpr int QT = 64, KT = 64, HD = 64, KP = 72;            // KP: fp16 per LDS row (64 + 8: 144-byte rows)
+    static constexpr int PLANE = 64 * KP;
+    static constexpr size_t lds_bytes = (size_t)4 * PLANE * 2 + 32;     // K hi / lo [key][dim], V^T hi / lo [dim][key], 6 amax words
+};
+
+// 8 fp32 (two quads) x scale -> the hi / lo fp16 fragments of one MFMA operand (split16.h: scaled value = hi + lo)
+__device__ __forceinline__ void split16_pack8(const f32x4 a, const f32x4 b, const float sc, f16x8& hi, f16x8& lo) {
+    const f32x4 s0 = a * sc, s1 = b * sc;                                // exact: sc is a power of two
+    const f16x4_t h0 = __builtin_convertvector(s0, f16x4_t), h1 = __builtin_convertvector(s1, f16x4_t);
+    const f16x4_t l0 = __builtin_convertvector(s0 - __builtin_convertvector(h0, f32x4), f16x4_t);
+    const f16x4_t l1 = __builtin_convertvector(s1 - __builtin_convertvector(h1, f32x4), f16x4_t);
+    hi = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+    lo = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+__global__ __launch_bounds__(256, 2) void attention16_kernel(const AttnParams p) {
+    using Cfg = Attn16Cfg;
+    constexpr int KT = Cfg::KT, HD = Cfg::HD, KP = Cfg::KP, PLANE = Cfg::PLANE;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    _Float16* Kp = reinterpret_cast<_Float16*>(smem);         // [2 planes][64 keys][KP]
+    _Float16* Vp = Kp + 2 * PLANE;                             // [2 planes][64 dims][KP]  (keys along the row)
+    unsigned* slot = reinterpret_cast<unsigned*>(Vp + 2 * PLANE);   // [3 rotating][K, V]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, kq = lane >> 4;
+    const int q0 = blockIdx.x * Cfg::QT, h = blockIdx.y, b = blockIdx.z;
+    const long long rs = 3LL * p.A;
+    const float* base = p.qkv + (long long)b * p.T * rs + (long long)h * HD;
+    if (tid < 6) slot[tid] = 0u;
+
+    // ---- Q^T fragments: lane (query li, kq) holds dims 8 kq .. + 7 (k-step 0) and 32 + 8 kq .. (k-step 1), RoPE in registers
+    const int qi = q0 + wave * 16 + li;
+    f16x8 qh[2], ql[2];
+    float iq;
+    {
+        f32x4 xa[2], xb[2], cv[2], sv[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            xa[u] = xb[u] = cv[u] = sv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (qi < p.T) {
+                const float* src = base + (long long)qi * rs + 8 * kq + 4 * u;
+                xa[u] = *reinterpret_cast<const f32x4*>(src);
+                xb[u] = *reinterpret_cast<const f32x4*>(src + HD / 2);
+                cv[u] = *reinterpret_cast<const f32x4*>(p.cos + (long long)qi * HD + 8 * kq + 4 * u);
+                sv[u] = *reinterpret_cast<const f32x4*>(p.sin + (long long)qi * HD + 8 * kq + 4 * u);
+            }
+        }
+        f32x4 ra[2], rb[2];                                    // x cos + rotate_half(x) sin  ([HF]:582-599), unfused like the reference
+        unsigned am = 0;
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                ra[u][e] = __fadd_rn(__fmul_rn(xa[u][e], cv[u][e]), __fmul_rn(-xb[u][e], sv[u][e]));
+                rb[u][e] = __fadd_rn(__fmul_rn(xb[u][e], cv[u][e]), __fmul_rn(xa[u][e], sv[u][e]));
+                amax_acc(am, ra[u][e]);
+                amax_acc(am, rb[u][e]);
+            }
+#pragma unroll
+        for (int sh = 1; sh < 64; sh <<= 1) {
+            const unsigned t = (unsigned)__shfl_xor((int)am, sh);
+            am = t > am ? t : am;
+        }
+        const int eq = s16_exponent(am);
+        iq = s16_pow2(-eq);
+        split16_pack8(ra[0], ra[1], s16_pow2(eq), qh[0], ql[0]);
+        split16_pack8(rb[0], rb[1], s16_pow2(eq), qh[1], ql[1]);
+    }
+
+    // ---- staging registers of one key tile: K as (dims 4 g .., 32 + 4 g ..) pairs of two rows per thread, V as a 4-key x 4-dim block
+    f32x4 kx0[2], kx1[2], kc[2], ksn[2], vv[4];
+    const int kg = tid >> 4, dg = tid & 15;
+    auto issue_loads = [&](int kb) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int e2 = tid + 256 * i, row = e2 >> 3, g = e2 & 7;
+            const int t = kb + row;
+            kx0[i] = kx1[i] = kc[i] = ksn[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (t < p.T) {
+                const float* src = base + (long long)t * rs + p.A + 4 * g;
+                kx0[i] = *reinterpret_cast<const f32x4*>(src);
+                kx1[i] = *reinterpret_cast<const f32x4*>(src + HD / 2);
+                kc[i] = *reinterpret_cast<const f32x4*>(p.cos + (long long)t * HD + 4 * g);
+                ksn[i] = *reinterpret_cast<const f32x4*>(p.sin + (long long)t * HD + 4 * g);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int t = kb + 4 * kg + r;
+            vv[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (t < p.T) vv[r] = *reinterpret_cast<const f32x4*>(base + (long long)t * rs + 2 * p.A + 4 * dg);
+        }
+    };
+
+    float m_run = -INFINITY, l_run = 0.f;
+    f32x4 o[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) o[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int k_lo = max(0, q0 - p.window + 1) / KT * KT;
+    const int k_hi = min(p.T, q0 + Cfg::QT);
+    issue_loads(k_lo);
+    __syncthreads();                                           // the amax words are zero
+    int jt = 0;
+    for (int kb = k_lo; kb < k_hi; kb += KT, ++jt) {
+        // ---- RoPE on K, the tile's two maxima
+        f32x4 klo[2], khi[2];
+        unsigned amk = 0, amv = 0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                klo[i][e] = __fadd_rn(__fmul_rn(kx0[i][e], kc[i][e]), __fmul_rn(-kx1[i][e], ksn[i][e]));
+                khi[i][e] = __fadd_rn(__fmul_rn(kx1[i][e], kc[i][e]), __fmul_rn(kx0[i][e], ksn[i][e]));
+                amax_acc(amk, klo[i][e]);
+                amax_acc(amk, khi[i][e]);
+            }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) amax_acc4(amv, vv[r]);
+#pragma unroll
+        for (int sh = 1; sh < 64; sh <<= 1) {
+            const unsigned t1 = (unsigned)__shfl_xor((int)amk, sh), t2 = (unsigned)__shfl_xor((int)amv, sh);
+            amk = t1 > amk ? t1 : amk;
+            amv = t2 > amv ? t2 : amv;
+        }
+        unsigned* sl = slot + (jt % 3) * 2;
+        if (lane == 0) { atomicMax(sl, amk); atomicMax(sl + 1, amv); }
+        __syncthreads();                                       // A: maxima complete; every wave is done with the previous tile's planes
+        if (tid < 2) slot[((jt + 1) % 3) * 2 + tid] = 0u;      // (next tile's words: last read before the previous tile's barrier B)
+        const int ek = s16_exponent(sl[0]), ev = s16_exponent(sl[1]);
+        const float sk = s16_pow2(ek), svs = s16_pow2(ev);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int e2 = tid + 256 * i, row = e2 >> 3, g = e2 & 7;
+            split16_store4s(klo[i], sk, Kp, PLANE, row * KP + 4 * g);
+            split16_store4s(khi[i], sk, Kp, PLANE, row * KP + HD / 2 + 4 * g);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)                            // V^T: four consecutive keys of one dim per 8-byte store
+            split16_store4s(f32x4{vv[0][u], vv[1][u], vv[2][u], vv[3][u]}, svs, Vp, PLANE, (4 * dg + u) * KP + 4 * kg);
+        if (kb + KT < k_hi) issue_loads(kb + KT);              // in flight during this tile's products
+        __syncthreads();                                       // B: planes visible
+
+        // ---- S^T = K Q^T: accumulator c, register r <-> key kb + 16 c + 4 kq + r, this lane's query
+        f32x4 s[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            s[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const f16x8 kh = *reinterpret_cast<const f16x8*>(Kp + (c * 16 + li) * KP + 32 * ks + 8 * kq);
+                const f16x8 kl = *reinterpret_cast<const f16x8*>(Kp + PLANE + (c * 16 + li) * KP + 32 * ks + 8 * kq);
+                s[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl, qh[ks], s[c], 0, 0, 0);
+                s[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, ql[ks], s[c], 0, 0, 0);
+                s[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, qh[ks], s[c], 0, 0, 0);
+            }
+        }
+        // ---- mask, online softmax (lane-local but for the four kq groups of the query)
+        const float ds = iq * s16_pow2(-ek) * p.scaling;
+        float mx = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = kb + c * 16 + kq * 4 + r;
+                const bool vis = j <= qi && qi - j < p.window && j < p.T;
+                const float v = vis ? s[c][r] * ds : -INFINITY;
+                s[c][r] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run, mx);
+        float alpha = 1.f, sum = 0.f;
+        if (m_new == -INFINITY) {                              // nothing visible yet for this query
+#pragma unroll
+            for (int c = 0; c < 4; ++c) s[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        } else {
+            alpha = __expf(m_run - m_new);                     // exp(-inf) = 0 on the first visible tile
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pv = __expf(s[c][r] - m_new);
+                    s[c][r] = pv;
+                    sum += pv;
+                }
+        }
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        l_run = l_run * alpha + sum;
+        m_run = m_new;
+        // ---- O^T += V^T P^T, the tile's contribution in its own units first
+        f32x4 tacc[4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) tacc[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            f16x8 ph, pl;
+            split16_pack8(s[2 * kk], s[2 * kk + 1], 16384.0f, ph, pl);
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const _Float16* vr = Vp + (d * 16 + li) * KP + 32 * kk + 4 * kq;
+                const f16x4_t vh0 = *reinterpret_cast<const f16x4_t*>(vr), vh1 = *reinterpret_cast<const f16x4_t*>(vr + 16);
+                const f16x4_t vl0 = *reinterpret_cast<const f16x4_t*>(vr + PLANE), vl1 = *reinterpret_cast<const f16x4_t*>(vr + PLANE + 16);
+                const f16x8 vh = __builtin_shufflevector(vh0, vh1, 0, 1, 2, 3, 4, 5, 6, 7);
+                const f16x8 vl = __builtin_shufflevector(vl0, vl1, 0, 1, 2, 3, 4, 5, 6, 7);
+                tacc[d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl, ph, tacc[d], 0, 0, 0);
+                tacc[d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, pl, tacc[d], 0, 0, 0);
+                tacc[d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, ph, tacc[d], 0, 0, 0);
+            }
+        }
+        const float dv = s16_pow2(-ev) * (1.0f / 16384.0f);
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[d][r] = __fmaf_rn(tacc[d][r], dv, o[d][r] * alpha);
+    }
+    // ---- normalise and store: this lane's query, dims 16 d + 4 kq .. + 3
+    if (qi < p.T) {
+        float* dst = p.out + ((long long)b * p.T + qi) * p.A + (long long)h * HD + 4 * kq;
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+            *reinterpret_cast<f32x4*>(dst + d * 16) = f32x4{o[d][0] / l_run, o[d][1] / l_run, o[d][2] / l_run, o[d][3] / l_run};
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Depthwise transposed conv (groups == channels), kernel 2*s, stride s, k - s samples trimmed on the right:
 //   y[i*s + ph][c] = x[i][c] * w[c][ph] + x[i-1][c] * w[c][ph + s]          (x[-1] = 0)
 // HBM-bound: 4*C*(1 + s) bytes per input frame.  One thread per (output step, 4 channels).

@@ -119,9 +119,12 @@ int attention_fwd(ac_handle* h, hipStream_t st, const float* qkv, float* out, in
     p.scaling = 1.0f / std::sqrt((float)c.head_dim);
     const dim3 grid(cdiv(T, 64), c.num_attention_heads, B);
     const double keys = std::min<double>(T, c.sliding_window);
-    ProfScope ps(h, st, "attention_kernel", 4.0 * B * c.num_attention_heads * (double)T * keys * c.head_dim * 0.5,
+    const bool a16 = c.head_dim == 64 && !h->gemm_fp32 && !h->dev.attn_exact && (p.A % 4) == 0;
+    ProfScope ps(h, st, a16 ? "attention16_kernel" : "attention_kernel", 4.0 * B * c.num_attention_heads * (double)T * keys * c.head_dim * 0.5,
                  16.0 * B * (double)T * p.A);
-    if (c.head_dim == 64) {
+    if (a16) {      // split16 products on the fp16 pipe (mimi.h)
+        hipLaunchKernelGGL(attention16_kernel, grid, dim3(256), Attn16Cfg::lds_bytes, st, p);
+    } else if (c.head_dim == 64) {
         if (int rc = ensure_lds(h, reinterpret_cast<const void*>(attention_kernel<64>), AttnCfg<64>::lds_bytes)) return rc;
         hipLaunchKernelGGL(attention_kernel<64>, grid, dim3(256), AttnCfg<64>::lds_bytes, st, p);
     } else if (c.head_dim == 32) {
