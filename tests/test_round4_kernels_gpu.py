@@ -1,0 +1,76 @@
+"""Round-4 kernels that REPLACE an older kernel with a different summation order -- attention16_kernel (csrc/mimi.h: Mimi attention
+in split16 arithmetic) and head4_kernel (csrc/thin.h: four lanes per output sample) -- against the kernels they replace, which
+stay selectable (ac_debug_set "attn_exact" / "head_seq").  The oracle parity of the default path is tests/test_mimi_gpu_parity.py /
+test_dac_gpu_parity.py; here the two implementations of one layer are compared with each other over the sizes where they differ in
+structure: one transformer frame, the 64-query / 64-key tile edges, more frames than the sliding window (250), ragged batches."""
+import pytest
+import torch
+
+from golden_cases import noise
+
+pytestmark = pytest.mark.gpu
+
+
+def _codec(name):
+    import bench
+
+    return bench.build_codec(name)[0]
+
+
+def _kernels(codec, fn):
+    return {s[0].split("<")[0] for s in codec.profile_kernels(fn)}
+
+
+# Mimi: 1920 samples per 12.5 Hz frame, the transformers run at 25 Hz: T25 = 2 * frames.  32 / 33 frames = 64 / 66 positions (tile edge),
+# 130 frames = 260 positions (> window 250: the first key tile of the last query tile is partly masked), 163 frames = 326 positions.
+@pytest.mark.parametrize("B,frames", [(1, 1), (2, 32), (3, 33), (2, 130), (1, 163)])
+def test_attention16_matches_the_fp32_mfma_attention(B, frames):
+    from audiocodecs_amd._native import debug_set
+
+    codec = _codec("mimi")
+    sig = noise(9100 + frames, B, 1920 * frames).cuda()
+    with torch.no_grad():
+        codec.sig_to_toks(sig[:1])
+        debug_set(codec, "attn_exact", 1)
+        assert "attention16_kernel" not in _kernels(codec, lambda: codec.sig_to_feats(sig))
+        f_ref = codec.sig_to_feats(sig)
+        r_ref = codec.toks_to_sig(codec.sig_to_toks(sig))
+        debug_set(codec, "attn_exact", 0)
+        assert "attention16_kernel" in _kernels(codec, lambda: codec.sig_to_feats(sig))
+        f_new = codec.sig_to_feats(sig)
+        t_new = codec.sig_to_toks(sig)
+        r_new = codec.toks_to_sig(t_new)
+        again = codec.sig_to_feats(sig)
+    assert torch.equal(f_new, again)                                   # deterministic (no atomics in the data path: the amax words are maxima)
+    scale = float(f_ref.abs().max())
+    assert float((f_new - f_ref).abs().max()) <= 2e-5 * scale, (float((f_new - f_ref).abs().max()), scale)
+    assert torch.isfinite(r_new).all()
+    # the waveform goes through a token decision: compare where the tokens agree (they do outside near-ties)
+    debug_set(codec, "attn_exact", 1)
+    with torch.no_grad():
+        t_ref = codec.sig_to_toks(sig)
+    debug_set(codec, "attn_exact", 0)
+    agree = float((t_ref == t_new).float().mean())
+    assert agree >= 0.97, agree
+    if agree == 1.0:
+        assert float((r_new - r_ref).abs().max()) <= 2e-4 * max(float(r_ref.abs().max()), 1e-3)
+
+
+@pytest.mark.parametrize("name,B,T", [("mimi", 2, 1920 * 3 + 5), ("mimi", 1, 1920), ("dac", 2, 5000), ("dac", 1, 700)])
+def test_head4_matches_the_sequential_head(name, B, T):
+    from audiocodecs_amd._native import debug_set
+
+    codec = _codec(name)
+    sig = noise(9300 + T, B, T).cuda()
+    with torch.no_grad():
+        toks = codec.sig_to_toks(sig)
+        debug_set(codec, "head_seq", 1)
+        assert "head4_kernel" not in _kernels(codec, lambda: codec.toks_to_sig(toks))
+        ref = codec.toks_to_sig(toks)
+        debug_set(codec, "head_seq", 0)
+        assert "head4_kernel" in _kernels(codec, lambda: codec.toks_to_sig(toks))
+        new = codec.toks_to_sig(toks)
+        assert torch.equal(new, codec.toks_to_sig(toks))
+    assert new.shape == ref.shape
+    # one fp32 dot product of 7 F (3 F) terms per sample in two summation orders
+    assert float((new - ref).abs().max()) <= 4e-6 * max(float(ref.abs().max()), 1.0), float((new - ref).abs().max())
