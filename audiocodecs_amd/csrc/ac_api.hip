@@ -82,6 +82,7 @@ static void latch_dev_switches(ac_handle* h) {
     h->dev.prof_detail = num("AC_PROF_DETAIL", 0);
     h->dev.head_seq = num("AC_HEAD_SEQ", 0);
     h->dev.attn_exact = num("AC_ATTN_EXACT", 0);
+    h->dev.dac_unit = num("AC_DAC_UNIT", 1);
 }
 
 int ac_debug_set(ac_handle* h, const char* key, int value) {
@@ -89,7 +90,7 @@ int ac_debug_set(ac_handle* h, const char* key, int value) {
     struct { const char* k; int* v; } tab[] = {
         {"tap_epi_staged", &h->dev.tap_epi_staged}, {"tap_dil", &h->dev.tap_dil}, {"tap_stagger", &h->dev.tap_stagger}, {"tap_pick", &h->dev.tap_pick}, {"tap8", &h->dev.tap8}, {"tap8_form", &h->dev.tap8_form},
         {"rb6_dbg", &h->dev.rb6_dbg}, {"front_seg", &h->dev.front_seg}, {"tail_seg", &h->dev.tail_seg}, {"front_ldspad", &h->dev.front_ldspad},
-        {"lstm_dbg", &h->dev.lstm_dbg}, {"lstm_fuse_in", &h->dev.lstm_fuse_in}, {"rvq_exact", &h->dev.rvq_exact}, {"prof_detail", &h->dev.prof_detail}, {"head_seq", &h->dev.head_seq}, {"attn_exact", &h->dev.attn_exact},
+        {"lstm_dbg", &h->dev.lstm_dbg}, {"lstm_fuse_in", &h->dev.lstm_fuse_in}, {"rvq_exact", &h->dev.rvq_exact}, {"prof_detail", &h->dev.prof_detail}, {"head_seq", &h->dev.head_seq}, {"attn_exact", &h->dev.attn_exact}, {"dac_unit", &h->dev.dac_unit},
     };
     for (auto& t : tab)
         if (std::strcmp(t.k, key) == 0) { *t.v = value; return AC_OK; }

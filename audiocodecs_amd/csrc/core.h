@@ -185,6 +185,7 @@ struct ac_handle {
         int rvq_exact = 0;          // AC_RVQ=fp32         : exact-product codebook search
         int prof_detail = 0;        // AC_PROF_DETAIL=1    : one profile record per tap-GEMM shape
         int attn_exact = 0;         // AC_ATTN_EXACT=1     : Mimi attention on the fp32 MFMA (attention_kernel) instead of attention16_kernel
+        int dac_unit = 1;           // AC_DAC_UNIT=0       : DAC's 96-channel residual units as two tap-GEMM launches instead of dac_unit6_kernel
         int head_seq = 0;           // AC_HEAD_SEQ=1       : the one-thread-per-sample head kernel (A/B against head4_kernel)
     } dev;
     bool fuse_chains = true;        // AC_FUSE=0 at ac_finalize: the layers of the fused chains as separate kernels (A/B runs, cross-check tests)

@@ -14,6 +14,7 @@
 // epilogue, the padded transposed conv writes shifted rows with a range mask.
 #include "core.h"
 #include "dac.h"
+#include "dac_unit6.h"
 
 namespace acimpl {
 
@@ -94,9 +95,90 @@ int dac_convtr(ac_handle* h, hipStream_t st, const PackedGemm& g, const Act& x, 
     return rc;
 }
 
+// the 96-channel ResidualUnit as ONE kernel (dac_unit6.h); returns false when the shape, the alignment or the arithmetic mode
+// asks for the two tap-GEMM launches (then nothing was launched)
+bool dac_unit_fused(ac_handle* h, hipStream_t st, const DacResUnitPlan& ru, int C, const Act2& x, Out out, SnakeP next, int B, Act2* y, int* rc_out) {
+    *rc_out = AC_OK;
+    // (96 channels only: measured per unit, 32 clips -- 14.5 -> 13.9 ms; the 64-channel units LOSE, 6.9 -> 8.7 ms: their two-launch path runs
+    //  64 x 32 wave tiles at three workgroups per CU, the wave-local second product needs 32 x 64 ones; profiles/r4_variants.md.
+    //  The developer switches that select a tap-GEMM code path -- slab reload per tap, staged epilogue -- mean the tap-GEMM.)
+    if (h->gemm_fp32 || h->dbg || h->dev.dac_unit == 0 || h->dev.tap_dil == 0 || h->dev.tap_epi_staged != 0 || C != 96 || ru.c7.N != C || ru.c1.N != C || ru.c1.Ktot != C || ru.c7.Ktot != 7 * C) return false;
+    if (!ru.c7.has_bias || !ru.c1.has_bias || !out.elu || !next.a || next.n < C) return false;
+    auto w1 = h->w6_of.find(ru.c7.w_off), w2 = h->w6_of.find(ru.c1.w_off);
+    auto i1 = h->winv_of.find(ru.c7.w_off), i2 = h->winv_of.find(ru.c1.w_off);
+    if (w1 == h->w6_of.end() || w2 == h->w6_of.end() || i1 == h->winv_of.end() || i2 == h->winv_of.end()) return false;
+    const Act& xe = x.elu;
+    const Act& xr = x.raw;
+    const int dil = ru.dil, L = xe.L;
+    if (!xe.p || !xr.p || xe.ts != C || xr.ts != C || xe.C != C || L < 1 || 6 * dil > T6_DIL_HALO || !aligned16(xe.p) || !aligned16(xr.p) || !aligned16(out.elu) ||
+        (out.raw && !aligned16(out.raw)) || (xe.bs % 4) || (xr.bs % 4) || (long long)L * C * 4 >= 0x7fffffffLL)
+        return false;
+    DacUnitParams q{};
+    TapGemmParams& p = q.g;
+    p.nseg = 1;
+    p.seg[0] = make_seg(xe, 1, 7, PAD_ZERO, 0, 0, nullptr);
+    p.seg[0].pad = 3 * dil;
+    p.seg[0].dil = dil;
+    p.seg[0].amax = amax_of(h, st, xe.p, xe.bs, xe.ts, xe.L, xe.C, B, xe.amax_n == B ? xe.amax : nullptr);
+    if (!p.seg[0].amax) { *rc_out = fail(h, AC_ESTATE, "out of amax slots (split16.h)"); return true; }
+    p.w = h->blob + ru.c7.w_off;
+    p.bias = h->blob + ru.c7.b_off;
+    p.winv = h->blob + i1->second;
+    p.y = out.raw;
+    p.y_elu = out.elu;
+    p.y_bs = (long long)L * C;
+    p.y_rs = C;
+    p.B = B;
+    p.M = L;                                    // "same" padding: 3 dil each side of a k7 conv with dilation dil
+    p.N = C;
+    p.Ktot = 7 * C;
+    p.res = xr.p;
+    p.res_bs = xr.bs;
+    p.res_rs = xr.ts;
+    p.alpha = next.a;
+    p.alpha_inv = next.ai;
+    p.alpha_n = next.n;
+    p.amax_out = amax_new(h);
+    if (!p.amax_out) { *rc_out = fail(h, AC_ESTATE, "out of amax slots (split16.h)"); return true; }
+    p.epi_direct = 1;
+    p.mtiles = cdiv(L, 128);
+    p.ntiles = 1;
+    p.stagger = 0;
+    p.clk = nullptr;
+    q.a_mid = h->blob + ru.a2;
+    q.a_mid_inv = h->blob + ru.a2i;
+    q.bias2 = h->blob + ru.c1.b_off;
+    q.winv2 = h->blob + i2->second;
+    const __bf16* wp1 = reinterpret_cast<const __bf16*>(h->blob + w1->second);
+    const __bf16* wp2 = reinterpret_cast<const __bf16*>(h->blob + w2->second);
+    const long long blocks = (long long)B * p.mtiles;
+    const double flops = 2.0 * B * (double)L * C * (7.0 * C + C);
+    const double bytes = (double)B * L * C * 4.0 * (2 + (out.raw ? 1 : 0) + 1);
+#define DAC_UNIT_LAUNCH(WN, HALO, NAME)                                                                                              \
+    do {                                                                                                                            \
+        const size_t lds = DacUnitCfg<WN>::lds_bytes<HALO>();                                                                       \
+        if ((*rc_out = ensure_lds(h, reinterpret_cast<const void*>(dac_unit6_kernel<WN, HALO>), lds))) return true;                \
+        ProfScope ps(h, st, NAME, flops, bytes);                                                                                   \
+        hipLaunchKernelGGL((dac_unit6_kernel<WN, HALO>), dim3((unsigned)blocks), dim3(256), lds, st, q, wp1, wp2);                  \
+    } while (0)
+    if (dil == 1) DAC_UNIT_LAUNCH(3, 7, "dac_unit6_kernel<3>"); else DAC_UNIT_LAUNCH(3, T6_DIL_HALO, "dac_unit6_kernel<3, dil>");
+#undef DAC_UNIT_LAUNCH
+    if (hipGetLastError() != hipSuccess) { *rc_out = fail(h, AC_ESTATE, "dac_unit6 launch failed"); return true; }
+    y->raw = Act{out.raw, p.y_bs, C, L, C, p.amax_out, B};
+    y->elu = Act{out.elu, p.y_bs, C, L, C, p.amax_out, B};
+    return true;
+}
+
 // one ResidualUnit; `next`: Snake of whatever consumes the unit's output; `want_raw`: the next layer is another unit
 int dac_res_unit(ac_handle* h, hipStream_t st, const DacResUnitPlan& ru, int C, const Act2& x, WsPtrs& ws, SnakeP next, bool want_raw, int B,
                  Act2* y) {
+    {
+        Out o{want_raw ? ws.take() : nullptr, ws.take()};
+        int rc = AC_OK;
+        if (dac_unit_fused(h, st, ru, C, x, o, next, B, y, &rc)) return rc;
+        if (o.raw) ws.give(o.raw);
+        ws.give(o.elu);
+    }
     float* hb = ws.take();
     Act2 hv;
     int rc = dac_conv(h, st, ru.c7, x.elu, 7, 1, ru.dil, 3 * ru.dil, Out{nullptr, hb}, dac_snake(h, ru.a2, ru.a2i, C), B, &hv);

@@ -343,9 +343,21 @@ __device__ __forceinline__ void tap6_epilogue(const TapGemmParams& p, f32x16 (&a
     }
 }
 
-template <int WGM, int WGN, int WMT, int WN, int NP = 2, int HALO = 7>
-__global__ __launch_bounds__(64 * WGM * WGN, (tap6_occupancy<WGM, WGN, WMT, WN, NP>())) void tap_gemm6_kernel(const TapGemmParams p, const __bf16* __restrict__ wp) {
-    static_assert(NP == 2, "split16 arithmetic only");
+// what the main loop hands to the epilogue of its tile
+struct Tap6Tile {
+    int b, m0, n0;
+    float a_inv;
+    bool rowmode;
+    unsigned long long clk_t0, clk_r0;
+    bool t6_ph;
+};
+
+// ---- the main loop of a tile (prologue, K loop): tap_gemm6_kernel = this + tap6_epilogue; dac_unit6_kernel (dac_unit6.h) = this with
+// SWAP + a second product + tap6_epilogue.  SWAP: the MFMA's operands exchanged -- the accumulators hold the TRANSPOSED 32 x 32 tiles
+// (lane = row of the tile, register r = column 8 (r / 4) + 4 kh + r % 4), same products, same order.
+template <int WGM, int WGN, int WMT, int WN, int HALO, bool SWAP>
+__device__ __forceinline__ void tap6_mainloop(const TapGemmParams& p, const __bf16* __restrict__ wp, float* smem, f32x16 (&acc)[WMT][WN], Tap6Tile& tl) {
+    constexpr int NP = 2;
     using Cfg = Tap6Cfg<WGM, WGN, WMT, WN, HALO>;
     constexpr int BM = Cfg::BM, BN = Cfg::BN, NT = Cfg::NT, A_SLOTS = Cfg::A_SLOTS, PLANE = Cfg::PLANE;
     unsigned long long clk_t0 = 0, clk_r0 = 0;
@@ -355,7 +367,6 @@ __global__ __launch_bounds__(64 * WGM * WGN, (tap6_occupancy<WGM, WGN, WMT, WN, 
         const unsigned long long t0 = __builtin_amdgcn_s_memtime();
         while (__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(32);
     }
-    extern __shared__ __attribute__((aligned(16))) float smem[];
     __bf16* As0 = reinterpret_cast<__bf16*>(smem);            // [2 buffers][NPL planes][A_ROWS][T6_PITCH]
     constexpr int NPL = 2;
 
@@ -379,7 +390,6 @@ __global__ __launch_bounds__(64 * WGM * WGN, (tap6_occupancy<WGM, WGN, WMT, WN, 
     T6_PHASE(1);
 #endif
 
-    f32x16 acc[WMT][WN];
 #pragma unroll
     for (int a = 0; a < WMT; ++a)
 #pragma unroll
@@ -550,9 +560,15 @@ __global__ __launch_bounds__(64 * WGM * WGN, (tap6_occupancy<WGM, WGN, WMT, WN, 
             for (int c = 0; c < WN; ++c) {
                 f32x16 v = acc[a][c];
                 // lo hi, hi lo, hi hi (small terms first)
+                if constexpr (SWAP) {
+                    v = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, bf[0][c]), __builtin_bit_cast(f16x8, af[1][a]), v, 0, 0, 0);
+                    v = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, bf[1][c]), __builtin_bit_cast(f16x8, af[0][a]), v, 0, 0, 0);
+                    acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, bf[0][c]), __builtin_bit_cast(f16x8, af[0][a]), v, 0, 0, 0);
+                } else {
                 v = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[1][a]), __builtin_bit_cast(f16x8, bf[0][c]), v, 0, 0, 0);
                 v = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[0][a]), __builtin_bit_cast(f16x8, bf[1][c]), v, 0, 0, 0);
                 acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[0][a]), __builtin_bit_cast(f16x8, bf[0][c]), v, 0, 0, 0);
+                }
             }
     };
 #ifdef T6_TRACE
@@ -668,13 +684,22 @@ __global__ __launch_bounds__(64 * WGM * WGN, (tap6_occupancy<WGM, WGN, WMT, WN, 
         }
     }
 
-    tap6_epilogue<WGM, WGN, WMT, WN, HALO>(p, acc, smem, b, m0, n0, a_inv, rowmode, clk_t0, clk_r0,
+    tl.b = b; tl.m0 = m0; tl.n0 = n0; tl.a_inv = a_inv; tl.rowmode = rowmode; tl.clk_t0 = clk_t0; tl.clk_r0 = clk_r0;
 #ifdef T6_TRACE
-                                            t6_ph
+    tl.t6_ph = t6_ph;
 #else
-                                            false
+    tl.t6_ph = false;
 #endif
-                                            );
+}
+
+template <int WGM, int WGN, int WMT, int WN, int NP = 2, int HALO = 7>
+__global__ __launch_bounds__(64 * WGM * WGN, (tap6_occupancy<WGM, WGN, WMT, WN, NP>())) void tap_gemm6_kernel(const TapGemmParams p, const __bf16* __restrict__ wp) {
+    static_assert(NP == 2, "split16 arithmetic only");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    f32x16 acc[WMT][WN];
+    Tap6Tile tl;
+    tap6_mainloop<WGM, WGN, WMT, WN, HALO, false>(p, wp, smem, acc, tl);
+    tap6_epilogue<WGM, WGN, WMT, WN, HALO>(p, acc, smem, tl.b, tl.m0, tl.n0, tl.a_inv, tl.rowmode, tl.clk_t0, tl.clk_r0, tl.t6_ph);
 }
 
 }  // namespace ac

@@ -74,3 +74,28 @@ def test_head4_matches_the_sequential_head(name, B, T):
     assert new.shape == ref.shape
     # one fp32 dot product of 7 F (3 F) terms per sample in two summation orders
     assert float((new - ref).abs().max()) <= 4e-6 * max(float(ref.abs().max()), 1.0), float((new - ref).abs().max())
+
+
+@pytest.mark.parametrize("B,T", [(2, 9000), (1, 700), (3, 4099)])
+def test_dac_unit6_matches_the_two_launch_residual_unit(B, T, dac_checkpoints):
+    """dac_unit6_kernel (csrc/dac_unit6.h: k7 conv -> Snake -> 1 x 1 conv + residual of the 96-channel units as one kernel, the hidden
+    activation scaled per wave tile instead of per clip) against the two tap-GEMM launches it replaces (ac_debug_set "dac_unit" 0): same
+    tokens (the units are in the decoder), waveform equal to fp32 rounding; clip edges inside the dilated halo (T = 700)."""
+    from audiocodecs_amd import DAC
+    from audiocodecs_amd._native import debug_set
+
+    cfg, sd = dac_checkpoints("full", 0)
+    codec = DAC(44100, 44100, num_codebooks=9, state_dict=sd, config=cfg).eval()
+    sig = noise(9500 + T, B, T).cuda()
+    with torch.no_grad():
+        toks = codec.sig_to_toks(sig)
+        debug_set(codec, "dac_unit", 0)
+        assert not any(n.startswith("dac_unit6") for n in _kernels(codec, lambda: codec.toks_to_sig(toks)))
+        ref = codec.toks_to_sig(toks)
+        debug_set(codec, "dac_unit", 1)
+        names = _kernels(codec, lambda: codec.toks_to_sig(toks))
+        assert "dac_unit6_kernel" in names, names
+        new = codec.toks_to_sig(toks)
+        assert torch.equal(new, codec.toks_to_sig(toks))
+        assert torch.equal(codec.sig_to_toks(sig), toks)
+    assert float((new - ref).abs().max()) <= 2e-5 * max(float(ref.abs().max()), 1e-3), float((new - ref).abs().max())
