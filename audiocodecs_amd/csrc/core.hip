@@ -361,6 +361,12 @@ int run_tap(ac_handle* h, hipStream_t st, TapGemmParams& p) {
                     form = 2;
                     model = kk >= 3072 && fill8(256, 128) >= 0.70;
                 }
+                // tiny launches (the batch-1 / batch-8 regime: at most 64 tiles of 128 x 128): every workgroup has a CU of its own and walks its K
+                // loop at one memory round trip per stage -- the ring's deeper look-ahead is what counts (1.39 -> 1.34 ms per 1 s call)
+                if ((double)p.B * cdiv(p.M, 128) * (p.N / 128) <= 64.0) {
+                    form = p.N % 256 == 0 ? 3 : 2;
+                    model = true;
+                }
                 if (h->dev.tap8_form >= 1 && h->dev.tap8_form <= 3 && (h->dev.tap8_form == 2 || p.N % 256 == 0)) form = h->dev.tap8_form;
                 use8 = want8 >= 1 || model;
                 if (use8) {

@@ -7,10 +7,15 @@ os.environ["AC_PROF_DETAIL"] = "1"
 import bench
 from audiocodecs_amd import prng
 codec, cfg, sd = bench.build_codec("encodec")
+from audiocodecs_amd._native import debug_set
+TAP8 = [int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("tap8=")]
+sys.argv = [a for a in sys.argv if not a.startswith("tap8=")]
 for B, sec in [(int(a.split("x")[0]), float(a.split("x")[1])) for a in sys.argv[1:]] or [(1, 1.0), (1, 10.0)]:
     T = int(round(sec * cfg.sampling_rate))
     sig = torch.from_numpy((prng.normal(123, "bench.sig.lat", (B, T)) * 0.1).astype(np.float32)).cuda()
     with torch.no_grad():
+        codec.sig_to_toks(sig)
+        if TAP8: debug_set(codec, "tap8", TAP8[0])
         for _ in range(3): codec.toks_to_sig(codec.sig_to_toks(sig))
         torch.cuda.synchronize()
         import time
