@@ -17,11 +17,16 @@ HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -fno-strict-aliasing -fPIC -Wall -Wno-unused-function -I"$here/../../include" "$@")
 mkdir -p "$obj"
 pids=()
+# -save-temps=obj: the device assembly of every translation unit stays beside its object for tools/mfma_branch_hazard.py (below)
 for tu in core mimi_path dac_path wavtok_path ac_api; do
-    "$HIPCC" "${FLAGS[@]}" -c "$here/$tu.hip" -o "$obj/$tu.o" &
+    "$HIPCC" "${FLAGS[@]}" -save-temps=obj -c "$here/$tu.hip" -o "$obj/$tu.o" &
     pids+=($!)
 done
 for p in "${pids[@]}"; do wait "$p"; done
 "$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$out" "$obj"/core.o "$obj"/mimi_path.o "$obj"/dac_path.o "$obj"/wavtok_path.o "$obj"/ac_api.o
 echo "built $out"
 bash "$here/check_isa.sh" "$out"
+# Round 4: hipcc's hazard recogniser left an MFMA -> taken branch -> v_accvgpr_read of the MFMA's result without wait states in one
+# version of rvq16.h's tile loop (run-to-run different tokens; profiles/r4_variants.md).  The scan fails the build if any kernel
+# reads an MFMA result across a branch closer than the matrix pipe needs.
+python3 "$here/../../tools/mfma_branch_hazard.py" "$obj"/*-hip-amdgcn-amd-amdhsa-gfx950.s | tail -1

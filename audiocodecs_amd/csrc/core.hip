@@ -1148,6 +1148,7 @@ int rvq_encode_fwd(ac_handle* h, hipStream_t st, const float* feats, int F, int 
                      (double)F * p.H * 4 + (double)F * K * 8 + (double)K * p.C * p.H * 4);
         if (HV == 32) hipLaunchKernelGGL((rvq_encode16_kernel<32, 1, false, true>), dim3(cdiv(F, 16)), block, 0, st, q);      // WavTokenizer: 4096 x 512, one stage
         else if (MS == 3) hipLaunchKernelGGL((rvq_encode16_kernel<8, 3, false>), grid, block, 0, st, q);
+        else if (F <= 4096 && p.C % 128 == 0) hipLaunchKernelGGL((rvq_encode16_kernel<8, 1, false, false, 4>), grid, dim3(256), 0, st, q);   // few frame groups: four waves share each (rvq16.h WS)
         else hipLaunchKernelGGL((rvq_encode16_kernel<8, 1, false>), grid, block, 0, st, q);
         HIPCHK(h, hipGetLastError());
         return AC_OK;

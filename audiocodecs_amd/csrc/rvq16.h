@@ -29,12 +29,19 @@ struct RvqEnc16Params {
 
 // K1: a single stage (WavTokenizer: one codebook of 4096 x 512) -- no residual update, so the 128 registers of the fp32 row are free once
 // its planes are built and the code tiles can stay double-buffered at H = 512
-template <int HV, int MS, bool CDIST, bool K1 = false>
-__global__ __launch_bounds__(64) void rvq_encode16_kernel(const RvqEnc16Params q) {
+// WS (round 4): waves per frame group -- the batch-1 regime has 5 - 47 frame groups for 1024 SIMDs and a wave walks 8 stages x 64
+// code tiles at one L2 round trip per tile (0.17 ms of a 1.3 ms call): WS = 4 waves take every fourth tile each and combine their
+// (best, first index) through LDS once per stage; every wave keeps the whole residual.  Same distances, same first-index rule.
+template <int HV, int MS, bool CDIST, bool K1 = false, int WS = 1>
+__global__ __launch_bounds__(64 * WS) void rvq_encode16_kernel(const RvqEnc16Params q) {
     static_assert(HV % 2 == 0, "k-steps of 32 dims");
+    static_assert(WS == 1 || (MS == 1 && !K1), "the shared form is the small-batch form");
     constexpr int KS = HV / 2;
     const RvqEncParams& p = q.base;
     const int lane = threadIdx.x & 63;
+    const int wv = WS == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    __shared__ float sbest[WS == 1 ? 1 : 2][WS][16];
+    __shared__ int sidx[WS == 1 ? 1 : 2][WS][16];
     const int li = lane & 15, kq = lane >> 4;
     const int f0 = blockIdx.x * (16 * MS);
     const int H = p.H;
@@ -131,7 +138,27 @@ __global__ __launch_bounds__(64) void rvq_encode16_kernel(const RvqEnc16Params q
                     if (d > best[m][r]) { best[m][r] = d; bidx[m][r] = code; }
                 }
         };
-        if constexpr (HV <= 16 || K1) {    // code tiles double-buffered in registers: tile ct + 1 travels under tile ct's MFMAs
+        if constexpr (WS > 1) {            // this wave's share: tiles wv, wv + WS, ... (double-buffered like below)
+            f16x8 bh0[KS], bl0[KS], bh1[KS], bl1[KS];
+            float ee0, ee1 = 0.f;
+            // (C % (32 WS) == 0: every wave has an even number of tiles; the look-ahead past the end re-reads the wave's last tile)
+            load_tile(wv, bh0, bl0, ee0);
+#ifdef RVQ16_COND_LOADS   // the first version: look-ahead loads under conditions -- run-to-run different tokens (profiles/r4_variants.md)
+            for (int ct = wv; ct < ctiles; ct += 2 * WS) {
+                if (ct + WS < ctiles) load_tile(ct + WS, bh1, bl1, ee1);
+                run_tile(ct, bh0, bl0, ee0);
+                if (ct + 2 * WS < ctiles) load_tile(ct + 2 * WS, bh0, bl0, ee0);
+                if (ct + WS < ctiles) run_tile(ct + WS, bh1, bl1, ee1);
+            }
+#else
+            for (int ct = wv; ct < ctiles; ct += 2 * WS) {
+                load_tile(ct + WS, bh1, bl1, ee1);
+                run_tile(ct, bh0, bl0, ee0);
+                load_tile(ct + 2 * WS < ctiles ? ct + 2 * WS : ct + WS, bh0, bl0, ee0);
+                run_tile(ct + WS, bh1, bl1, ee1);
+            }
+#endif
+        } else if constexpr (HV <= 16 || K1) {    // code tiles double-buffered in registers: tile ct + 1 travels under tile ct's MFMAs
             f16x8 bh0[KS], bl0[KS], bh1[KS], bl1[KS];
             float ee0, ee1 = 0.f;
             load_tile(0, bh0, bl0, ee0);
@@ -160,7 +187,25 @@ __global__ __launch_bounds__(64) void rvq_encode16_kernel(const RvqEnc16Params q
                     if (ob > best[m][r] || (ob == best[m][r] && oi < bidx[m][r])) { best[m][r] = ob; bidx[m][r] = oi; }
                 }
             }
-            if (li == 0) {
+            if constexpr (WS > 1) {            // the waves' shares meet: larger distance value wins, equal values go to the lower index
+                if (li == 0) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { sbest[k & 1][wv][kq * 4 + r] = best[m][r]; sidx[k & 1][wv][kq * 4 + r] = bidx[m][r]; }
+                }
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    best[m][r] = sbest[k & 1][0][kq * 4 + r];
+                    bidx[m][r] = sidx[k & 1][0][kq * 4 + r];
+#pragma unroll
+                    for (int w2 = 1; w2 < WS; ++w2) {
+                        const float ob = sbest[k & 1][w2][kq * 4 + r];
+                        const int oi = sidx[k & 1][w2][kq * 4 + r];
+                        if (ob > best[m][r] || (ob == best[m][r] && oi < bidx[m][r])) { best[m][r] = ob; bidx[m][r] = oi; }
+                    }
+                }
+            }
+            if (li == 0 && wv == 0) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int f = f0 + m * 16 + kq * 4 + r;
