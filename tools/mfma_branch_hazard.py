@@ -35,7 +35,7 @@ def scan(path):
             label_at[s[:-1]] = len(instrs)
             continue
         instrs.append((s, kernel))
-    found = []
+    found, seen = [], set()
     for i, (s, k) in enumerate(instrs):
         if not s.startswith("v_mfma"): continue
         dst = regs(s.split()[1].rstrip(","))
@@ -62,7 +62,9 @@ def scan(path):
                     if u.startswith("v_mfma") and len(ops) > 4 and regs(ops[4]) & dst and not any(regs(o) & dst for o in ops[2:4]):
                         break                                             # accumulation (srcC = the result): forwarded in hardware
                     if u.startswith("v_") and len(ops) > 2 and any(regs(o.lstrip("-|").rstrip("|")) & dst for o in ops[2:]):
-                        found.append((k, s, t, u, slots))
+                        if (i, q) not in seen:
+                            seen.add((i, q))
+                            found.append((k, s, t, u, slots))
                         break
                     if u.startswith("v_mfma") and any(regs(o) & dst for o in ops[1:2]): break     # overwritten by the next MFMA chain
                     slots += passes(ops[0]) if u.startswith("v_mfma") else 1
