@@ -83,6 +83,7 @@ static void latch_dev_switches(ac_handle* h) {
     h->dev.head_seq = num("AC_HEAD_SEQ", 0);
     h->dev.attn_exact = num("AC_ATTN_EXACT", 0);
     h->dev.dac_unit = num("AC_DAC_UNIT", 1);
+    h->dev.mimi_tail = num("AC_MIMI_TAIL", 1);
 }
 
 int ac_debug_set(ac_handle* h, const char* key, int value) {
@@ -90,7 +91,7 @@ int ac_debug_set(ac_handle* h, const char* key, int value) {
     struct { const char* k; int* v; } tab[] = {
         {"tap_epi_staged", &h->dev.tap_epi_staged}, {"tap_dil", &h->dev.tap_dil}, {"tap_stagger", &h->dev.tap_stagger}, {"tap_pick", &h->dev.tap_pick}, {"tap8", &h->dev.tap8}, {"tap8_form", &h->dev.tap8_form},
         {"rb6_dbg", &h->dev.rb6_dbg}, {"front_seg", &h->dev.front_seg}, {"tail_seg", &h->dev.tail_seg}, {"front_ldspad", &h->dev.front_ldspad},
-        {"lstm_dbg", &h->dev.lstm_dbg}, {"lstm_fuse_in", &h->dev.lstm_fuse_in}, {"rvq_exact", &h->dev.rvq_exact}, {"prof_detail", &h->dev.prof_detail}, {"head_seq", &h->dev.head_seq}, {"attn_exact", &h->dev.attn_exact}, {"dac_unit", &h->dev.dac_unit},
+        {"lstm_dbg", &h->dev.lstm_dbg}, {"lstm_fuse_in", &h->dev.lstm_fuse_in}, {"rvq_exact", &h->dev.rvq_exact}, {"prof_detail", &h->dev.prof_detail}, {"head_seq", &h->dev.head_seq}, {"attn_exact", &h->dev.attn_exact}, {"dac_unit", &h->dev.dac_unit}, {"mimi_tail", &h->dev.mimi_tail},
     };
     for (auto& t : tab)
         if (std::strcmp(t.k, key) == 0) { *t.v = value; return AC_OK; }

@@ -186,6 +186,7 @@ struct ac_handle {
         int prof_detail = 0;        // AC_PROF_DETAIL=1    : one profile record per tap-GEMM shape
         int attn_exact = 0;         // AC_ATTN_EXACT=1     : Mimi attention on the fp32 MFMA (attention_kernel) instead of attention16_kernel
         int dac_unit = 1;           // AC_DAC_UNIT=0       : DAC's 96-channel residual units as two tap-GEMM launches instead of dac_unit6_kernel
+        int mimi_tail = 1;          // AC_MIMI_TAIL=0      : Mimi's last residual block and the final conv as two kernels (rb_fused6<64,false> + head4)
         int head_seq = 0;           // AC_HEAD_SEQ=1       : the one-thread-per-sample head kernel (A/B against head4_kernel)
     } dev;
     bool fuse_chains = true;        // AC_FUSE=0 at ac_finalize: the layers of the fused chains as separate kernels (A/B runs, cross-check tests)
@@ -876,6 +877,7 @@ int decoder_fwd(ac_handle* h, hipStream_t st, const long long* toks, int B, int 
 
 // ---- wrappers around launches whose kernels live in core.hip (the per-codec translation units never include a header that
 // DEFINES a non-template kernel: one definition per library)
+bool rb64_identity_head_fwd(ac_handle* h, hipStream_t st, const ResBlockPlan& rb, const Act2& x, const PackedGemm& head, int head_k, float* sig, int B, int* rc);
 int rb64_identity_fwd(ac_handle* h, hipStream_t st, const ResBlockPlan& rb, const Act2& x, Out out, int B, const unsigned** amax_out);   // rb_fused6<64, false> / rb_fused<64,64,2,false>
 int rb128_identity_fwd(ac_handle* h, hipStream_t st, const ResBlockPlan& rb, const Act2& x, Out out, int B, const unsigned** amax_out); // rb128_fused6<false>
 int rvq_encode_cdist_launch(ac_handle* h, hipStream_t st, const RvqEncParams& p, unsigned blocks, const _Float16* epk16 = nullptr, const float* einv = nullptr);   // rvq_encode16_kernel<16, 1, true> (images given, H = 256) or rvq_encode_kernel<H/16, 1, true>

@@ -601,9 +601,17 @@ bool rb_split16(ac_handle* h, hipStream_t st, const ResBlockPlan& rb, const Act2
 
 
 template <int C, bool SC>
-int launch_rb_fused6(ac_handle* h, hipStream_t st, const ResBlockPlan& rb, const Act2& x, Out out, int B, int pad = PAD_REFLECT, const unsigned** amax_out = nullptr) {
+int launch_rb_fused6(ac_handle* h, hipStream_t st, const ResBlockPlan& rb, const Act2& x, Out out, int B, int pad = PAD_REFLECT, const unsigned** amax_out = nullptr,
+                     const PackedGemm* head = nullptr, int head_k = 0, float* head_y = nullptr) {
     using Cfg = Rb6Cfg<C, SC>;
     RbFused6Params p{};
+    const bool with_head = head && C == 64 && !SC;
+    if (with_head) {            // the decoder's final Conv1d(C, 1, k) applied to the block's output tile in LDS (rb_fused6.h HEAD)
+        p.head_w = h->blob + head->w_off;
+        p.head_b = h->blob + head->b_off;
+        p.head_y = head_y;
+        p.head_k = head_k;
+    }
     p.xr = x.raw.p;
     p.w3f = reinterpret_cast<const __bf16*>(h->blob + rb.w3f_off);
     p.wff = reinterpret_cast<const __bf16*>(h->blob + rb.wff_off);
@@ -615,21 +623,23 @@ int launch_rb_fused6(ac_handle* h, hipStream_t st, const ResBlockPlan& rb, const
     p.L = x.raw.L;
     p.lpad = h->noncausal ? 1 : 2;
     p.Lp = x.raw.L > p.lpad ? x.raw.L : p.lpad + 1;
-    p.ntiles = cdiv(x.raw.L, Cfg::BM);
+    p.ntiles = cdiv(x.raw.L, with_head ? Cfg::BM - (head_k - 1) : Cfg::BM);
     p.pad = pad;
     p.dbg = h->dev.rb6_dbg;
     if (!rb_split16(h, st, rb, x, B, p, amax_out)) return fail(h, AC_ESTATE, "fused residual block without split16 images");
     if (!p.amax_in) return fail(h, AC_ESTATE, "out of amax slots (split16.h)");
-    const size_t lds6 = Cfg::lds_bytes16;
-    if (int rc = ensure_lds(h, reinterpret_cast<const void*>(rb_fused6_kernel<C, SC, 2>), lds6)) return rc;
+    if (with_head) p.amax_out = nullptr;        // nothing reads the block's output but the head
+    const size_t lds6 = with_head ? Cfg::lds_bytes16_head : Cfg::lds_bytes16;
+    if (int rc = ensure_lds(h, with_head ? reinterpret_cast<const void*>(rb_fused6_head_kernel) : reinterpret_cast<const void*>(rb_fused6_kernel<C, SC, 2>), lds6)) return rc;
     const long long total = (long long)B * p.ntiles;
-    const int per_cu = rb6_occupancy<C, SC, 2>();
+    const int per_cu = with_head ? RB6_HEAD_OCC : rb6_occupancy<C, SC, 2>();
     const int grid = (int)std::min<long long>(total, (long long)per_cu * 256);   // persistent
     const double L = x.raw.L;
-    ProfScope ps(h, st, !SC ? "rb_fused6_kernel<64, false, 2>" : C == 32 ? "rb_fused6_kernel<32, true, 2>" : "rb_fused6_kernel<64, true, 2>",
-                 2.0 * B * L * ((double)(C / 2) * 3 * C + (double)C * (C / 2 + (SC ? C : 0))),
-                 (double)B * L * C * 4.0 * (1 + (out.raw ? 1 : 0) + (out.elu ? 1 : 0)));
-    hipLaunchKernelGGL((rb_fused6_kernel<C, SC, 2>), dim3(grid), dim3(256), lds6, st, p);
+    ProfScope ps(h, st, with_head ? "rb_fused6_head_kernel" : !SC ? "rb_fused6_kernel<64, false, 2>" : C == 32 ? "rb_fused6_kernel<32, true, 2>" : "rb_fused6_kernel<64, true, 2>",
+                 2.0 * B * L * ((double)(C / 2) * 3 * C + (double)C * (C / 2 + (SC ? C : 0)) + (with_head ? (double)head_k * C : 0.0)),
+                 with_head ? (double)B * L * (C + 1) * 4.0 : (double)B * L * C * 4.0 * (1 + (out.raw ? 1 : 0) + (out.elu ? 1 : 0)));
+    if (with_head) hipLaunchKernelGGL(rb_fused6_head_kernel, dim3(grid), dim3(256), lds6, st, p);
+    else hipLaunchKernelGGL((rb_fused6_kernel<C, SC, 2>), dim3(grid), dim3(256), lds6, st, p);
     return AC_OK;
 }
 
@@ -1492,6 +1502,12 @@ int upload_blob(ac_handle* h, Packer& pk, int device) {
 }
 
 // ---- wrappers for the per-codec translation units
+// Mimi's last decoder block with the final Conv1d(64, 1, k) folded in (rb_fused6.h HEAD); false: the shape / mode wants the two kernels
+bool rb64_identity_head_fwd(ac_handle* h, hipStream_t st, const ResBlockPlan& rb, const Act2& x, const PackedGemm& head, int head_k, float* sig, int B, int* rc) {
+    if (!rb.has6 || h->gemm_fp32 || h->dbg || h->dev.mimi_tail == 0 || head_k < 1 || head_k > 8 || head.N != 1 || head.Ktot != head_k * 64 || !head.has_bias) return false;
+    *rc = launch_rb_fused6<64, false>(h, st, rb, x, Out{}, B, PAD_ZERO, nullptr, &head, head_k, sig);
+    return true;
+}
 int rb64_identity_fwd(ac_handle* h, hipStream_t st, const ResBlockPlan& rb, const Act2& x, Out out, int B, const unsigned** amax_out) {
     return rb.has6 && !h->gemm_fp32 ? launch_rb_fused6<64, false>(h, st, rb, x, out, B, PAD_ZERO, amax_out) : launch_rb_fused<64, 64, 2, false>(h, st, rb, x, out, B, PAD_ZERO);
 }

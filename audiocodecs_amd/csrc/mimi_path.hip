@@ -384,6 +384,15 @@ int mimi_decoder_fwd(ac_handle* h, hipStream_t st, const float* qfeats, int B, i
         ws.give(x);
         x = y;
         capture(h, st, x.raw, B);
+        // last block: the final conv runs on the block's output tile in LDS (rb_fused6.h HEAD) -- the widest tensor of the path stays on chip
+        if (i == c.num_ratios - 1 && m.dec_rb[i].C == 64 && c.residual_kernel_size == 3 && c.compress == 2 && c.num_filters == 64 && x.raw.ts == 64 &&
+            x.raw.bs == (long long)x.raw.L * 64 && aligned16(x.raw.p)) {
+            int rc2 = AC_OK;
+            if (rb64_identity_head_fwd(h, st, m.dec_rb[i], x, m.dec_head, c.last_kernel_size, sig, B, &rc2)) {
+                ws.give(x);
+                return rc2;
+            }
+        }
         float* hb = ws.take();
         rc = mimi_resblock(h, st, m.dec_rb[i], x, hb, Out{dbg ? ws.take() : nullptr, ws.take()}, B, &y);
         if (rc) return rc;

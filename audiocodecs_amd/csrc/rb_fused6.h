@@ -42,6 +42,15 @@ struct RbFused6Params {
     const float* winv3;     // [C/2]
     const float* winvf;     // [C]
     float hb0, hb1;
+    // HEAD (round 4; C = 64, identity shortcut: Mimi's last block): the block's ELU'd output does not go to HBM -- the decoder's
+    // final Conv1d(C, 1, k) (causal, zero-padded) is applied to the tile in LDS and one float per sample is stored.  Tiles then
+    // advance by BM - (k - 1) rows and start k - 1 rows early (the conv's left context is recomputed, 3 % of the block's work);
+    // the conv's arithmetic is head4_kernel's (thin.h), in the same order: bit-identical samples.  Saves the 2 x 7.9 GB round
+    // trip of Mimi's widest tensor (128 clips x 10 s).
+    const float* head_w;    // [k][C] tap-major, null = off
+    const float* head_b;    // [1]
+    float* head_y;          // [B][L]
+    int head_k;
 };
 
 // split16.h scales of one clip of a fused block: sx for ELU(x) in the k3 conv; sb for the hidden activation AND the raw x of
@@ -72,6 +81,8 @@ struct Rb6Cfg {
     static constexpr int XE_PLANE = XE_ROWS * XP, XR_PLANE = SC ? BM * XP : 0, H_PLANE = BM * HP;
     static constexpr int SLOTS = (XE_ROWS * (C / 4) + 255) / 256;
     static constexpr size_t lds_bytes16 = (size_t)2 * (XE_PLANE + XR_PLANE + H_PLANE) * 2;   // split16.h: two planes
+    static constexpr int YP = C + 4;                                    // HEAD: fp32 rows of the ELU'd output tile
+    static constexpr size_t lds_bytes16_head = lds_bytes16 + (size_t)BM * YP * 4;
 };
 
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
@@ -99,8 +110,8 @@ __device__ __forceinline__ f32x4 mma6(const bf16x8 (&w)[3], const bf16x8 (&x)[3]
 // 12 / 43 registers at the higher occupancy and run 1.2-1.8x slower
 template <int C, bool SC, int NP>
 constexpr int rb6_occupancy() { return (C == 64 ? 2 : 3) + ((NP == 2 && C == 64 && !SC) ? 1 : 0); }
-template <int C, bool SC, int NP = 2>
-__global__ __launch_bounds__(256, (rb6_occupancy<C, SC, NP>())) void rb_fused6_kernel(const RbFused6Params p) {
+template <int C, bool SC, int NP, bool HEADT>
+__device__ __forceinline__ void rb_fused6_body(const RbFused6Params& p) {
     using Cfg = Rb6Cfg<C, SC>;
     constexpr int BM = Cfg::BM, HC = Cfg::HC, XP = Cfg::XP, HP = Cfg::HP;
     constexpr int MS = Cfg::MS, NA = Cfg::NA, NB = Cfg::NB, KSA = Cfg::KSA, KSH = Cfg::KSH, KSB = Cfg::KSB;
@@ -110,6 +121,10 @@ __global__ __launch_bounds__(256, (rb6_occupancy<C, SC, NP>())) void rb_fused6_k
     constexpr int NPL = NP == 2 ? 2 : 3;                           // planes held in LDS
     __bf16* Xr = Xe + NPL * Cfg::XE_PLANE;                         // [NPL][BM][XP]     (SC only)
     __bf16* Hs = Xr + NPL * Cfg::XR_PLANE;                         // [NPL][BM][HP]
+    float* Ys = reinterpret_cast<float*>(Hs + NPL * Cfg::H_PLANE); // [BM][YP]  (HEAD launches only: the launcher sizes the LDS)
+    constexpr bool HEAD = HEADT;                                   // (its own kernel: rb_fused6_head_kernel)
+    const int tstep = HEAD ? BM - (p.head_k - 1) : BM;             // rows a tile advances by
+    const int tback = HEAD ? p.head_k - 1 : 0;                     // rows a tile starts early
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -163,7 +178,7 @@ __global__ __launch_bounds__(256, (rb6_occupancy<C, SC, NP>())) void rb_fused6_k
     const int clip_bytes = p.L * C * 4;                         // buffer range: loads past the clip return 0, stores are dropped
     f32x4 rx[SLOTS];
     auto load_tile = [&](int tile) {
-        const int b = tile / p.ntiles, t0 = (tile % p.ntiles) * BM;
+        const int b = tile / p.ntiles, t0 = (tile % p.ntiles) * tstep - tback;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.xr + (long long)b * p.L * C), 0, clip_bytes, 0x00020000);
 #pragma unroll
         for (int i = 0; i < SLOTS; ++i) {
@@ -260,7 +275,7 @@ __global__ __launch_bounds__(256, (rb6_occupancy<C, SC, NP>())) void rb_fused6_k
         if (next < total && !(p.dbg & 4)) store_tile(next);
         // ---- output: lane (li, kq) holds channels nb0 + 16c + 4kq .. +3 of time row r0 + 16a + li
         if (!(p.dbg & 8)) {
-            const int b = tile / p.ntiles, t0 = (tile % p.ntiles) * BM;
+            const int b = tile / p.ntiles, t0 = (tile % p.ntiles) * tstep - tback;
             if (p.amax_out && b != omax_b) {                     // clip change: hand the finished clip's maximum over
                 amax_flush(omax, amax_at(p.amax_out, omax_b));
                 omax = 0;
@@ -273,7 +288,7 @@ __global__ __launch_bounds__(256, (rb6_occupancy<C, SC, NP>())) void rb_fused6_k
 #pragma unroll
             for (int a = 0; a < MS; ++a) {
                 const int t = t0 + r0 + a * 16 + li;
-                const int orow = t < p.L ? t * (C * 4) : 0x7fff0000;   // rows past the clip: out of range, dropped
+                const int orow = t >= 0 && t < p.L ? t * (C * 4) : 0x7fff0000;   // rows outside the clip: out of range, dropped
 #pragma unroll
                 for (int c = 0; c < NB; ++c) {
                     const int o = orow + (nb0 + c * 16 + 4 * kq) * 4;
@@ -286,15 +301,53 @@ __global__ __launch_bounds__(256, (rb6_occupancy<C, SC, NP>())) void rb_fused6_k
                         const f32x4 xv = bufload16(rs, o, 0);
                         v = f32x4{__fadd_rn(xv.x, v.x), __fadd_rn(xv.y, v.y), __fadd_rn(xv.z, v.z), __fadd_rn(xv.w, v.w)};
                     }
+                    if (HEAD) {      // the final conv's input tile: ELU(y) inside the clip, the conv's zero padding outside
+                        *reinterpret_cast<f32x4*>(Ys + (r0 + a * 16 + li) * Cfg::YP + nb0 + c * 16 + 4 * kq) = t >= 0 && t < p.L ? elu4(v) : zero4;
+                        continue;
+                    }
                     if (p.amax_out && t < p.L) amax_acc4(omax, v);
                     if (p.y) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), ry, o, 0, 0);
                     if (p.y_elu) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, elu4(v)), re, o, 0, 0);
                 }
             }
+            if (HEAD) {
+                // sample t0 + tback + tl = sum over taps j, channels c of w[j][c] Ys[tl + j][c] + bias: four lanes per sample, each over a
+                // quarter of the channels (all taps), quarters added pairwise, the bias last -- head4_kernel's order (thin.h)
+                lds_barrier();
+                const int tl = tid >> 2, q = tid & 3;
+                float hacc = 0.f;
+                for (int j = 0; j < p.head_k; ++j) {
+                    const float* yr = Ys + (tl + j < BM ? tl + j : BM - 1) * Cfg::YP + q * (C / 4);     // (rows past the tile: lanes that store nothing)
+                    const float* wr = p.head_w + j * C + q * (C / 4);
+#pragma unroll
+                    for (int g = 0; g < C / 16; ++g) {
+                        const f32x4 xv = *reinterpret_cast<const f32x4*>(yr + 4 * g);
+                        const f32x4 wv = *reinterpret_cast<const f32x4*>(wr + 4 * g);
+                        hacc = fmaf(wv.x, xv.x, hacc); hacc = fmaf(wv.y, xv.y, hacc);
+                        hacc = fmaf(wv.z, xv.z, hacc); hacc = fmaf(wv.w, xv.w, hacc);
+                    }
+                }
+                hacc += __shfl_xor(hacc, 1);
+                hacc += __shfl_xor(hacc, 2);
+                const int ts = t0 + tback + tl;
+                if (q == 0 && tl < tstep && ts < p.L) p.head_y[(long long)b * p.L + ts] = hacc + p.head_b[0];
+            }
         }
         lds_barrier();  
     }
     if (p.amax_out) amax_flush(omax, amax_at(p.amax_out, omax_b));
+}
+
+template <int C, bool SC, int NP = 2>
+__global__ __launch_bounds__(256, (rb6_occupancy<C, SC, NP>())) void rb_fused6_kernel(const RbFused6Params p) {
+    rb_fused6_body<C, SC, NP, false>(p);
+}
+// the 64-channel identity-shortcut block with the decoder's final conv folded in (RbFused6Params::head_*)
+#ifndef RB6_HEAD_OCC
+#define RB6_HEAD_OCC 2
+#endif
+__global__ __launch_bounds__(256, RB6_HEAD_OCC) void rb_fused6_head_kernel(const RbFused6Params p) {
+    rb_fused6_body<64, false, 2, true>(p);
 }
 
 }  // namespace ac

@@ -322,7 +322,7 @@ int ac_profile_end(ac_handle* h, ac_kernel_stat* out, int cap);
  * past the capacity).  Disarm with ac_debug_capture(h, NULL, 0). */
 int ac_debug_capture(ac_handle* h, float* buf_dev, size_t cap_floats);
 /* Developer / test switches of a handle (A/B paths, fault injection, timing variants): "tap_epi_staged", "tap_dil", "tap_stagger",
- * "tap_pick", "tap8", "tap8_form", "rb6_dbg", "front_seg", "tail_seg", "front_ldspad", "lstm_dbg", "lstm_fuse_in", "rvq_exact", "prof_detail", "head_seq", "attn_exact", "dac_unit".  Their
+ * "tap_pick", "tap8", "tap8_form", "rb6_dbg", "front_seg", "tail_seg", "front_ldspad", "lstm_dbg", "lstm_fuse_in", "rvq_exact", "prof_detail", "head_seq", "attn_exact", "dac_unit", "mimi_tail".  Their
  * initial values come from the environment variables of the same meaning (AC_TAP_EPI, AC_TAP_DIL, ...), read ONCE, at ac_finalize; no
  * compute entry point reads the environment.  Not part of the product interface. */
 int ac_debug_set(ac_handle* h, const char* key, int value);

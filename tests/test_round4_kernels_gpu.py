@@ -64,6 +64,7 @@ def test_head4_matches_the_sequential_head(name, B, T):
     sig = noise(9300 + T, B, T).cuda()
     with torch.no_grad():
         toks = codec.sig_to_toks(sig)
+        if name == "mimi": debug_set(codec, "mimi_tail", 0)        # (by default Mimi's final conv is folded into its last block: rb_fused6_head_kernel)
         debug_set(codec, "head_seq", 1)
         assert "head4_kernel" not in _kernels(codec, lambda: codec.toks_to_sig(toks))
         ref = codec.toks_to_sig(toks)
@@ -99,3 +100,26 @@ def test_dac_unit6_matches_the_two_launch_residual_unit(B, T, dac_checkpoints):
         assert torch.equal(new, codec.toks_to_sig(toks))
         assert torch.equal(codec.sig_to_toks(sig), toks)
     assert float((new - ref).abs().max()) <= 2e-5 * max(float(ref.abs().max()), 1e-3), float((new - ref).abs().max())
+
+
+@pytest.mark.parametrize("B,frames", [(2, 3), (1, 1), (3, 7)])
+def test_mimi_tail_with_the_final_conv_folded_in_is_bit_identical(B, frames):
+    """rb_fused6_head_kernel (csrc/rb_fused6.h HEAD: Mimi's last residual block with the decoder's final Conv1d(64, 1, 3) applied to the
+    block's output tile in LDS, tiles advancing by 62 rows) against rb_fused6<64, false> + head4_kernel (ac_debug_set "mimi_tail" 0): the
+    block's arithmetic is unchanged and the conv's is head4_kernel's in the same order -- the waveform must be BIT-identical, tile seams
+    (every 62 samples), the clip's first samples (zero left context) and ragged ends included."""
+    from audiocodecs_amd._native import debug_set
+
+    codec = _codec("mimi")
+    sig = noise(9700 + frames, B, 1920 * frames + 13).cuda()
+    with torch.no_grad():
+        toks = codec.sig_to_toks(sig)
+        debug_set(codec, "mimi_tail", 0)
+        assert "rb_fused6_head_kernel" not in _kernels(codec, lambda: codec.toks_to_sig(toks))
+        ref = codec.toks_to_sig(toks)
+        debug_set(codec, "mimi_tail", 1)
+        names = _kernels(codec, lambda: codec.toks_to_sig(toks))
+        assert "rb_fused6_head_kernel" in names and "head4_kernel" not in names, names
+        new = codec.toks_to_sig(toks)
+    assert new.shape == ref.shape
+    assert torch.equal(new, ref), float((new - ref).abs().max())
