@@ -93,8 +93,18 @@ int ac_debug_set(ac_handle* h, const char* key, int value) {
         {"rb6_dbg", &h->dev.rb6_dbg}, {"front_seg", &h->dev.front_seg}, {"tail_seg", &h->dev.tail_seg}, {"front_ldspad", &h->dev.front_ldspad},
         {"lstm_dbg", &h->dev.lstm_dbg}, {"lstm_fuse_in", &h->dev.lstm_fuse_in}, {"rvq_exact", &h->dev.rvq_exact}, {"prof_detail", &h->dev.prof_detail}, {"head_seq", &h->dev.head_seq}, {"attn_exact", &h->dev.attn_exact}, {"dac_unit", &h->dev.dac_unit}, {"mimi_tail", &h->dev.mimi_tail},
     };
+    // (before ac_finalize a value would be overwritten when finalize latches the environment; under stream capture a flipped kernel
+    //  path would be baked into part of a graph)
+    if (!h->finalized) return fail(h, AC_ESTATE, "ac_debug_set('%s'): the switches are latched by ac_finalize; set them afterwards", key);
     for (auto& t : tab)
-        if (std::strcmp(t.k, key) == 0) { *t.v = value; return AC_OK; }
+        if (std::strcmp(t.k, key) == 0) {
+            const bool nonneg = t.v == &h->dev.front_seg || t.v == &h->dev.tail_seg || t.v == &h->dev.front_ldspad || t.v == &h->dev.tap_stagger;
+            if (nonneg && value < 0) return fail(h, AC_EINVAL, "ac_debug_set('%s', %d): the value must be >= 0", key, value);
+            if (t.v == &h->dev.front_ldspad && value > 16384) return fail(h, AC_EINVAL, "ac_debug_set('front_ldspad', %d): at most 16384 bytes", value);
+            if (t.v == &h->dev.tap8_form && (value < 0 || value > 5)) return fail(h, AC_EINVAL, "ac_debug_set('tap8_form', %d): 0 (cost model) .. 5", value);
+            *t.v = value;
+            return AC_OK;
+        }
     return fail(h, AC_EINVAL, "ac_debug_set: unknown switch '%s'", key);
 }
 
@@ -113,6 +123,8 @@ int ac_finalize(ac_handle* h) {
         int pr = h->precision;
         if (pr < 0) {
             const char* gm = std::getenv("AC_GEMM");
+            if (gm && *gm && std::strcmp(gm, "fp32") != 0 && std::strcmp(gm, "split16") != 0)     // (bf16 / bf16x3 named modes that no longer exist)
+                return fail(h, AC_EINVAL, "AC_GEMM=%s: unknown arithmetic (fp32 = exact fp32 products, split16 or unset = the default)", gm);
             pr = gm && std::strcmp(gm, "fp32") == 0 ? AC_PRECISION_FP32_EXACT : AC_PRECISION_FP32;
         }
         const char* fz = std::getenv("AC_FUSE");

@@ -26,7 +26,29 @@ for p in "${pids[@]}"; do wait "$p"; done
 "$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$out" "$obj"/core.o "$obj"/mimi_path.o "$obj"/dac_path.o "$obj"/wavtok_path.o "$obj"/ac_api.o
 echo "built $out"
 bash "$here/check_isa.sh" "$out"
+# The structural scans below read hipcc's device assembly; what they accept was validated against ONE compiler.  A different hipcc
+# may schedule around the requests it cannot see (tap_gemm8.h) differently: fail loudly instead of trusting stale scans
+# (AC_ALLOW_HIPCC=1 builds anyway, e.g. to re-validate: run the GPU bit-identity tests, then update the version here).
+HIPCC_VALIDATED="7.2.26015"
+hipcc_ver="$("$HIPCC" --version | sed -n 's/^HIP version: *//p' | head -1)"
+echo "hipcc: HIP version $hipcc_ver (scans validated with $HIPCC_VALIDATED*)"
+case "$hipcc_ver" in
+    "$HIPCC_VALIDATED"*) ;;
+    *) if [ "${AC_ALLOW_HIPCC:-0}" != "1" ]; then
+           echo "build.sh: hipcc $hipcc_ver differs from the version the ISA scans were validated with ($HIPCC_VALIDATED): re-validate (GPU bit-identity tests) and update HIPCC_VALIDATED, or set AC_ALLOW_HIPCC=1" >&2
+           exit 1
+       fi ;;
+esac
+asm=()
+for tu in core mimi_path dac_path wavtok_path ac_api; do asm+=("$obj/$tu-hip-amdgcn-amd-amdhsa-gfx950.s"); done    # (explicit list: no stale .s of removed translation units)
 # Round 4: hipcc's hazard recogniser left an MFMA -> taken branch -> v_accvgpr_read of the MFMA's result without wait states in one
 # version of rvq16.h's tile loop (run-to-run different tokens; profiles/r4_variants.md).  The scan fails the build if any kernel
 # reads an MFMA result across a branch closer than the matrix pipe needs.
-python3 "$here/../../tools/mfma_branch_hazard.py" "$obj"/*-hip-amdgcn-amd-amdhsa-gfx950.s | tail -1
+scan_log="$obj/mfma_branch_hazard.log"
+if ! python3 "$here/../../tools/mfma_branch_hazard.py" "${asm[@]}" > "$scan_log" 2>&1; then cat "$scan_log"; exit 1; fi
+tail -1 "$scan_log"
+# Round 5: tap_gemm8's counted wait (s_waitcnt vmcnt(A_SLOTS)) is only right while hipcc emits exactly A_SLOTS buffer loads behind the
+# LDS-DMA requests of every stage, on every path (tap_gemm8.h; the race of profiles/r4_tapgemm8.md section 2.1 passed every test).
+scan_log="$obj/tap8_pipeline_scan.log"
+if ! python3 "$here/../../tools/tap8_pipeline_scan.py" "${asm[@]}" > "$scan_log" 2>&1; then cat "$scan_log"; exit 1; fi
+tail -1 "$scan_log"

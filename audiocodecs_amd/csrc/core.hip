@@ -793,8 +793,9 @@ int thin_head(ac_handle* h, hipStream_t st, const PackedGemm& g, int F, int k, i
     p.k = k;
     p.Lp = x.L > k - 1 ? x.L : k;
     p.pad = pad;
-    if (F % 16 == 0 && !h->dev.head_seq) {      // four lanes per sample (thin.h head4_kernel)
+    if (F % 16 == 0 && F <= 128 && k <= THIN_MAXK && !h->dev.head_seq) {      // four lanes per sample (thin.h head4_kernel; its slab is sized for F <= 128, k <= THIN_MAXK like head_kernel's)
         const size_t lds4 = ((size_t)(HEAD4_TT + THIN_MAXK) * (F + 4) + (size_t)THIN_MAXK * F) * sizeof(float);
+        if (int rc = ensure_lds(h, reinterpret_cast<const void*>(head4_kernel), lds4)) return rc;
         ProfScope ps(h, st, "head4_kernel", 2.0 * B * (double)x.L * F * k, (double)B * x.L * 4.0 * (F + 1));
         hipLaunchKernelGGL(head4_kernel, dim3(cdiv(x.L, HEAD4_TT), B), dim3(256), lds4, st, p);
         HIPCHK(h, hipGetLastError());

@@ -1,14 +1,15 @@
 // split16: fp32-fidelity products on the fp16 matrix pipe with TWO planes per operand and THREE partial products.
 //
 //   x * 2^s = hi + lo,   hi = fp16_rn(x * 2^s),   lo = fp16_rn(x * 2^s - hi)            (|lo| <= 2^-12 |x 2^s|)
-//   a * b  ~=  (a_hi b_hi + a_hi b_lo + a_lo b_hi) * 2^-(sa + sb)                          (a_lo b_lo <= 2^-24 |a b| dropped)
+//   a * b  ~=  (a_hi b_hi + a_hi b_lo + a_lo b_hi) * 2^-(sa + sb)                          (a_lo b_lo <= 2^-22 |a b| dropped, worst case)
 //
-// hi carries 11 significand bits, the residual of a round-to-nearest is itself below half an ulp and lo carries its
-// leading 11 bits: the pair represents x to 2^-24 relative -- the precision of the fp32 value -- wherever lo is a normal
-// fp16 number, and to 2^-25 ABSOLUTE (of the scaled value) below that: v_mfma_f32_*_f16 keeps fp16 denormal inputs
-// (tools/ubench/mfma_f16_probe.hip).  Products of fp16 values are exact in the fp32 accumulator.  Against the three-plane bf16
-// split of tap_gemm6.h (6 partial products) this is half the MFMAs and two thirds of the operand bytes at the same error
-// (K = 1536 dot products of random data, rms error / rms value: fp32 chain 1.8e-7, bf16 x 3 1.9e-7, fp16 x 2 1.9e-7).
+// hi carries 11 significand bits; the residual of that round-to-nearest is below half an ulp of hi (up to 2^-11 |hi| just above a
+// power of two, i.e. up to 12 significant bits below hi's last) and lo keeps its leading 11: WORST case the pair represents x to
+// 2^-23 relative (typically 2^-24, the precision of the fp32 value) wherever lo is a normal fp16 number, and to 2^-25 ABSOLUTE (of
+// the scaled value) below that: v_mfma_f32_*_f16 keeps fp16 denormal inputs (tools/ubench/mfma_f16_probe.hip).  Products of fp16
+// values are exact in the fp32 accumulator; the dropped lo lo term is at most 2^-11 * 2^-11 = 2^-22 of |a b| (both residuals at
+// their worst), typically 2^-24 or less.  So the arithmetic is fp32-GRADE, not fp32-equal -- measured on K = 1536 dot products of
+// random data, rms error / rms value: fp32 FMA chain 1.8e-7, this 1.9e-7 (the removed three-plane bf16 split, 6 products: 1.9e-7).
 //
 // What fp16 lacks is range, so every operand carries a power-of-two scale (multiplying by it is exact):
 //   * weights: one scale per OUTPUT CHANNEL, chosen offline from the row's largest magnitude; 2^-s comes back in the epilogue;

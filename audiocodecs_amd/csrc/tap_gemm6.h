@@ -397,12 +397,14 @@ __device__ __forceinline__ void tap6_mainloop(const TapGemmParams& p, const __bf
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
 
-    int a_lds[A_SLOTS], a_boff[A_SLOTS];
-#pragma unroll
-    for (int i = 0; i < A_SLOTS; ++i) {
-        const int e = tid + i * NT;
-        a_lds[i] = (e / (KC / 4)) < Cfg::A_ROWS ? (e / (KC / 4)) * T6_PITCH + 4 * (e % (KC / 4)) : -1;
-    }
+    // slot i of a thread = element tid + i * NT of the slab = (row tid / 8 + (NT / 8) i, 16-byte column tid % 8): the LDS offsets of a
+    // thread's slots are NT / 8 rows apart (ONE register + constants; a per-slot array cost the 128 x 32 arrangement three spilled
+    // registers at its 168-register budget, and a kernel with scratch is not safe to replay from a hipGraph -- DESIGN.md section 1);
+    // only the last slot can fall outside the slab
+    static_assert(NT % (KC / 4) == 0, "slots are whole rows apart");
+    int a_boff[A_SLOTS];
+    const int a_lds0 = (tid / (KC / 4)) * T6_PITCH + 4 * (tid % (KC / 4));
+    const bool last_slot_ok = (tid + (A_SLOTS - 1) * NT) / (KC / 4) < Cfg::A_ROWS;
 
     // ---- segment state (wave-uniform); identical to tap_gemm4
     int si = 0, c0 = 0, j = 0;
@@ -449,9 +451,13 @@ __device__ __forceinline__ void tap6_mainloop(const TapGemmParams& p, const __bf
     };
     // split16: one power-of-two scale for the clip's activation operand(s) (both segments share the accumulator)
     // (row mode: one scale per ROW of the merged row matrix instead -- a_rsc[slot])
+    // (row mode is a one-tap, undilated affair -- run_tap --: the wide-slab instantiations never see it, and their per-slot scale
+    //  registers collapse to one; they spilled 2 - 7 registers with the array)
+    constexpr bool CAN_ROWMODE = HALO == 7;
+    constexpr int NRSC = CAN_ROWMODE ? A_SLOTS : 1;
     float a_scale = 1.f, a_inv = 1.f;
-    float a_rsc[A_SLOTS];
-    const bool rowmode = NP == 2 && p.amax_rows;
+    float a_rsc[NRSC];
+    const bool rowmode = CAN_ROWMODE && NP == 2 && p.amax_rows;
     if (NP == 2) {
         if (!rowmode) {
             unsigned am = *amax_at(p.seg[0].amax, b);
@@ -461,7 +467,7 @@ __device__ __forceinline__ void tap6_mainloop(const TapGemmParams& p, const __bf
             a_inv = s16_pow2(-se);
         }
 #pragma unroll
-        for (int i = 0; i < A_SLOTS; ++i) {
+        for (int i = 0; i < NRSC; ++i) {
             a_rsc[i] = a_scale;
             if (rowmode) {
                 const int m = m0 + (tid + i * NT) / (KC / 4);
@@ -506,9 +512,9 @@ __device__ __forceinline__ void tap6_mainloop(const TapGemmParams& p, const __bf
     auto store_a = [&](__bf16* dst) {
 #pragma unroll
         for (int i = 0; i < A_SLOTS; ++i)
-            if (a_lds[i] >= 0) {
+            if (i + 1 < A_SLOTS || last_slot_ok) {
                 const f32x4 v = (a_zero & (1u << i)) ? f32x4{0.f, 0.f, 0.f, 0.f} : ra[i];
-                split16_store4s(v, a_rsc[i], dst, PLANE, a_lds[i]);
+                split16_store4s(v, a_rsc[CAN_ROWMODE ? i : 0], dst, PLANE, a_lds0 + i * (NT / (KC / 4)) * T6_PITCH);
             }
     };
     // B fragments of this wave's WN column tiles for ONE k-step: [plane][c]; k-step index inside the packed rows

@@ -200,12 +200,14 @@ class DAC(Codec):
         return out  # [K, C, 8] (latent) or [K, C, H]
 
     def _encode(self, sig, want_qfeats: bool):
-        nat = self._native_for(sig)
-        sig = sig.to(torch.float32).contiguous()
         B, T = sig.shape
         K, N = self._K(), self._frames(T)
         toks = torch.empty(B, N, K, dtype=torch.int64, device=sig.device)
         qf = torch.empty(B, N, self.config.hidden_size, dtype=torch.float32, device=sig.device) if want_qfeats else None
+        if B == 0:   # an empty shard (sharding.shard_bounds): nothing to run, the library is not called
+            return toks, qf
+        nat = self._native_for(sig)
+        sig = sig.to(torch.float32).contiguous()
         with torch.cuda.device(nat.device):
             ws = nat.workspace(nat.lib.ac_encode_workspace_bytes(nat.h, B, T))
             if want_qfeats:
@@ -223,12 +225,14 @@ class DAC(Codec):
     # override
     def _sig_to_feats(self, sig, length):
         # sig: [B, T] -> encoder output [B, N, H], or quantizers[0].in_proj of it [B, N, 8] when latent (dac.py:103-112)
-        nat = self._native_for(sig)
-        sig = sig.to(torch.float32).contiguous()
         B, T = sig.shape
         N = self._frames(T)
         width = self.config.codebook_dim if self.latent else self.config.hidden_size
         feats = torch.empty(B, N, width, dtype=torch.float32, device=sig.device)
+        if B == 0:
+            return feats
+        nat = self._native_for(sig)
+        sig = sig.to(torch.float32).contiguous()
         with torch.cuda.device(nat.device):
             ws = nat.workspace(nat.lib.ac_encode_workspace_bytes(nat.h, B, T))
             if self.latent:
@@ -246,11 +250,13 @@ class DAC(Codec):
     # override
     def _toks_to_sig(self, toks, length):
         # toks: [B, N, K] -> quantizer.from_codes -> decoder -> [B, T'] (dac.py:123-130)
-        nat = self._native_for(toks)
-        toks = toks.to(torch.int64).contiguous()
         B, N, K = toks.shape
         L = self.config.num_samples(N)
         sig = torch.empty(B, L, dtype=torch.float32, device=toks.device)
+        if B == 0:
+            return sig
+        nat = self._native_for(toks)
+        toks = toks.to(torch.int64).contiguous()
         with torch.cuda.device(nat.device):
             ws = nat.workspace(nat.lib.ac_decode_workspace_bytes(nat.h, B, N))
             _native.check(

@@ -190,11 +190,13 @@ class Encodec(Codec):
     def _sig_to_toks(self, sig, length):
         # sig: [B, T]
         K = self._num_quantizers()
+        B, T = sig.shape
+        N = self.config.num_frames(T)
+        if B == 0:   # an empty shard (sharding.shard_bounds): nothing to run, the library is not called
+            return torch.empty(0, N, K, dtype=torch.int64, device=sig.device)
         nat = self._native_for(sig)
         sig = sig.to(torch.float32).contiguous()
         length = self._check_length(sig, length)
-        B, T = sig.shape
-        N = self.config.num_frames(T)
         toks = torch.empty(B, N, K, dtype=torch.int64, device=sig.device)
         with torch.cuda.device(nat.device):
             nbytes = nat.lib.ac_encode_workspace_bytes(nat.h, B, T)
@@ -209,10 +211,12 @@ class Encodec(Codec):
     def _sig_to_feats(self, sig, length):
         # sig: [B, T] -> [B, N, H].  The reference masks here only when config.normalize
         # (encodec.py:107-112): never for the 24 kHz model, so `length` is ignored.
-        nat = self._native_for(sig)
-        sig = sig.to(torch.float32).contiguous()
         B, T = sig.shape
         N = self.config.num_frames(T)
+        if B == 0:
+            return torch.empty(0, N, self.config.hidden_size, dtype=torch.float32, device=sig.device)
+        nat = self._native_for(sig)
+        sig = sig.to(torch.float32).contiguous()
         feats = torch.empty(B, N, self.config.hidden_size, dtype=torch.float32, device=sig.device)
         with torch.cuda.device(nat.device):
             ws = nat.workspace(nat.lib.ac_encode_workspace_bytes(nat.h, B, T))
@@ -230,9 +234,11 @@ class Encodec(Codec):
     # override
     def _toks_to_sig(self, toks, length):
         # toks: [B, N, K] -> [B, N*hop]
+        B, N, K = toks.shape
+        if B == 0:
+            return torch.empty(0, N * self.config.hop_length, dtype=torch.float32, device=toks.device)
         nat = self._native_for(toks)
         toks = toks.to(torch.int64).contiguous()
-        B, N, K = toks.shape
         sig = torch.empty(B, N * self.config.hop_length, dtype=torch.float32, device=toks.device)
         with torch.cuda.device(nat.device):
             ws = nat.workspace(nat.lib.ac_decode_workspace_bytes(nat.h, B, N))
@@ -245,9 +251,11 @@ class Encodec(Codec):
     # override
     def _toks_to_qfeats(self, toks, length):
         # toks: [B, N, K] -> [B, N, H]
+        B, N, K = toks.shape
+        if B == 0:
+            return torch.empty(0, N, self.config.hidden_size, dtype=torch.float32, device=toks.device)
         nat = self._native_for(toks)
         toks = toks.to(torch.int64).contiguous()
-        B, N, K = toks.shape
         out = torch.empty(B, N, self.config.hidden_size, dtype=torch.float32, device=toks.device)
         with torch.cuda.device(nat.device):
             _native.check(nat.lib.ac_dequantize(nat.h, _ptr(toks), B, N, K, _ptr(out), _stream()), nat.h, "ac_dequantize")

@@ -160,11 +160,13 @@ class Mimi(Codec):
         # sig: [B, T].  The padding mask the reference builds (mimi.py:95-104) is not applied to the
         # samples by the model ([HF] mimi :1245-1247): `length` does not change the result.
         self._check_num_codebooks()
-        nat = self._native_for(sig)
-        sig = sig.to(torch.float32).contiguous()
         B, T = sig.shape
         K = self.num_codebooks
         N = self.config.num_frames(T)
+        if B == 0:   # an empty shard (sharding.shard_bounds): nothing to run, the library is not called
+            return torch.empty(0, N, K, dtype=torch.int64, device=sig.device)
+        nat = self._native_for(sig)
+        sig = sig.to(torch.float32).contiguous()
         toks = torch.empty(B, N, K, dtype=torch.int64, device=sig.device)
         with torch.cuda.device(nat.device):
             ws = nat.workspace(nat.lib.ac_encode_workspace_bytes(nat.h, B, T))
@@ -177,10 +179,12 @@ class Mimi(Codec):
     # override
     def _sig_to_feats(self, sig, length):
         # sig: [B, T] -> [B, N, hidden]: encoder -> encoder_transformer -> downsample (mimi.py:112-121)
-        nat = self._native_for(sig)
-        sig = sig.to(torch.float32).contiguous()
         B, T = sig.shape
         N = self.config.num_frames(T)
+        if B == 0:
+            return torch.empty(0, N, self.config.hidden_size, dtype=torch.float32, device=sig.device)
+        nat = self._native_for(sig)
+        sig = sig.to(torch.float32).contiguous()
         feats = torch.empty(B, N, self.config.hidden_size, dtype=torch.float32, device=sig.device)
         with torch.cuda.device(nat.device):
             ws = nat.workspace(nat.lib.ac_encode_workspace_bytes(nat.h, B, T))
@@ -197,9 +201,11 @@ class Mimi(Codec):
     # override
     def _toks_to_sig(self, toks, length):
         # toks: [B, N, K] -> [B, N*hop] (not trimmed: mimi.py:146-148 passes no padding mask)
+        B, N, K = toks.shape
+        if B == 0:
+            return torch.empty(0, N * self.config.hop_length, dtype=torch.float32, device=toks.device)
         nat = self._native_for(toks)
         toks = toks.to(torch.int64).contiguous()
-        B, N, K = toks.shape
         sig = torch.empty(B, N * self.config.hop_length, dtype=torch.float32, device=toks.device)
         with torch.cuda.device(nat.device):
             ws = nat.workspace(nat.lib.ac_decode_workspace_bytes(nat.h, B, N))
@@ -212,9 +218,11 @@ class Mimi(Codec):
     # override
     def _toks_to_qfeats(self, toks, length):
         # toks: [B, N, K] -> [B, N, hidden]
+        B, N, K = toks.shape
+        if B == 0:
+            return torch.empty(0, N, self.config.hidden_size, dtype=torch.float32, device=toks.device)
         nat = self._native_for(toks)
         toks = toks.to(torch.int64).contiguous()
-        B, N, K = toks.shape
         out = torch.empty(B, N, self.config.hidden_size, dtype=torch.float32, device=toks.device)
         with torch.cuda.device(nat.device):
             ws = nat.workspace(nat.lib.ac_quantizer_workspace_bytes(nat.h, B, N))

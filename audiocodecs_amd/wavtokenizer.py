@@ -171,6 +171,8 @@ class WavTokenizer(Codec):
     # override
     def _sig_to_toks(self, sig, length):
         # sig: [B, T] -> [B, N, 1]  (`length` is not used by the reference either, wavtokenizer.py:92-96)
+        if sig.shape[0] == 0:   # an empty shard (sharding.shard_bounds): nothing to run, the library is not called
+            return torch.empty(0, self.arch.num_frames(sig.shape[1]), 1, dtype=torch.int64, device=sig.device)
         nat = self._native_for(sig)
         sig = sig.to(torch.float32).contiguous()
         B, T = sig.shape
@@ -187,6 +189,8 @@ class WavTokenizer(Codec):
     # override
     def _sig_to_feats(self, sig, length):
         # sig: [B, T] -> [B, N, dimension]
+        if sig.shape[0] == 0:   # an empty shard (sharding.shard_bounds): nothing to run, the library is not called
+            return torch.empty(0, self.arch.num_frames(sig.shape[1]), self.arch.dimension, dtype=torch.float32, device=sig.device)
         nat = self._native_for(sig)
         sig = sig.to(torch.float32).contiguous()
         B, T = sig.shape
@@ -208,6 +212,8 @@ class WavTokenizer(Codec):
     # override
     def _toks_to_sig(self, toks, length):
         # toks: [B, N, 1] -> [B, N*hop]
+        if toks.shape[0] == 0:   # an empty shard (sharding.shard_bounds): nothing to run, the library is not called
+            return torch.empty(0, toks.shape[1] * self.arch.hop_length, dtype=torch.float32, device=toks.device)
         nat = self._native_for(toks)
         toks = toks.to(torch.int64).contiguous()
         B, N, K = toks.shape
@@ -223,6 +229,8 @@ class WavTokenizer(Codec):
     # override
     def _toks_to_qfeats(self, toks, length):
         # toks: [B, N, 1] -> [B, N, dimension]
+        if toks.shape[0] == 0:   # an empty shard (sharding.shard_bounds): nothing to run, the library is not called
+            return torch.empty(0, toks.shape[1], self.arch.dimension, dtype=torch.float32, device=toks.device)
         nat = self._native_for(toks)
         toks = toks.to(torch.int64).contiguous()
         B, N, K = toks.shape
@@ -234,6 +242,8 @@ class WavTokenizer(Codec):
     # override
     def _feats_to_sig(self, feats, length):
         # feats: [B, N, dimension] -> [B, N*hop]
+        if feats.shape[0] == 0:   # an empty shard (sharding.shard_bounds): nothing to run, the library is not called
+            return torch.empty(0, feats.shape[1] * self.arch.hop_length, dtype=torch.float32, device=feats.device)
         nat = self._native_for(feats)
         feats = feats.to(torch.float32).contiguous()
         B, N, H = feats.shape

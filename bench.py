@@ -2,7 +2,9 @@
 """Benchmark of the hot path: EnCodec-24k, 8 codebooks, encode + decode of 64 x 10 s per GPU.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    (N > 1: either under a launcher -- python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+     --master-port P bench.py --gpus N ... -- or bare: `python bench.py --gpus N` then starts that launcher itself as a child
+     process before touching the GPU and forwards its output and exit code)
 
 A step = Codec.sig_to_toks + Codec.toks_to_sig over one synthetic batch that is already resident
 in HBM (BASELINE.json configs[1]; weights: seeded synthetic checkpoint -- no pretrained weights
@@ -602,6 +604,8 @@ def parse_args(argv=None):
     ap.add_argument("--precision", choices=["fp32", "fp32_exact"], default=None,
                     help="arithmetic of the GEMM-shaped kernels: default = fp32 fidelity (split16: the parity arithmetic, what `value` is "
                          "quoted for); fp32_exact = every product an IEEE fp32 product")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="nccl = RCCL on the GPUs (the measurement); gloo = tests only: the same launch + run() flow on CPU with a stub codec")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the parity gates and every other untimed extra (profiling passes: keeps the kernel trace to the timed workload)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short runs of BASELINE.json configs 3-5 (DAC, Mimi, WavTokenizer) that travel in the same JSON line")
@@ -610,14 +614,59 @@ def parse_args(argv=None):
     return ap.parse_args(argv)
 
 
-def main():
-    args = parse_args()
+def launch_ranks(argv, gpus):
+    """`python bench.py --gpus N` without a launcher: start `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port <free> bench.py <same arguments>` as a CHILD process and hand back its exit code; the
+    child's stdout (rank 0's one JSON line) and stderr pass straight through.  The parent has not touched the GPU when it gets
+    here (main() calls this before any HIP / torch.cuda call) and never does: on this pool a process that has initialised the
+    GPU must not exec or be replaced, and a parent holding a context would also sit on rank 0's device."""
+    import socket
+    import subprocess
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL needs on this pool's host driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def main_gloo_stub(args, rank, world):
+    """--backend gloo (tests only): the same flow -- launcher, process group, run(), one JSON line -- on CPU tensors over gloo with
+    the stub codec of tests/bench_flow_child.py standing in for the HIP library.  Measures nothing; it exists so that the N > 1
+    launch path of THIS file can be executed where there is no GPU (tests/test_bench_launcher_gloo.py)."""
+    import torch.distributed as dist
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from bench_flow_child import StubCodec
+    from audiocodecs_amd.config import ENCODEC_24KHZ as cfg
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sig = torch.zeros(args.batch, int(round(args.seconds * cfg.sampling_rate)))
+    args.no_cpu_baseline = True
+    rc = run(args, StubCodec(rank), cfg, None, sig, sig, rank, world, dist, torch.device("cpu"))
+    dist.destroy_process_group()
+    return rc
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else list(argv)
+    args = parse_args(argv)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and os.environ.get("RANK") is None:
+        # not under a launcher: spawn the N ranks ourselves (BEFORE anything touches the GPU) and forward the child's exit code
+        return launch_ranks(argv, args.gpus)
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}, or without a launcher")
+    if args.backend == "gloo":
+        return main_gloo_stub(args, rank, world)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
@@ -639,7 +688,8 @@ def main():
     run(args, codec, cfg, sd, sig, sig_cpu, rank, world, dist, device)
     if dist is not None:
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -30,8 +30,10 @@
  *  - activations, weights and results are fp32, accumulation is fp32, tokens are int64 like the reference's.  The
  *    large GEMMs, the fused residual blocks and the LSTM products run "split-operand" arithmetic on the fp16 matrix pipe:
  *    every fp32 operand, scaled by a power of two, is written as two fp16 terms and 3 of the 4 exact partial products
- *    are accumulated in fp32 (error equal to fp32 arithmetic; ac_set_precision lists the
- *    alternatives: three bf16 terms / 6 products, exact fp32 products (v_mfma_f32_16x16x4_f32), opt-in bf16).
+ *    are accumulated in fp32 (fp32-grade error: K = 1536 dot products measure 1.9e-7 rms against an fp32 FMA chain's
+ *    1.8e-7).  ac_set_precision selects the one alternative: exact fp32 products
+ *    (v_mfma_f32_16x16x4_f32) in every kernel.  (The three-bf16-term and rounded-bf16 modes of rounds 1-3 are gone;
+ *    their values are rejected.)
  */
 #ifndef AUDIOCODECS_AMD_H
 #define AUDIOCODECS_AMD_H
