@@ -370,10 +370,14 @@ int run_tap(ac_handle* h, hipStream_t st, TapGemmParams& p) {
                 if (h->dev.tap8_form >= 1 && h->dev.tap8_form <= 3 && (h->dev.tap8_form == 2 || p.N % 256 == 0)) form = h->dev.tap8_form;
                 use8 = want8 >= 1 || model;
                 if (use8) {
+#define TAP8_LAUNCH_KP(WGM, WGN, WMT, WN, RM, J1, PP)                                                                    \
+    do {                                                                                                                \
+        if ((rc = ensure_lds(h, reinterpret_cast<const void*>(tap_gemm8_kernel<WGM, WGN, WMT, WN, RM, J1, PP>), Cfg8::lds_bytes))) return rc; \
+        hipLaunchKernelGGL((tap_gemm8_kernel<WGM, WGN, WMT, WN, RM, J1, PP>), dim3((unsigned)blocks), dim3(Cfg8::NT), Cfg8::lds_bytes, st, p, w6); \
+    } while (0)
 #define TAP8_LAUNCH_K(WGM, WGN, WMT, WN, RM, J1)                                                                         \
     do {                                                                                                                \
-        if ((rc = ensure_lds(h, reinterpret_cast<const void*>(tap_gemm8_kernel<WGM, WGN, WMT, WN, RM, J1>), Cfg8::lds_bytes))) return rc; \
-        hipLaunchKernelGGL((tap_gemm8_kernel<WGM, WGN, WMT, WN, RM, J1>), dim3((unsigned)blocks), dim3(Cfg8::NT), Cfg8::lds_bytes, st, p, w6); \
+        if (h->dev.tap8_pp) TAP8_LAUNCH_KP(WGM, WGN, WMT, WN, RM, J1, true); else TAP8_LAUNCH_KP(WGM, WGN, WMT, WN, RM, J1, false); \
     } while (0)
 #define TAP8_LAUNCH(WGM, WGN, WMT, WN)                                                                                   \
     do {                                                                                                                \
@@ -383,12 +387,13 @@ int run_tap(ac_handle* h, hipStream_t st, TapGemmParams& p) {
         const long long blocks = (long long)p.B * p.mtiles * p.ntiles;                                                  \
         ProfScope ps(h, st, (std::string("tap_gemm8_kernel<" #WGM ", " #WGN ", " #WMT ", " #WN ", 2>") + shape).c_str(), flops, bytes); \
         if (s0.J == 1) { if (p.amax_rows) TAP8_LAUNCH_K(WGM, WGN, WMT, WN, true, true); else TAP8_LAUNCH_K(WGM, WGN, WMT, WN, false, true); } \
-        else           { if (p.amax_rows) TAP8_LAUNCH_K(WGM, WGN, WMT, WN, true, false); else TAP8_LAUNCH_K(WGM, WGN, WMT, WN, false, false); } \
+        else           { TAP8_LAUNCH_K(WGM, WGN, WMT, WN, false, false); }   /* (row mode is a one-tap affair: run_tap's `rowmode`) */ \
     } while (0)
                     if (form == 1) TAP8_LAUNCH(2, 4, 4, 2);
                     else if (form == 3) TAP8_LAUNCH(2, 4, 2, 2);
                     else TAP8_LAUNCH(4, 2, 2, 2);
 #undef TAP8_LAUNCH_K
+#undef TAP8_LAUNCH_KP
 #undef TAP8_LAUNCH
                     HIPCHK(h, hipGetLastError());
                     return AC_OK;

@@ -78,10 +78,24 @@ def test_rejects_a_wait_that_counts_the_wrong_number(tmp_path):
     assert f and "A_SLOTS = 3" in f[0]
 
 
-def test_rejects_a_barrier_without_a_covering_wait(tmp_path):
-    body = loop(DMA * 2 + loads(3) + MFMA * 4 + "\ts_waitcnt lgkmcnt(0)\n\ts_barrier\n")
+def test_rejects_a_wait_that_lost_its_barrier(tmp_path):
+    body = loop(DMA * 2 + loads(3) + MFMA * 4 + "\t;;#ASMSTART\n\ts_waitcnt vmcnt(3)\n\t;;#ASMEND\n\tds_read_b128 v[20:23], v5\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier\n")
     f = run(tmp_path, body)
-    assert any("s_barrier" in x and "no covering wait" in x for x in f), f
+    assert any("not followed by its barrier" in x for x in f), f
+
+
+def test_rejects_requests_in_flight_at_the_end_of_the_kernel(tmp_path):
+    # the last stage still issues weight requests and nothing drains them before the (LDS-reusing) epilogue / s_endpgm
+    body = loop(stage()) + DMA + MFMA * 4 + "\ts_waitcnt lgkmcnt(0)\n\ts_barrier\n"
+    f = run(tmp_path, body)
+    assert any("s_endpgm" in x and "no covering wait" in x for x in f), f
+
+
+def test_accepts_requests_in_flight_across_segment_barriers(tmp_path):
+    # the ping-pong loop: requests at the top of a stage, two segment barriers, THEN the counted wait and its barrier
+    seg = "\ts_waitcnt lgkmcnt(0)\n\ts_barrier\n"
+    body = loop(DMA * 2 + loads(3) + seg + MFMA * 4 + "\ts_barrier\n" + MFMA * 0 + WAIT.format(3) + MFMA * 4 + "\ts_barrier\n")
+    assert run(tmp_path, body) == []
 
 
 def test_other_vector_memory_traffic_in_the_window_is_rejected(tmp_path):

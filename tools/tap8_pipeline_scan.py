@@ -16,9 +16,13 @@ checks:
      along every path, the first N vector-memory instructions met are `buffer_load_dwordx4` (no `... lds`, no `global_load_lds*`, no store or
      atomic) -- conditional branches are followed both ways, so a load inside a region some waves skip (`s_cbranch_execz`) fails the
      path that skips it; N must be the instantiation's A_SLOTS (from its template arguments);
-  2. every `s_barrier`: on every path into it a covering wait -- the kernel's counted wait, or any `s_waitcnt vmcnt(0)` -- is met (walking
-     backwards) before any LDS-DMA request;
-  3. the kernel contains LDS-DMA requests at all (otherwise the scan is looking at the wrong thing).
+  2. every wait of the kernel's own (`s_waitcnt vmcnt(..)` from inline asm) is followed directly by its `s_barrier` (only further
+     `s_waitcnt`s in between): the hand-over "my requests have landed -> everybody may read" is intact;
+  3. walking backwards from every `s_endpgm`, a covering wait -- the counted wait, or any `vmcnt(0)` -- is met before any LDS-DMA request:
+     nothing is in flight when the staged epilogue reuses the LDS or the wave ends;
+  4. the kernel contains LDS-DMA requests at all (otherwise the scan is looking at the wrong thing).
+(Requests stay in flight ACROSS barriers by design -- that is the pipeline: the lock-step loop keeps them over one stage, the ping-pong
+loop over three segment barriers; what must hold is that the wait covering them precedes the barrier in front of their first read.)
 Exit status 1 and one line per finding if anything fails.  Usage: tap8_pipeline_scan.py file.s [...]
 (tests/test_tap8_pipeline_scan.py feeds it synthetic assembly with each failure.)"""
 import re
@@ -249,10 +253,27 @@ def scan_kernel(name, ins, lab):
     if n_waits == 0:
         findings.append(f"{name}: no counted inline-asm wait (s_waitcnt vmcnt(N), N > 0) found")
 
-    # 2. barriers: on every path into a barrier, a covering wait -- the kernel's own counted wait (checked above) or any vmcnt(0) -- comes
-    # before (walking backwards) any LDS-DMA request
+    # 2. a counted / draining wait of the kernel (inline asm) hands over at a barrier: `s_waitcnt vmcnt(..)` -> [`s_waitcnt lgkmcnt(0)`] ->
+    # `s_barrier`, nothing that touches LDS or memory in between
+    for i, (t, in_asm) in enumerate(ins):
+        if not (in_asm and t.startswith("s_waitcnt") and "vmcnt" in t):
+            continue
+        j, ok = i + 1, False
+        while j < len(ins) and j - i <= 6:
+            op2 = ins[j][0].split()[0]
+            if op2 == "s_barrier":
+                ok = True
+                break
+            if not op2.startswith("s_") or op2.startswith(("s_cbranch", "s_branch", "s_endpgm", "s_setpc", "s_load", "s_buffer_load")):
+                break                      # (other scalar ALU instructions the scheduler drops in between are harmless)
+            j += 1
+        if not ok:
+            findings.append(f"{name}: the kernel's wait `{t}` at instruction {i} is not followed by its barrier")
+
+    # 3. no LDS-DMA request may still be in flight when the kernel's LDS is reused (the staged epilogue) or the wave ends: walking backwards
+    # from every s_endpgm, a covering wait is met before any request
     for i, (t, _) in enumerate(ins):
-        if t.split()[0] != "s_barrier":
+        if t.split()[0] != "s_endpgm":
             continue
 
         def visit(j, st):
@@ -263,12 +284,12 @@ def scan_kernel(name, ins, lab):
                 if m and (int(m.group(1)) == 0 or (in_asm and int(m.group(1)) == n_slots)):
                     return True, st
             if is_vmem(op2) and is_lds_dma(t2):
-                return f"LDS-DMA request at instruction {j} (`{t2}`) reaches the barrier with no covering wait (vmcnt({n_slots}) from inline asm, or vmcnt(0))", st
+                return f"LDS-DMA request at instruction {j} (`{t2}`) can reach the end of the kernel with no covering wait behind it", st
             return None, st
 
         bad = w.walk(i, visit, 0, lambda st: None)
         if bad:
-            findings.append(f"{name}: s_barrier at instruction {i}: {bad}")
+            findings.append(f"{name}: s_endpgm at instruction {i}: {bad}")
     return findings
 
 
