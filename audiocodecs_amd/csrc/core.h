@@ -177,7 +177,7 @@ struct ac_handle {
         int tap_pick = -1;          // AC_TAP_PICK=0|1|2   : force a tile arrangement for N % 256 == 0 layers
         int tap8 = -1;              // AC_TAP8=-1|0|1      : tap_gemm8.h by the cost model (default) / never / wherever the shape allows
         int tap8_form = 0;          // AC_TAP8_FORM=1|2|3  : force its tile form (256 x 256, 256 x 128, 128 x 256) where the shape allows
-        int tap8_pp = 1;            // AC_TAP8_PP=0        : tap_gemm8's lock-step main loop instead of the ping-pong one (round-5 A/B; bit-identical)
+        int tap8_spread = 1;        // AC_TAP8_SPREAD=0|1|2: tap_gemm8's requests of a stage at its top / dealt between its MFMA units where that measured faster (128-row tiles) / dealt everywhere (bit-identical)
         int rb6_dbg = 0;            // AC_RB6_DBG          : timing variants of the fused blocks (wrong results)
         int front_seg = 0, tail_seg = 0;   // AC_FRONT_SEG / AC_TAIL_SEG: chunks per stream of the fused chains (0: from the batch size)
         int front_ldspad = 0;       // AC_FRONT_LDSPAD     : extra dynamic LDS (forces one workgroup per CU)

@@ -110,12 +110,21 @@ void pool_bind(ac_handle* h, void* mem, int pool_B, size_t rows) {
 }
 
 
+// `words` 32-bit words from p (16-byte aligned, words % 4 == 0) to zero with zero16_kernel (split16_kernels.h: not a memset node)
+static void zero_words(hipStream_t st, unsigned* p, size_t words) {
+    const size_t n16 = words / 4;
+    const unsigned grid = (unsigned)std::min<size_t>(std::max<size_t>((n16 + 255) / 256, 1), 2048);
+    hipLaunchKernelGGL(zero16_kernel, dim3(grid), dim3(256), 0, st, reinterpret_cast<s16_f32x4*>(p), n16);
+}
+
+
 // start of a pass over B clips: all slots of the bound pool back to zero (one memset of AMAX_SLOTS x B lines on the caller's stream)
 int amax_begin(ac_handle* h, hipStream_t st, int B) {
     h->amax_next = 0;
     if (h->gemm_fp32 || !h->amax_buf) return AC_OK;
     if (B > h->amax_B) return fail(h, AC_ENOMEM, "workspace pool holds amax slots for %d clips, the pass has %d", h->amax_B, B);
-    HIPCHK(h, hipMemsetAsync(h->amax_buf, 0, (size_t)AMAX_SLOTS * h->amax_B * AMAX_STRIDE * 4, st));
+    zero_words(st, h->amax_buf, (size_t)AMAX_SLOTS * h->amax_B * AMAX_STRIDE);
+    HIPCHK(h, hipGetLastError());
     return AC_OK;
 }
 
@@ -147,7 +156,10 @@ unsigned* rowmax_new(ac_handle* h, hipStream_t st, long long rows, bool zero) {
     if (h->row_next + need > h->row_cap) h->row_next = 0;
     unsigned* r = h->row_buf + h->row_next;
     h->row_next += need;
-    if (zero && hipMemsetAsync(r, 0, (size_t)rows * 4, st) != hipSuccess) return nullptr;
+    if (zero) {          // (the granule is 64 words: whole 16-byte units, the tail of the last granule belongs to this allocation too)
+        zero_words(st, r, need);
+        if (hipGetLastError() != hipSuccess) return nullptr;
+    }
     return r;
 }
 
@@ -370,14 +382,16 @@ int run_tap(ac_handle* h, hipStream_t st, TapGemmParams& p) {
                 if (h->dev.tap8_form >= 1 && h->dev.tap8_form <= 3 && (h->dev.tap8_form == 2 || p.N % 256 == 0)) form = h->dev.tap8_form;
                 use8 = want8 >= 1 || model;
                 if (use8) {
-#define TAP8_LAUNCH_KP(WGM, WGN, WMT, WN, RM, J1, PP)                                                                    \
+#define TAP8_LAUNCH_KP(WGM, WGN, WMT, WN, RM, J1, SP)                                                                    \
     do {                                                                                                                \
-        if ((rc = ensure_lds(h, reinterpret_cast<const void*>(tap_gemm8_kernel<WGM, WGN, WMT, WN, RM, J1, PP>), Cfg8::lds_bytes))) return rc; \
-        hipLaunchKernelGGL((tap_gemm8_kernel<WGM, WGN, WMT, WN, RM, J1, PP>), dim3((unsigned)blocks), dim3(Cfg8::NT), Cfg8::lds_bytes, st, p, w6); \
+        if ((rc = ensure_lds(h, reinterpret_cast<const void*>(tap_gemm8_kernel<WGM, WGN, WMT, WN, RM, J1, SP>), Cfg8::lds_bytes))) return rc; \
+        hipLaunchKernelGGL((tap_gemm8_kernel<WGM, WGN, WMT, WN, RM, J1, SP>), dim3((unsigned)blocks), dim3(Cfg8::NT), Cfg8::lds_bytes, st, p, w6); \
     } while (0)
 #define TAP8_LAUNCH_K(WGM, WGN, WMT, WN, RM, J1)                                                                         \
     do {                                                                                                                \
-        if (h->dev.tap8_pp) TAP8_LAUNCH_KP(WGM, WGN, WMT, WN, RM, J1, true); else TAP8_LAUNCH_KP(WGM, WGN, WMT, WN, RM, J1, false); \
+        /* requests dealt between the MFMA units (tap_gemm8.h SPREAD): measured per form -- 128 x 256 tiles gain, 256 x 256 are level, 256 x 128 lose */ \
+        const bool spread = h->dev.tap8_spread == 2 || (h->dev.tap8_spread == 1 && (WGM) * (WMT) * 32 == 128);         \
+        if (spread) TAP8_LAUNCH_KP(WGM, WGN, WMT, WN, RM, J1, true); else TAP8_LAUNCH_KP(WGM, WGN, WMT, WN, RM, J1, false); \
     } while (0)
 #define TAP8_LAUNCH(WGM, WGN, WMT, WN)                                                                                   \
     do {                                                                                                                \

@@ -5,6 +5,15 @@
 
 namespace ac {
 
+// Clearing the amax slots / row words: a kernel of the library's own, not hipMemsetAsync.  A memset node captured into a hipGraph does not
+// replay reliably on this runtime (ROCm 7.0.2 / HIP 7.0.51831: after the first replay part of the range holds garbage --
+// tools/experiments/r5i_memset_in_graph.py), and slots that are not cleared keep the atomicMax of every earlier replay: a captured
+// encode replayed on NEW data was wrong by 0.5 absolute (tools/experiments/r5j_graph_newdata.py) while every test that replayed the data it
+// had captured with stayed green.  16 bytes per thread; n16 = number of 16-byte units.
+__global__ __launch_bounds__(256) void zero16_kernel(s16_f32x4* __restrict__ p, size_t n16) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) p[i] = s16_f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
 // Fallback for tensors whose producer reports no amax: slot[b] = max |x[b]| over [L][C] rows of pitch ts.
 __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, long long bs, long long ts, int L, int C, unsigned* __restrict__ slot) {
     const int b = blockIdx.y;

@@ -59,8 +59,8 @@ __device__ __forceinline__ void t8_wait() {
 // RM: row mode (a linear layer over a merged row matrix: one split16 scale per ROW instead of per clip) -- a compile-time copy of
 // TapGemmParams::amax_rows, so that the per-slot scale registers exist only where they are needed
 // J1: the segment has ONE tap (two activation register sets); otherwise J >= 2 (one set) -- see the main loop
-// PP: the "ping-pong" main loop (round 5, below) instead of the lock-step one
-template <int WGM, int WGN, int WMT, int WN, bool RM, bool J1, bool PP = true>
+// SPREAD: the stage's requests are issued between its MFMA units instead of at its top (round 5, `tasks` below)
+template <int WGM, int WGN, int WMT, int WN, bool RM, bool J1, bool SPREAD = true>
 __global__ __launch_bounds__(512, 1) void tap_gemm8_kernel(const TapGemmParams p, const __bf16* __restrict__ wp) {
     using Cfg = Tap8Cfg<WGM, WGN, WMT, WN>;
     constexpr int BM = Cfg::BM, BN = Cfg::BN, NT = Cfg::NT, A_SLOTS = Cfg::A_SLOTS, PLANE = Cfg::PLANE, NTILES = Cfg::NTILES;
@@ -92,10 +92,13 @@ __global__ __launch_bounds__(512, 1) void tap_gemm8_kernel(const TapGemmParams p
     int t8_stage = 0;
     if (t6_ph) p.clk[4] = clk_t0;
 #define T8_STAMP(k) do { if (t8_on && t8_stage < 16) p.clk[16 + (wave * 16 + t8_stage) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+    // unit stamps of stages 2 and 3 (one that writes a slab, one that requests a chunk when J = 2): word 5 / 6 of the stage slots 8 + u
+#define T8_USTAMP(u) do { if (t8_on && (t8_stage == 2 || t8_stage == 3) && (u) < 8) p.clk[16 + (wave * 16 + 8 + (u)) * 8 + 3 + t8_stage] = __builtin_amdgcn_s_memtime(); } while (0)
     T6_PHASE(1);
 #else
     const bool t6_ph = false;
 #define T8_STAMP(k) do { } while (0)
+#define T8_USTAMP(u) do { } while (0)
 #endif
 
     // ---- the one segment (wave-uniform)
@@ -186,6 +189,22 @@ __global__ __launch_bounds__(512, 1) void tap_gemm8_kernel(const TapGemmParams p
             for (int i = 0; i < A_SLOTS; ++i) ra[i] = bufload16(a_rs, voff[i], 0);
         }
     };
+    // the same, ONE slot (SPREAD: the requests of a stage sit between its MFMA units)
+    auto load_slot = [&](int c, bool live, f32x4 (&ra)[A_SLOTS], int i) {
+        const int c_ = c * KC;
+        if (seg_interior || !live) {
+            const int soff = __builtin_amdgcn_readfirstlane(live ? c_ * 4 : 0);
+            const __amdgpu_buffer_rsrc_t rs = live ? a_rs : a_rs_null;
+            ra[i] = bufload16(rs, a_boff[i], soff);
+        } else {
+            const int e = tid + i * NT;
+            const int row = e / (KC / 4), q = e % (KC / 4);
+            const int cc = c_ + 4 * q;
+            const int tp = sg.cin_shift >= 0 ? (cc >> sg.cin_shift) : (cc / sg.cin);
+            const long long jj = row < R ? src_index(sg, (m0 + row) * sg.s + tp - sg.pad) : -1;
+            ra[i] = bufload16(a_rs, jj < 0 ? A_OOB : (int)((jj * sg.ts + (cc - tp * sg.cin)) * 4), 0);
+        }
+    };
     // slot i of a landed chunk: split (split16.h) and written to the slab.  One slot at a time, so that the work can sit between the
     // MFMAs of a stage (compute's hook) instead of behind them
     auto store_slot = [&](const f32x4 (&ra)[A_SLOTS], __bf16* dst, int i) {
@@ -213,6 +232,13 @@ __global__ __launch_bounds__(512, 1) void tap_gemm8_kernel(const TapGemmParams p
             const int ks = f / (2 * NTILES), t = (f / 2) % NTILES, pl = f % 2;
             t8_glds16(wtile + ((long long)t * ksteps + k0 + ks) * 1024 + pl * 512, bs_lds + (unsigned)((slot * Cfg::B_PIECES + f) * 1024));
         }
+    };
+
+    auto issue_piece = [&](int c, int j, int slot, int i) {
+        const int k0 = (seg_kofs + j * seg_Cw + c * KC) >> 4;
+        const int f = wave * Cfg::PPW + i;
+        const int ks = f / (2 * NTILES), t = (f / 2) % NTILES, pl = f % 2;
+        t8_glds16(wtile + ((long long)t * ksteps + k0 + ks) * 1024 + pl * 512, bs_lds + (unsigned)((slot * Cfg::B_PIECES + f) * 1024));
     };
 
     // ---- fragment reads + MFMAs of one stage: slab `abuf`, tap row offset `jr`, ring slot `slot`
@@ -252,6 +278,7 @@ __global__ __launch_bounds__(512, 1) void tap_gemm8_kernel(const TapGemmParams p
             }
             hook(u);                                   // (same scheduling region as the unit's MFMAs: VALU / LDS-write work issues in their shadow)
             __builtin_amdgcn_sched_barrier(0);
+            T8_USTAMP(u);
         }
     };
     auto no_hook = [](int) {};
@@ -266,6 +293,39 @@ __global__ __launch_bounds__(512, 1) void tap_gemm8_kernel(const TapGemmParams p
         }
     };
 
+    // SPREAD (round 5).  With every request at the top of a stage, all eight waves spent its first 600 - 1 200 cycles pushing 9 vector-memory
+    // instructions each through the CU's one address path -- no wave of a SIMD had an MFMA to issue -- and the younger wave of each pair
+    // then ran the tail of the stage alone (s_memtime stamps, profiles/r5a_lockstep_trace.txt: a 256 x 256 stage of 3 072 matrix cycles per
+    // SIMD took 4 650).  Now the stage's work items -- [weight pieces of stage s + 1][activation slots of chunk c + 2][slab writes of chunk
+    // c + 1] -- are dealt over the stage's units IN THAT ORDER, one or two behind each unit's MFMAs: the first MFMA of a stage waits for
+    // its fragment reads only.  The counted wait is unchanged: the weight pieces still precede the activation slots in program order.
+    // Measured (profiles/r5c_spread_ab.txt, r5e_unit_trace.txt): 128 x 256 tiles -5.5 % (K = 4096), 256 x 256 within +-1 %, 256 x 128 with
+    // seven taps +19 % -- run_tap picks per form.  The unit stamps show where a stage's time goes: a unit (6 MFMAs, 146 matrix ticks, 292
+    // with the partner wave's) takes ~330 by itself, +150..400 on the wave that issues an LDS-DMA piece in it (the request arbitrates for
+    // the LDS beside sixteen waves' fragment reads), +0..50 with a buffer load, ~+200 with a slab slot (15 VALU, 2 ds_write_b64).  Also
+    // built and measured, not kept: the weight stage through registers (buffer loads + ds_write_b128: +3..7 % -- hipcc's own vmcnt waits
+    // for the ring writes drain the activation requests, profiles/r5f_wreg_ab.txt) and the "ping-pong" loop (SIMD partners one segment
+    // apart, load segments and pure-MFMA segments between workgroup barriers: +4..23 %, the load segments take 1 150 - 1 800 ticks against
+    // a compute segment's 583 -- profiles/r5b_pingpong_ab.txt); the MFMA stream itself runs at 24.3 ticks per MFMA per SIMD at ANY
+    // distance between dependent MFMAs and with LDS reads / VALU between them (tools/ubench/mfma_dep_distance.hip).
+    auto tasks = [&](int u, bool has_next, int nc, int nj, int nslot, bool issue, int creq, f32x4 (&ra_req)[A_SLOTS], bool store, const f32x4 (&ra_st)[A_SLOTS], __bf16* dst,
+                     auto issue_tag, auto store_tag) {
+        constexpr bool ISSUE = decltype(issue_tag)::value, STORE = decltype(store_tag)::value;
+        constexpr int NTASK = Cfg::PPW + (ISSUE ? A_SLOTS : 0) + (STORE ? A_SLOTS : 0);
+        const int lo = u * NTASK / UNITS, hi = (u + 1) * NTASK / UNITS;
+#pragma unroll
+        for (int t = 0; t < NTASK; ++t) {
+            if (t < lo || t >= hi) continue;
+            if (t < Cfg::PPW) {
+                if (has_next) issue_piece(nc, nj, nslot, t);
+            } else if (ISSUE && t < Cfg::PPW + A_SLOTS) {
+                load_slot(creq, issue, ra_req, t - Cfg::PPW);
+            } else {
+                if (store) store_slot(ra_st, dst, t - Cfg::PPW - (ISSUE ? A_SLOTS : 0));
+            }
+        }
+    };
+
     using T = std::true_type;
     using F = std::false_type;
     // (the scales are in registers before the first LDS-DMA request goes out: the compiler's wait for ITS amax load would otherwise
@@ -275,116 +335,7 @@ __global__ __launch_bounds__(512, 1) void tap_gemm8_kernel(const TapGemmParams p
 #ifdef T6_TRACE
     T6_PHASE(2);
 #endif
-    if constexpr (PP) {
-        // ---- round 5: the two waves of a SIMD in OPPOSITE phases ("ping-pong").  What the lock-step loop below loses (s_memtime stamps
-        // of a -DT6_TRACE build, profiles/r5_tapgemm8_pingpong.md): all eight waves start a stage together, so for the first 600 - 1200
-        // cycles of every stage -- weight requests, activation requests, the first fragment reads -- NO wave of a SIMD has an MFMA to
-        // issue, the older wave of each pair then takes the matrix pipe and waits ~1300 cycles at the stage barrier for the younger one:
-        // a stage of 3072 matrix cycles per SIMD takes 4650 (256 x 256 tiles; 1536 vs 3050 for 128 x 256).
-        // Here a k-step of a wave is a LOAD segment (fragment reads of that k-step into registers, plus the wave's share of the stage's
-        // requests / slab writes / the counted wait) followed by a COMPUTE segment (nothing but the k-step's 3 x WMT x WN MFMAs, operands
-        // already in registers), every segment ends at a workgroup barrier, and waves 4..7 -- the SIMD partners of waves 0..3 -- run ONE
-        // segment behind: whenever one wave of a SIMD is in a load segment its partner is in a compute segment and owns the matrix pipe.
-        // Interval t of the workgroup:  waves 0..3: L(i) at t = 2i, C(i) at 2i + 1;  waves 4..7: L(i) at 2i + 1, C(i) at 2i + 2.
-        // Hazards (stage s = k-steps 2s, 2s + 1; intervals 4s .. 4s + 3 for waves 0..3, one later for 4..7):
-        //   * ring slot (s + 1) & 1 was last read in L(2s - 1) of waves 4..7 (interval 4s - 1); stage s + 1's weights are requested at the
-        //     top of L(2s) (interval 4s / 4s + 1), counted-waited for at the bottom of L(2s + 1) (4s + 2 / 4s + 3) and first read in
-        //     interval 4s + 4, behind the barrier that ends 4s + 3;
-        //   * slab (c + 1) & 1 was last read in the last stage of chunk c - 1 (by waves 4..7 in the interval before chunk c's first); it
-        //     is written in L(2s + 1) of chunk c's FIRST stage and first read in chunk c + 1's first interval, at least two barriers later.
-        // The per-accumulator order of the products is the lock-step loop's (k-steps ascending; lo hi, hi lo, hi hi): bit-identical results.
-        const bool late = wave >= 4;
-        f16x8 bfr[2][WN], afr[2][WMT];                         // the fragments of ONE k-step: [plane][tile]
-        auto read_frags = [&](int abuf, int jr, int slot, int ks) {
-            const __bf16* Ac = As0 + abuf * 2 * PLANE + a_frag + jr * T6_PITCH + ks * 16;
-            const __bf16* Bc = Bs0 + slot * Cfg::B_SLOT + lane * 8 + (ks * NTILES + wn * WN) * 2 * 512;
-#pragma unroll
-            for (int c = 0; c < WN; ++c)
-#pragma unroll
-                for (int pl = 0; pl < 2; ++pl) bfr[pl][c] = *reinterpret_cast<const f16x8*>(Bc + (c * 2 + pl) * 512);
-#pragma unroll
-            for (int a = 0; a < WMT; ++a)
-#pragma unroll
-                for (int pl = 0; pl < 2; ++pl) afr[pl][a] = *reinterpret_cast<const f16x8*>(Ac + pl * PLANE + a * 32 * T6_PITCH);
-        };
-        auto mfmas = [&]() {
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int a = 0; a < WMT; ++a)
-#pragma unroll
-                for (int c = 0; c < WN; ++c) {   // lo hi, hi lo, hi hi: tap_gemm6's order
-                    f32x16 v = acc[a][c];
-                    v = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[1][a], bfr[0][c], v, 0, 0, 0);
-                    v = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[0][a], bfr[1][c], v, 0, 0, 0);
-                    acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[0][a], bfr[0][c], v, 0, 0, 0);
-                }
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        auto seg_barrier = [&]() {                             // end of a compute segment: nothing of this wave's is outstanding in LDS
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-        };
-        // one stage of a wave: L(2s) C(2s) L(2s + 1) C(2s + 1).  STORE: it writes the chunk in `ra` (requested a stage or more ago) to
-        // slab (c + 1) & 1; ISSUE_TOP / ISSUE_LATE: it requests chunk c + 2 into `ra` -- at the top of the stage (J >= 2: the chunk's last
-        // tap; `ra` was written out in the chunk's first tap), or in L(2s + 1) right behind the stage's own slab write (one tap per chunk:
-        // every stage writes AND requests, with ONE register set -- two sets, as the lock-step loop keeps, spill beside the k-step's
-        // 48 fragment registers; the request then has one stage, ~3 000 cycles, to arrive: such layers' operands are the merged token
-        // matrices of Mimi / WavTokenizer, 65 - 80 MB, resident in the 256 MB Infinity Cache)
-        f32x4 ra[A_SLOTS];
-        auto stage = [&](int c, int j, int s, bool has_next, int nc, int nj, auto top_tag, auto late_tag, auto store_tag) {
-            constexpr bool ISSUE_TOP = decltype(top_tag)::value, ISSUE_LATE = decltype(late_tag)::value, STORE = decltype(store_tag)::value;
-            T8_STAMP(0);
-            if (has_next) issue_b(nc, nj, (s + 1) & 1);
-            if constexpr (ISSUE_TOP) load_a(c + 2, c + 2 < NC, ra);
-            __builtin_amdgcn_sched_barrier(0);
-            read_frags(c & 1, j * rowstep, s & 1, 0);
-            lds_barrier();
-            T8_STAMP(1);
-            mfmas();
-            seg_barrier();
-            T8_STAMP(2);
-            read_frags(c & 1, j * rowstep, s & 1, 1);
-            if constexpr (STORE) {
-                if (c + 1 < NC) store_a(ra, As0 + ((c + 1) & 1) * 2 * PLANE);
-                else asm volatile("" ::"v"(ra[A_SLOTS - 1]));      // (the last slot's load stays outside every branch: store_slot's note)
-            }
-            if constexpr (ISSUE_LATE) {
-                __builtin_amdgcn_sched_barrier(0);
-                load_a(c + 2, c + 2 < NC, ra);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (ISSUE_TOP || ISSUE_LATE) t8_wait<A_SLOTS>(); else t8_wait<0>();
-            lds_barrier();
-            T8_STAMP(3);
-            mfmas();
-            seg_barrier();
-            T8_STAMP(4);
-#ifdef T6_TRACE
-            ++t8_stage;
-#endif
-        };
-        issue_b(0, 0, 0);
-        load_a(0, true, ra);
-        store_a(ra, As0);
-        load_a(1, NC > 1, ra);              // (chunk 1 has only the first stage to arrive: once per tile)
-        t8_wait<A_SLOTS>();
-        lds_barrier();
-#ifdef T6_TRACE
-        T6_PHASE(6);
-#endif
-        if (late) seg_barrier();
-        if constexpr (J1) {
-            for (int c = 0; c < NC; ++c) stage(c, 0, c, c + 1 < NC, c + 1, 0, F{}, T{}, T{});
-        } else {
-            for (int c = 0; c < NC; ++c) {
-                const int s0 = c * seg_J;
-                stage(c, 0, s0, true, c, 1, F{}, F{}, T{});
-                for (int j = 1; j < seg_J - 1; ++j) stage(c, j, s0 + j, true, c, j + 1, F{}, F{}, F{});
-                stage(c, seg_J - 1, s0 + seg_J - 1, c + 1 < NC, c + 1, 0, T{}, F{}, F{});
-            }
-        }
-        if (!late) seg_barrier();
-    } else if constexpr (J1) {
+    if constexpr (J1) {
         // ---- ONE tap per chunk (linear layers, 1 x 1 convs): every stage is a new chunk.  Two register sets: chunk c + 2 is requested at
         // the top of stage c into the free set, chunk c + 1 (the other set, requested a stage earlier) is written to its slab at the
         // bottom.  The stage's single wait leaves exactly this stage's activation requests in flight: two stages of latency budget.
@@ -400,14 +351,19 @@ __global__ __launch_bounds__(512, 1) void tap_gemm8_kernel(const TapGemmParams p
 #endif
         auto stage = [&](int c, f32x4 (&ra_next)[A_SLOTS], f32x4 (&ra_free)[A_SLOTS]) {
             T8_STAMP(0);
-            if (c + 1 < NC) issue_b(c + 1, 0, (c + 1) & 1);
-            load_a(c + 2, c + 2 < NC, ra_free);
-            __builtin_amdgcn_sched_barrier(0);
-            T8_STAMP(1);
             const bool st = c + 1 < NC;
             __bf16* dst = As0 + ((c + 1) & 1) * 2 * PLANE;
-            // the slots of chunk c + 1 are split and written between the MFMAs of the stage's last A_SLOTS units
-            compute(c & 1, 0, c & 1, [&](int u) { store_hook(ra_next, dst, st, u); });
+            if constexpr (SPREAD) {
+                T8_STAMP(1);
+                compute(c & 1, 0, c & 1, [&](int u) { tasks(u, c + 1 < NC, c + 1, 0, (c + 1) & 1, c + 2 < NC, c + 2, ra_free, st, ra_next, dst, T{}, T{}); });
+            } else {
+                if (c + 1 < NC) issue_b(c + 1, 0, (c + 1) & 1);
+                load_a(c + 2, c + 2 < NC, ra_free);
+                __builtin_amdgcn_sched_barrier(0);
+                T8_STAMP(1);
+                // the slots of chunk c + 1 are split and written between the MFMAs of the stage's last A_SLOTS units
+                compute(c & 1, 0, c & 1, [&](int u) { store_hook(ra_next, dst, st, u); });
+            }
             __builtin_amdgcn_sched_barrier(0);
             T8_STAMP(2);
             t8_wait<A_SLOTS>();
@@ -443,6 +399,12 @@ __global__ __launch_bounds__(512, 1) void tap_gemm8_kernel(const TapGemmParams p
             int nc = c, nj = j + 1;
             if (nj == seg_J) { nj = 0; nc = c + 1; }
             T8_STAMP(0);
+            if constexpr (SPREAD) {
+                T8_STAMP(1);
+                const bool st = c + 1 < NC;
+                __bf16* dst = As0 + ((c + 1) & 1) * 2 * PLANE;
+                compute(c & 1, j * rowstep, s & 1, [&](int u) { tasks(u, nc < NC, nc, nj, (s + 1) & 1, c + 2 < NC, c + 2, ra, st, ra, dst, issue_tag, store_tag); });
+            } else {
             if (nc < NC) issue_b(nc, nj, (s + 1) & 1);
             if (ISSUE) load_a(c + 2, c + 2 < NC, ra);
             __builtin_amdgcn_sched_barrier(0);
@@ -453,6 +415,7 @@ __global__ __launch_bounds__(512, 1) void tap_gemm8_kernel(const TapGemmParams p
                 compute(c & 1, j * rowstep, s & 1, [&](int u) { store_hook(ra, dst, st, u); });
             } else {
                 compute(c & 1, j * rowstep, s & 1, no_hook);
+            }
             }
             __builtin_amdgcn_sched_barrier(0);
             T8_STAMP(2);
@@ -473,6 +436,7 @@ __global__ __launch_bounds__(512, 1) void tap_gemm8_kernel(const TapGemmParams p
 
     tap6_epilogue<WGM, WGN, WMT, WN, HALO>(p, acc, smem, b, m0, n0, a_inv, rowmode, clk_t0, clk_r0, t6_ph);
 #undef T8_STAMP
+#undef T8_USTAMP
 }
 
 }  // namespace ac

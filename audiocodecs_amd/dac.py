@@ -134,6 +134,7 @@ class DAC(Codec):
         config: Optional[DacConfig] = None,
         precision: Optional[str] = None,
         strict: bool = False,
+        graph: bool = False,
     ):
         """`state_dict`: HF `DacModel.state_dict()` names, or descript's own (`weights.pth["state_dict"]`, detected
         by its `weight_g` keys and converted by :func:`state_dict_from_descript`), or
@@ -141,6 +142,7 @@ class DAC(Codec):
         through `dac.utils.download` (dac.py:56) -- that package is not a dependency here, so it must be given."""
         super().__init__(sample_rate, orig_sample_rate, mode)
         self.strict = bool(strict)   # codec.py: poll the handle after every call
+        self.graph = bool(graph)     # codec.py: replay one hipGraph per (call, shape)
         self.num_codebooks = num_codebooks
         self.vocab_size = 1024  # dac.py:52
         self.latent = latent

@@ -89,6 +89,7 @@ class _Native:
 
 class Encodec(Codec):
     _accepts_none_length = True
+    _graph_capable = False        # codec.py: the persistent LSTM launch is not replayable from a hipGraph
 
     def __init__(
         self,
@@ -102,6 +103,7 @@ class Encodec(Codec):
         config: EncodecConfig = ENCODEC_24KHZ,
         precision: Optional[str] = None,
         strict: bool = False,
+        graph: bool = False,
     ):
         """`state_dict`: an HF-format EncodecModel state dict (keys of SURVEY.md Appendix A.3, e.g.
         `safetensors.torch.load_file(model.safetensors)` of facebook/encodec_24khz, or
@@ -111,6 +113,7 @@ class Encodec(Codec):
         "fp32_exact" = exact fp32 products (include/audiocodecs_amd.h ac_set_precision)."""
         super().__init__(sample_rate, orig_sample_rate, mode)
         self.strict = bool(strict)   # codec.py: poll the handle after every call
+        self.graph = bool(graph)     # codec.py: replay one hipGraph per (call, shape)
         self.precision = _native.check_precision(precision)
         if use_vocos:
             raise NotImplementedError("the Vocos decoder variant (encodec.py:53-66) is outside the MI355X path")

@@ -90,12 +90,14 @@ class Mimi(Codec):
         config: MimiConfig = MIMI_24KHZ,
         precision: Optional[str] = None,
         strict: bool = False,
+        graph: bool = False,
     ):
         """`state_dict`: an HF-format MimiModel state dict (`safetensors.torch.load_file` of kyutai/mimi's
         model.safetensors, or `checkpoint.synthetic_mimi_state_dict(cfg, seed)`); fetched through
         huggingface_hub like the reference when omitted (needs network or a warm cache)."""
         super().__init__(sample_rate, config.sampling_rate, mode)  # mimi.py:38
         self.strict = bool(strict)   # codec.py: poll the handle after every call
+        self.graph = bool(graph)     # codec.py: replay one hipGraph per (call, shape)
         self.num_codebooks = num_codebooks
         self.vocab_size = config.codebook_size  # 2048 (mimi.py:40)
         self.latent = latent

@@ -80,6 +80,7 @@ class _NativeWavTok:
 
 class WavTokenizer(Codec):
     _accepts_none_length = True
+    _graph_capable = False        # codec.py: the persistent LSTM launch is not replayable from a hipGraph
     SOURCES = [
         "novateur/WavTokenizer-large-unify-40token",
         "novateur/WavTokenizer-large-speech-75token",
@@ -105,6 +106,7 @@ class WavTokenizer(Codec):
         arch: Optional[WavTokenizerConfig] = None,
         precision: Optional[str] = None,
         strict: bool = False,
+        graph: bool = False,
     ):
         """`state_dict`: the `state_dict` of the upstream Lightning checkpoint (keys feature_extractor.* / backbone.* /
         head.*), or `checkpoint.synthetic_wavtok_state_dict(arch, seed)`; when omitted it is fetched through
@@ -112,6 +114,7 @@ class WavTokenizer(Codec):
         architecture the YAML `config` describes (default: picked from the config's name -- frame40 / frame75)."""
         super().__init__(sample_rate, 24000, mode)  # wavtokenizer.py:68
         self.strict = bool(strict)   # codec.py: poll the handle after every call
+        self.graph = bool(graph)     # codec.py: replay one hipGraph per (call, shape)
         if arch is None:
             arch = WAVTOK_75 if "frame75" in config else WAVTOK_40
         self.num_codebooks = 1

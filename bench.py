@@ -25,7 +25,8 @@ and, at N = 1, outside the timed region (all skipped by --no-parity):
                             WavTokenizer 64 x 10 s): value, ms_per_step, roofline (dominant kernel family) and parity gate of a
                             short (1 + 3 step) run each
   latency                -- the reference's own measurement regime (batch 1, its profiler's clip lengths): encode + decode of
-                            B = 1 / 8 clips of 1 / 10 / 32 s, ms per call, RTF, top-3 kernels
+                            B = 1 / 8 clips of 1 / 10 / 32 s, ms per call, RTF, top-3 kernels (other_configs.{mimi,dac}.batch1_latency: 1 x 1 s eager
+                            and through the wrappers' opt-in hipGraph replay, graph=True; the LSTM codecs decline it, audiocodecs_amd/codec.py)
 Nothing inside an `if rank == 0` block issues a collective (tests/test_bench_contract.py checks the source for it), and the
 flow from the warm-ups to the JSON line is `run()`, which tests/test_bench_flow_gloo.py executes at world size 2 over gloo.
 """
@@ -264,7 +265,7 @@ CODEC_LABEL = {"mimi": "Mimi-24k", "dac": "DAC-44.1k", "encodec": "EnCodec-24k",
 CODEC_NCB = {"dac": 9, "wavtokenizer": 1, "mimi": 8, "encodec": 8}
 
 
-def build_codec(name, precision=None):
+def build_codec(name, precision=None, graph=False):
     """(codec, cfg, state dict) of one of the four wrappers on seeded synthetic weights of the full architecture."""
     from audiocodecs_amd import DAC, Encodec, Mimi, WavTokenizer, checkpoint
     from audiocodecs_amd.config import DAC_44KHZ, ENCODEC_24KHZ, MIMI_24KHZ, WAVTOK_40
@@ -272,10 +273,10 @@ def build_codec(name, precision=None):
     cfg = {"mimi": MIMI_24KHZ, "dac": DAC_44KHZ, "encodec": ENCODEC_24KHZ, "wavtokenizer": WAVTOK_40}[name]
     if name == "mimi":
         sd = checkpoint.synthetic_mimi_state_dict(cfg, seed=0)
-        codec = Mimi(cfg.sampling_rate, num_codebooks=8, state_dict=sd, precision=precision).eval()
+        codec = Mimi(cfg.sampling_rate, num_codebooks=8, state_dict=sd, precision=precision, graph=graph).eval()
     elif name == "dac":
         sd = checkpoint.synthetic_dac_state_dict(cfg, seed=0)
-        codec = DAC(cfg.sampling_rate, cfg.sampling_rate, num_codebooks=9, state_dict=sd, config=cfg, precision=precision).eval()
+        codec = DAC(cfg.sampling_rate, cfg.sampling_rate, num_codebooks=9, state_dict=sd, config=cfg, precision=precision, graph=graph).eval()
     elif name == "wavtokenizer":
         sd = checkpoint.synthetic_wavtok_state_dict(cfg, seed=0)
         codec = WavTokenizer(cfg.sampling_rate, state_dict=sd, arch=cfg, precision=precision).eval()
@@ -396,6 +397,23 @@ def short_run(name, batch, seconds, steps, warmup, precision=None):
         torch.cuda.synchronize()
         dt_prof = time.perf_counter() - t1
         gate = parity_gate(name, codec)
+        b1 = None
+        if name in ("mimi", "dac"):     # batch 1 x 1 s, eager against the wrapper's hipGraph replay (median of 5 after 3 calls: the first captures)
+            b1 = {}
+            one = sig[:1, : cfg.sampling_rate].contiguous()
+            for label, c_ in (("eager_ms", codec), ("graph_ms", build_codec(name, precision, graph=True)[0])):
+                for _ in range(3):
+                    c_.toks_to_sig(c_.sig_to_toks(one))
+                torch.cuda.synchronize()
+                ts = []
+                for _ in range(5):
+                    t2 = time.perf_counter()
+                    c_.toks_to_sig(c_.sig_to_toks(one))
+                    torch.cuda.synchronize()
+                    ts.append(time.perf_counter() - t2)
+                b1[label] = round(sorted(ts)[2] * 1e3, 3)
+                if c_ is not codec:
+                    drop_codec(c_)
     del sig
     drop_codec(codec)
     audio_s = batch * T / cfg.sampling_rate * steps
@@ -403,7 +421,7 @@ def short_run(name, batch, seconds, steps, warmup, precision=None):
             "value": round(audio_s / dt, 1), "unit": "audio-s/s", "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps, "warmup": warmup,
             "roofline": roofline_of(stats, dt_prof, 1, name, batch, precision == "fp32_exact"),
             "whole_path": whole_path(stats, dt_prof, sum(s_[4] for s_ in stats)),
-            "top_kernels": kernel_rows(stats, 1, top=4), "parity": gate}
+            "top_kernels": kernel_rows(stats, 1, top=4), "parity": gate, "batch1_latency": b1}
 
 
 def latency_regime(codec, cfg):

@@ -29,11 +29,11 @@ def test_tap_gemm8_is_bit_identical_to_tap_gemm6(name, B, T):
     with torch.no_grad():
         codec.sig_to_toks(sig[:1])               # creates the handle
         ref = None
-        # (tap8_pp: the ping-pong main loop of round 5 / the lock-step one -- the same products in the same order per accumulator)
-        for tap8, form, pp in ((0, 0, 1), (1, 0, 1), (1, 1, 1), (1, 2, 1), (1, 3, 1), (-1, 0, 1), (1, 1, 0), (1, 2, 0), (1, 3, 0), (-1, 0, 0)):
+        # (tap8_spread 2 / 0: a stage's requests dealt between its MFMA units (round 5) everywhere / all at its top; 1: per tile form)
+        for tap8, form, pp in ((0, 0, 1), (1, 0, 1), (1, 1, 2), (1, 2, 2), (1, 3, 2), (-1, 0, 1), (1, 1, 0), (1, 2, 0), (1, 3, 0), (-1, 0, 0)):
             debug_set(codec, "tap8", tap8)
             debug_set(codec, "tap8_form", form)
-            debug_set(codec, "tap8_pp", pp)
+            debug_set(codec, "tap8_spread", pp)
             names = {s[0].split("<")[0] for s in codec.profile_kernels(lambda: codec.toks_to_sig(codec.sig_to_toks(sig)))}
             if tap8 == 0:
                 assert "tap_gemm8_kernel" not in names
@@ -50,4 +50,4 @@ def test_tap_gemm8_is_bit_identical_to_tap_gemm6(name, B, T):
             assert torch.equal(rec, ref[2]), (name, tap8, form, pp)
         debug_set(codec, "tap8", -1)
         debug_set(codec, "tap8_form", 0)
-        debug_set(codec, "tap8_pp", 1)
+        debug_set(codec, "tap8_spread", 1)

@@ -37,6 +37,14 @@ for name, shp, side in SHAPES:
         if not ok.any(): continue
         d = np.stack([st[ok, 1] - st[ok, 0], st[ok, 2] - st[ok, 1], st[ok, 3] - st[ok, 2], st[ok, 4] - st[ok, 3], st[ok, 4] - st[ok, 0]], 1)
         print(f"   wave {w}: {int(ok.sum())} stages; mean issue {d[:,0].mean():.0f} compute {d[:,1].mean():.0f} wait {d[:,2].mean():.0f} barrier {d[:,3].mean():.0f} | stage {d[:,4].mean():.0f} (max {d[:,4].max()}, min {d[:,4].min()})")
+    for sidx, word in ((2, 5), (3, 6)):      # unit stamps of stages 2 and 3: deltas between the units of each wave
+        rows = []
+        for w in range(8):
+            us = a[w, 8:16, word]
+            if us[0] and a[w, sidx, 1]:
+                t = np.concatenate([[a[w, sidx, 1]], us])
+                rows.append(f"w{w}: " + " ".join(f"{int(x):4d}" for x in np.diff(t)))
+        if rows: print(f"   stage {sidx} units (cycles from the stage's start / previous unit, per wave): " + " | ".join(rows))
     w = 1
     st = a[w]
     for s_ in range(16):
