@@ -384,6 +384,14 @@ __device__ __forceinline__ void tap6_mainloop(const TapGemmParams& p, const __bf
     const int mt = id % p.mtiles;
     const int b = id / p.mtiles;
     const int m0 = mt * BM, n0 = nt * BN;
+    // The clip's amax word(s) are REQUESTED here, as soon as the clip is known, and used when the first chunk is split (store_a): the
+    // ISA of round 4 had `global_load_dword` / `s_waitcnt vmcnt(0)` back to back in front of the tile's first activation request -- one
+    // exposed L2 round trip per tile (round-5 ISA reading; the kernel-argument s_loads in front of it are hipcc's own business).
+    // (NO request under a condition -- a loaded register that is carried on the other path becomes a copy at the join, and the copy waits
+    //  for the load: the second segment's word is the first segment's again when there is none; in row mode seg[0].amax is the row-word
+    //  array and b = 0, so the word read here exists and is simply not used)
+    const unsigned am_e0 = *amax_at(p.seg[0].amax, b);
+    const unsigned am_e1 = *amax_at(p.seg[p.nseg > 1 ? 1 : 0].amax, b);
 #ifdef T6_TRACE   // developer build: phase stamps of wave 1 of one workgroup (p.clk[4..15]), stage stamps below
     const bool t6_ph = p.clk && mt == p.mtiles / 2 && nt == 0 && b == p.B / 2 && tid == 64;      // an interior tile
     if (t6_ph) p.clk[4] = clk_t0;
@@ -458,23 +466,25 @@ __device__ __forceinline__ void tap6_mainloop(const TapGemmParams& p, const __bf
     float a_scale = 1.f, a_inv = 1.f;
     float a_rsc[NRSC];
     const bool rowmode = CAN_ROWMODE && NP == 2 && p.amax_rows;
-    if (NP == 2) {
+    unsigned am_rows[NRSC];              // row mode: the rows' words, requested here (unconditionally: word 0 otherwise), used in set_scales
+#pragma unroll
+    for (int i = 0; i < NRSC; ++i) {
+        const int m = m0 + (tid + i * NT) / (KC / 4);
+        am_rows[i] = p.seg[0].amax[rowmode ? (m < p.M ? m : p.M - 1) : 0];
+    }
+    auto set_scales = [&]() {
         if (!rowmode) {
-            unsigned am = *amax_at(p.seg[0].amax, b);
-            if (p.nseg > 1) { const unsigned a1 = *amax_at(p.seg[1].amax, b); am = a1 > am ? a1 : am; }
-            const int se = s16_exponent(am);
+            // (through a VGPR-constrained asm: hipcc otherwise moves the wave-uniform words to SGPRs -- v_readfirstlane, and the wait with it --
+            //  right behind their loads)
+            unsigned a0 = am_e0, a1 = am_e1;
+            asm volatile("" : "+v"(a0), "+v"(a1));
+            const int se = s16_exponent(a1 > a0 ? a1 : a0);
             a_scale = s16_pow2(se);
             a_inv = s16_pow2(-se);
         }
 #pragma unroll
-        for (int i = 0; i < NRSC; ++i) {
-            a_rsc[i] = a_scale;
-            if (rowmode) {
-                const int m = m0 + (tid + i * NT) / (KC / 4);
-                a_rsc[i] = s16_pow2(s16_exponent(p.seg[0].amax[m < p.M ? m : p.M - 1]));
-            }
-        }
-    }
+        for (int i = 0; i < NRSC; ++i) a_rsc[i] = rowmode ? s16_pow2(s16_exponent(am_rows[i])) : a_scale;
+    };
     f32x4 ra[A_SLOTS];
     // Exactly A_SLOTS buffer loads, whatever the stage needs (see `stage` below for why the COUNT must not depend on the path):
     //   interior tile : the per-slot offsets of enter_segment + one scalar offset for the chunk / tap
@@ -546,6 +556,8 @@ __device__ __forceinline__ void tap6_mainloop(const TapGemmParams& p, const __bf
 #ifdef T6_TRACE
     T6_PHASE(4);
 #endif
+    __builtin_amdgcn_sched_barrier(0);      // (the scale arithmetic -- the first use of the amax words -- stays behind the requests)
+    set_scales();
     store_a(As0);
 #ifdef T6_TRACE
     T6_PHASE(5);

@@ -103,6 +103,9 @@ __global__ __launch_bounds__(512, 1) void tap_gemm8_kernel(const TapGemmParams p
 
     // ---- the one segment (wave-uniform)
     const TapSeg& sg = p.seg[0];
+    // (the clip's amax word is requested HERE and used ~1 000 cycles of index arithmetic later, where the scales are set: the ISA of round 4
+    //  had the request and its s_waitcnt vmcnt(0) back to back in front of the tile's first weight request)
+    const unsigned am_early = RM ? 0u : *amax_at(sg.amax, b);
     const int seg_J = sg.J, seg_Cw = sg.s * sg.cin, seg_kofs = sg.kofs, rowstep = sg.dil;
     const int NC = seg_Cw / KC;                                  // activation chunks; stages = NC * J
     const long long lo_t = (long long)m0 * sg.s - sg.pad;
@@ -136,11 +139,16 @@ __global__ __launch_bounds__(512, 1) void tap_gemm8_kernel(const TapGemmParams p
         a_boff[i] = (int)((t * tsf + 4 * q) * 4);
     }
     // split16 scales: one per clip, or one per row of the merged row matrix (row mode)
+    __builtin_amdgcn_sched_barrier(0);        // (the first use of am_early stays HERE, behind the index arithmetic above, not next to its request)
     float a_scale = 1.f, a_inv = 1.f;
     float a_rsc[RM ? A_SLOTS : 1];
     constexpr bool rowmode = RM;
     if (!RM) {
-        const int se = s16_exponent(*amax_at(sg.amax, b));
+        // (through a VGPR-constrained asm: hipcc otherwise moves the wave-uniform word to an SGPR -- v_readfirstlane, and the wait with it --
+        //  right behind the load)
+        unsigned am = am_early;
+        asm volatile("" : "+v"(am));
+        const int se = s16_exponent(am);
         a_scale = s16_pow2(se);
         a_inv = s16_pow2(-se);
         a_rsc[0] = a_scale;
