@@ -257,9 +257,11 @@ def measured_traffic(kernel_name, unit, codec="encodec", batch=64):
             ks = json.load(open(f))["kernels"]
         except Exception:
             continue
-        for nm, k in ks.items():
-            if canonical_kernel(nm) == want and k.get("hbm_bytes_per_launch") is not None:
-                return round(k["hbm_bytes_per_launch"]), "profiles/" + os.path.basename(f)
+        # (several instantiations can share a canonical name -- tap_gemm8's row-mode / one-tap / request-placement flags: launch-weighted mean)
+        hits = [(k.get("launches", 1), k["hbm_bytes_per_launch"]) for nm, k in ks.items()
+                if canonical_kernel(nm) == want and k.get("hbm_bytes_per_launch") is not None]
+        if hits:
+            return round(sum(n_ * b_ for n_, b_ in hits) / sum(n_ for n_, _ in hits)), "profiles/" + os.path.basename(f)
     return None
 
 
