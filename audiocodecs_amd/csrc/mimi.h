@@ -68,11 +68,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LayerNormParams p)
         }
     }
     if (p.rowmax) {
-#pragma unroll
-        for (int sh = 1; sh < 64; sh <<= 1) {
-            const unsigned t = (unsigned)__shfl_xor((int)rmax, sh);
-            rmax = t > rmax ? t : rmax;
-        }
+        rmax = group_max_u32<64>(rmax);
         if (lane == 0) p.rowmax[row] = rmax;
     }
 }
@@ -321,11 +317,7 @@ __global__ __launch_bounds__(256, 2) void attention16_kernel(const AttnParams p)
                 amax_acc(am, ra[u][e]);
                 amax_acc(am, rb[u][e]);
             }
-#pragma unroll
-        for (int sh = 1; sh < 64; sh <<= 1) {
-            const unsigned t = (unsigned)__shfl_xor((int)am, sh);
-            am = t > am ? t : am;
-        }
+        am = group_max_u32<64>(am);
         const int eq = s16_exponent(am);
         iq = s16_pow2(-eq);
         split16_pack8(ra[0], ra[1], s16_pow2(eq), qh[0], ql[0]);
@@ -382,12 +374,8 @@ __global__ __launch_bounds__(256, 2) void attention16_kernel(const AttnParams p)
             }
 #pragma unroll
         for (int r = 0; r < 4; ++r) amax_acc4(amv, vv[r]);
-#pragma unroll
-        for (int sh = 1; sh < 64; sh <<= 1) {
-            const unsigned t1 = (unsigned)__shfl_xor((int)amk, sh), t2 = (unsigned)__shfl_xor((int)amv, sh);
-            amk = t1 > amk ? t1 : amk;
-            amv = t2 > amv ? t2 : amv;
-        }
+        amk = group_max_u32<64>(amk);
+        amv = group_max_u32<64>(amv);
         unsigned* sl = slot + (jt % 3) * 2;
         if (lane == 0) { atomicMax(sl, amk); atomicMax(sl + 1, amv); }
         __syncthreads();                                       // A: maxima complete; every wave is done with the previous tile's planes

@@ -63,13 +63,32 @@ __device__ __forceinline__ void amax_acc(unsigned& mx, float v) {
 __device__ __forceinline__ void amax_acc4(unsigned& mx, const s16_f32x4 v) {
     amax_acc(mx, v.x); amax_acc(mx, v.y); amax_acc(mx, v.z); amax_acc(mx, v.w);
 }
+// Maximum over aligned groups of LANES lanes (2 .. 64, a power of two), delivered to EVERY lane of the group -- what the xor butterfly of
+// __shfl_xor computes, without its LDS round trips: __shfl_xor is ds_bpermute_b32 (~120+ cycles each, waited for one by one: five of them per
+// row and store-loop iteration were ~0.6 k of the ~2.5 k cycles an iteration of the row-mode epilogue took, round-5 trace of Mimi's linear
+// layers).  Inside a row of 16 lanes the exchanges are DPP modifiers of the v_max itself (quad_perm xor 1, xor 2, row_half_mirror,
+// row_mirror: a max does not care that the last two are reflections rather than xors); only the 32- and 64-lane steps cross DPP rows and
+// keep their bpermute.  Integer maxima only: a float SUM would change its pairing order with the reflections.
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_max_u32(unsigned v) {
+    const unsigned t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
+    return t > v ? t : v;
+}
+template <int LANES>
+__device__ __forceinline__ unsigned group_max_u32(unsigned v) {
+    static_assert(LANES >= 1 && LANES <= 64 && (LANES & (LANES - 1)) == 0, "power of two up to the wave");
+    if (LANES >= 2) v = dpp_max_u32<0xB1>(v);      // quad_perm [1, 0, 3, 2]
+    if (LANES >= 4) v = dpp_max_u32<0x4E>(v);      // quad_perm [2, 3, 0, 1]
+    if (LANES >= 8) v = dpp_max_u32<0x141>(v);     // row_half_mirror
+    if (LANES >= 16) v = dpp_max_u32<0x140>(v);    // row_mirror
+    if (LANES >= 32) { const unsigned t = (unsigned)__shfl_xor((int)v, 16); v = t > v ? t : v; }
+    if (LANES >= 64) { const unsigned t = (unsigned)__shfl_xor((int)v, 32); v = t > v ? t : v; }
+    return v;
+}
+
 // wave maximum -> slot (one atomic per wave at most; none when the slot already holds at least as much)
 __device__ __forceinline__ void amax_flush(unsigned mx, unsigned* slot) {
-#pragma unroll
-    for (int o = 32; o; o >>= 1) {
-        const unsigned t = (unsigned)__shfl_xor((int)mx, o);
-        mx = t > mx ? t : mx;
-    }
+    mx = group_max_u32<64>(mx);
     if ((threadIdx.x & 63) == 0 && mx > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, mx);
 }
 

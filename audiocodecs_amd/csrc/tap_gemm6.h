@@ -229,6 +229,9 @@ __device__ __forceinline__ void tap6_epilogue(const TapGemmParams& p, f32x16 (&a
                 Cs[((wm * EH + a - a0) * 32 + 8 * (r / 4) + 4 * kh + (r % 4)) * CP + wn * 32 + i32] = NP == 2 ? __fmaf_rn(acc[a][c][r], iv, bq) : acc[a][c][r] + bv;
         }
         __syncthreads();
+#ifdef T6_TRACE
+        if (c == 0 && a0 == 0) T6_PHASE(8);          // staged epilogue: first pass staged
+#endif
         if (fastpass) {
             // the full-tile case (every epilogue flavour): no bounds; residual rows and row words requested two iterations ahead,
             // the per-column vectors already in registers -- the generic loop below waits for each of those loads in turn, which
@@ -269,11 +272,7 @@ __device__ __forceinline__ void tap6_epilogue(const TapGemmParams& p, f32x16 (&a
                 if (p.amax_out_rows) {      // the CW / 4 lanes that share this row (every lane runs every iteration)
                     unsigned rmax = 0;
                     amax_acc4(rmax, v);
-#pragma unroll
-                    for (int o2 = CW / 8; o2; o2 >>= 1) {
-                        const unsigned t2 = (unsigned)__shfl_xor((int)rmax, o2);
-                        rmax = t2 > rmax ? t2 : rmax;
-                    }
+                    rmax = group_max_u32<CW / 4>(rmax);
                     if (fq == 0 && rmax) atomicMax(p.amax_out_rows + m, rmax);
                 }
             }
@@ -321,14 +320,13 @@ __device__ __forceinline__ void tap6_epilogue(const TapGemmParams& p, f32x16 (&a
                 }
             }
             if (NP == 2 && p.amax_out_rows) {      // the CW / 4 lanes that share this row (every lane runs every iteration)
-#pragma unroll
-                for (int o2 = CW / 8; o2; o2 >>= 1) {
-                    const unsigned t2 = (unsigned)__shfl_xor((int)rmax, o2);
-                    rmax = t2 > rmax ? t2 : rmax;
-                }
+                rmax = group_max_u32<CW / 4>(rmax);
                 if (q == 0 && m < p.M && rmax) atomicMax(p.amax_out_rows + m, rmax);
             }
         }
+#ifdef T6_TRACE
+        if (c == 0 && a0 == 0) T6_PHASE(10);         // staged epilogue: first pass stored
+#endif
     }
 #ifdef T6_TRACE
     T6_PHASE(11);

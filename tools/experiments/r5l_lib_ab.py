@@ -27,4 +27,8 @@ for s in st:
     if s[0].startswith("tap_gemm"):
         shape = s[0].split("> ", 1)[1] if "> " in s[0] else s[0]
         r[shape] = r.get(shape, 0.0) + s[2] / 5
-print(f"{tag} {name}: step {step:.3f} ms, tap-GEMM {sum(r.values()):.3f} ms | " + " ".join(f"{v:.3f}" for k, v in sorted(r.items())), flush=True)
+import hashlib
+with torch.no_grad():
+    _t = codec.sig_to_toks(sig); _r = codec.toks_to_sig(_t); torch.cuda.synchronize()
+digest = hashlib.sha256(_t.cpu().numpy().tobytes() + _r.cpu().numpy().tobytes()).hexdigest()[:12]
+print(f"{tag} {name} [{digest}]: step {step:.3f} ms, tap-GEMM {sum(r.values()):.3f} ms | " + " ".join(f"{v:.3f}" for k, v in sorted(r.items())), flush=True)
