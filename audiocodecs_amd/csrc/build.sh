@@ -14,7 +14,10 @@ here="$(cd "$(dirname "$0")" && pwd)"
 out="${AC_OUT:-$here/../libaudiocodecs_amd.so}"     # AC_OUT / AC_OBJ: developer builds beside the product (timing variants)
 obj="${AC_OBJ:-$here/build}"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -fno-strict-aliasing -fPIC -Wall -Wno-unused-function -I"$here/../../include" "$@")
+# -pragma-unroll-threshold: the staged epilogue's pass loops (tap_gemm6.h, `#pragma unroll` over the wave's column tiles and row passes) hold
+# the paired store loop twice; at the default 16 k the unroller gives up on them, the accumulator index becomes dynamic and the tile goes
+# to scratch (check_isa.sh fails the build on that).
+FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -fno-strict-aliasing -fPIC -Wall -Wno-unused-function -mllvm -pragma-unroll-threshold=65536 -I"$here/../../include" "$@")
 mkdir -p "$obj"
 pids=()
 # -save-temps=obj: the device assembly of every translation unit stays beside its object for tools/mfma_branch_hazard.py (below)

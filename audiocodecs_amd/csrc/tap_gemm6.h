@@ -187,7 +187,8 @@ __device__ __forceinline__ void tap6_epilogue(const TapGemmParams& p, f32x16 (&a
     const int nvalid = p.n_valid ? p.n_valid : p.N;
     unsigned omax = 0;
     constexpr int EH = Cfg::EH, ER = 32 * WGM * EH;       // 32-row tiles / rows staged per pass
-    const bool fastpass = NP == 2 && p.y_len == 0 && p.y_off == 0 && nvalid == p.N && m0 + BM <= p.M && n0 + BN <= p.N && (ER * (CW / 4)) % NT == 0;
+    const bool fastpass = NP == 2 && p.y_len == 0 && p.y_off == 0 && nvalid == p.N && m0 + BM <= p.M && n0 + BN <= p.N && (ER * (CW / 4)) % NT == 0 &&
+                          (!p.res || ((long long)p.M * p.res_rs * 4 < 0x7fffffffLL));       // (the residual goes through a 32-bit buffer offset)
 #pragma unroll
     for (int c = 0; c < WN; ++c)
 #pragma unroll
@@ -195,25 +196,29 @@ __device__ __forceinline__ void tap6_epilogue(const TapGemmParams& p, f32x16 (&a
         // the residual rows of this pass are requested BEFORE the pass is staged: they arrive under the barriers and LDS writes
         // (the store loop used to wait for each of them in turn: 48 k of the 67 k cycles of a DAC 1 x 1 tile, profiles/r3_tapgemm_trace.md)
         constexpr int EITER = (ER * (CW / 4)) / NT;
-        auto res_at = [&](int i) -> f32x4 {
-            const int e = tid + i * NT;
-            const int row = e / (CW / 4), q = e % (CW / 4);
-            const int m = m0 + (row / (32 * EH)) * (32 * WMT) + a0 * 32 + row % (32 * EH), n = n0 + (q / 8) * (32 * WN) + 32 * c + 4 * (q % 8);
-            return *reinterpret_cast<const f32x4*>(p.res + (long long)b * p.res_bs + (long long)m * p.res_rs + n);
-        };
-        f32x4 rn1 = f32x4{0.f, 0.f, 0.f, 0.f}, rn2 = rn1;              // the residual rows two iterations ahead of the store loop
-        if (fastpass && p.res) { rn1 = res_at(0); if (EITER > 1) rn2 = res_at(1); }
-        // row mode: the rows' amax words likewise; a thread's four columns are the same in every iteration of a pass (NT is a
-        // multiple of CW / 4), so bias / LayerScale / Snake vectors are loaded once per pass, before it is staged
-        auto roww_at = [&](int i) -> unsigned {
+        // The residual rows and (row mode) the rows' amax words are requested two iterations ahead of the store loop -- WITHOUT a condition
+        // around any request: through buffer descriptors of zero records when the layer has no residual / is not in row mode (such a load
+        // returns zeros without touching memory), and with the index clamped instead of `if (i + 2 < EITER)`.  A register that is loaded on
+        // one path and carried on the other becomes a copy at the join, and the copy waits for the load: round 5 found `s_waitcnt vmcnt(0)`
+        // behind the residual add of EVERY iteration -- the request issued two lines earlier, and every store before it, waited for on the
+        // spot (2 340 ticks per iteration of Mimi's o-projection against 850 for a layer without residual, profiles/r5r_*).
+        const __amdgpu_buffer_rsrc_t r_res = __builtin_amdgcn_make_buffer_rsrc((void*)(p.res ? p.res + (long long)b * p.res_bs : nullptr), 0,
+                                                                                 p.res ? (int)(((long long)(p.M - 1) * p.res_rs + p.N) * 4) : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t r_row = __builtin_amdgcn_make_buffer_rsrc((void*)(rowmode ? p.seg[0].amax : nullptr), 0, rowmode ? p.M * 4 : 0, 0x00020000);
+        auto row_of = [&](int i) {
             const int row = (tid + i * NT) / (CW / 4);
-            return p.seg[0].amax[m0 + (row / (32 * EH)) * (32 * WMT) + a0 * 32 + row % (32 * EH)];
+            return m0 + (row / (32 * EH)) * (32 * WMT) + a0 * 32 + row % (32 * EH);
         };
-        unsigned rw1 = 0, rw2 = 0;
         const int fq = tid % (CW / 4), fn = n0 + (fq / 8) * (32 * WN) + 32 * c + 4 * (fq % 8);
+        auto res_at = [&](int i) -> f32x4 { return bufload16(r_res, (row_of(i) * (int)p.res_rs + fn) * 4, 0); };
+        auto roww_at = [&](int i) -> unsigned { return (unsigned)__builtin_amdgcn_raw_buffer_load_b32(r_row, row_of(i) * 4, 0, 0); };
+        f32x4 rn1 = f32x4{0.f, 0.f, 0.f, 0.f}, rn2 = rn1;              // the residual rows two iterations ahead of the store loop
+        unsigned rw1 = 0, rw2 = 0;
         f32x4 fb4 = f32x4{0.f, 0.f, 0.f, 0.f}, fsc4 = f32x4{1.f, 1.f, 1.f, 1.f}, fal = fb4, fai = fb4;
         if (fastpass) {
-            if (rowmode) { rw1 = roww_at(0); if (EITER > 1) rw2 = roww_at(1); if (p.bias) fb4 = *reinterpret_cast<const f32x4*>(p.bias + fn); }
+            rn1 = res_at(0); rn2 = res_at(EITER > 1 ? 1 : 0);
+            rw1 = roww_at(0); rw2 = roww_at(EITER > 1 ? 1 : 0);
+            if (rowmode) { if (p.bias) fb4 = *reinterpret_cast<const f32x4*>(p.bias + fn); }
             if (p.scale) fsc4 = *reinterpret_cast<const f32x4*>(p.scale + fn);
             if (p.alpha && p.y_elu) { const int ca = fn % p.alpha_n; fal = *reinterpret_cast<const f32x4*>(p.alpha + ca); fai = *reinterpret_cast<const f32x4*>(p.alpha_inv + ca); }
         }
@@ -237,25 +242,24 @@ __device__ __forceinline__ void tap6_epilogue(const TapGemmParams& p, f32x16 (&a
             // the per-column vectors already in registers -- the generic loop below waits for each of those loads in turn, which
             // was 48 k of the 67 k cycles of a DAC 1 x 1 tile and 150 k of the 250 k cycles of a Mimi o-projection tile
             // (profiles/r3_tapgemm_trace.md)
-            for (int i = 0; i < EITER; ++i) {
+            // The loop runs in PAIRS with one register set per parity, each set reloaded (for iteration i + 2) right behind its last use: a
+            // rotation rn1 = rn2, rn2 = load in a rolled loop became copies at the back edge, and the copy of the register just requested
+            // waits for it (`s_waitcnt vmcnt(0)` per iteration, as the conditional request did before).
+            auto one = [&](int i, f32x4& rn, unsigned& rw) {
                 const int row = (tid + i * NT) / (CW / 4);
                 const int m = m0 + (row / (32 * EH)) * (32 * WMT) + a0 * 32 + row % (32 * EH);
                 const long long o = yoff + (long long)m * p.y_rs + fn;
+                const int inext = i + 2 < EITER ? i + 2 : EITER - 1;       // (unconditional, clamped: see above)
                 f32x4 v = *reinterpret_cast<const f32x4*>(&Cs[row * CP + 4 * fq]);
                 if (rowmode) {
-                    const float ri = s16_pow2(-s16_exponent(rw1));
-                    rw1 = rw2;
-                    if (i + 2 < EITER) rw2 = roww_at(i + 2);
+                    const float ri = s16_pow2(-s16_exponent(rw));
                     v = f32x4{__fmaf_rn(v.x, ri, fb4.x), __fmaf_rn(v.y, ri, fb4.y), __fmaf_rn(v.z, ri, fb4.z), __fmaf_rn(v.w, ri, fb4.w)};
                 }
+                rw = roww_at(inext);
                 if (p.gelu) { v.x = gelu1(v.x); v.y = gelu1(v.y); v.z = gelu1(v.z); v.w = gelu1(v.w); }
                 if (p.scale) { v.x = __fmul_rn(fsc4.x, v.x); v.y = __fmul_rn(fsc4.y, v.y); v.z = __fmul_rn(fsc4.z, v.z); v.w = __fmul_rn(fsc4.w, v.w); }
-                if (p.res) {
-                    const f32x4 rv = rn1;
-                    rn1 = rn2;
-                    if (i + 2 < EITER) rn2 = res_at(i + 2);
-                    v.x = __fadd_rn(rv.x, v.x); v.y = __fadd_rn(rv.y, v.y); v.z = __fadd_rn(rv.z, v.z); v.w = __fadd_rn(rv.w, v.w);
-                }
+                if (p.res) { v.x = __fadd_rn(rn.x, v.x); v.y = __fadd_rn(rn.y, v.y); v.z = __fadd_rn(rn.z, v.z); v.w = __fadd_rn(rn.w, v.w); }
+                rn = res_at(inext);
                 if (p.tanh_out) { v.x = tanhf(v.x); v.y = tanhf(v.y); v.z = tanhf(v.z); v.w = tanhf(v.w); }
                 if (p.amax_out) amax_acc4(omax, v);
                 if (p.y) *reinterpret_cast<f32x4*>(p.y + o) = v;
@@ -275,7 +279,9 @@ __device__ __forceinline__ void tap6_epilogue(const TapGemmParams& p, f32x16 (&a
                     rmax = group_max_u32<CW / 4>(rmax);
                     if (fq == 0 && rmax) atomicMax(p.amax_out_rows + m, rmax);
                 }
-            }
+            };
+            for (int i = 0; i + 1 < EITER; i += 2) { one(i, rn1, rw1); one(i + 1, rn2, rw2); }
+            if (EITER & 1) one(EITER - 1, rn1, rw1);
         } else
         for (int e = tid; e < ER * (CW / 4); e += NT) {
             const int row = e / (CW / 4), q = e % (CW / 4);
