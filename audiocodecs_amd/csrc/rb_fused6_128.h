@@ -141,6 +141,17 @@ __global__ __launch_bounds__(512, 1) void rb128_fused6_kernel(const RbFused6Para
             }
         }
         lds_barrier();  
+        // identity shortcut: the x values of the output loop, requested here to arrive under stage B (rb_fused6.h)
+        const int tile_b = tile / p.ntiles, tile_t0 = (tile % p.ntiles) * BM;
+        f32x4 xsc[SC ? 1 : TT];
+        if constexpr (!SC) {
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.xr + (long long)tile_b * p.L * C), 0, clip_bytes, 0x00020000);
+#pragma unroll
+            for (int a = 0; a < TT; ++a) {
+                const int t = tile_t0 + a * 16 + li;
+                xsc[a] = bufload16(rs, (t < p.L ? t * (C * 4) : 0x7fff0000) + (wave * 16 + 4 * kq) * 4, 0);
+            }
+        }
         // ---- stage B: y = [W1 | Ws] * [hidden | x]^T + bf, output channels 16 wave ..
         f32x4 acc[TT];
 #pragma unroll
@@ -163,7 +174,7 @@ __global__ __launch_bounds__(512, 1) void rb128_fused6_kernel(const RbFused6Para
         lds_barrier();                                          // every wave is done reading the slabs
         if (next < total) store_tile(next);                     // staged before the output stores are issued (rb_fused6.h)
         {
-            const int b = tile / p.ntiles, t0 = (tile % p.ntiles) * BM;
+            const int b = tile_b, t0 = tile_t0;
             if (p.amax_out && b != omax_b) {                     // clip change: hand the finished clip's maximum over
                 amax_flush(omax, amax_at(p.amax_out, omax_b));
                 omax = 0;
@@ -172,7 +183,6 @@ __global__ __launch_bounds__(512, 1) void rb128_fused6_kernel(const RbFused6Para
             const long long ob = (long long)b * p.L * C;
             const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)(p.y ? p.y + ob : nullptr), 0, p.y ? clip_bytes : 0, 0x00020000);
             const __amdgpu_buffer_rsrc_t re = __builtin_amdgcn_make_buffer_rsrc((void*)(p.y_elu ? p.y_elu + ob : nullptr), 0, p.y_elu ? clip_bytes : 0, 0x00020000);
-            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.xr + ob), 0, clip_bytes, 0x00020000);
 #pragma unroll
             for (int a = 0; a < TT; ++a) {
                 const int t = t0 + a * 16 + li;
@@ -182,8 +192,8 @@ __global__ __launch_bounds__(512, 1) void rb128_fused6_kernel(const RbFused6Para
                     const f32x4 iv = ifv * cs.ib;
                     v = f32x4{__fmaf_rn(v.x, iv.x, bfv.x), __fmaf_rn(v.y, iv.y, bfv.y), __fmaf_rn(v.z, iv.z, bfv.z), __fmaf_rn(v.w, iv.w, bfv.w)};
                 }
-                if (!SC) {                                       // identity shortcut: x + block(x)
-                    const f32x4 xv = bufload16(rs, o, 0);
+                if constexpr (!SC) {                             // identity shortcut: x + block(x)
+                    const f32x4 xv = xsc[a];
                     v = f32x4{__fadd_rn(xv.x, v.x), __fadd_rn(xv.y, v.y), __fadd_rn(xv.z, v.z), __fadd_rn(xv.w, v.w)};
                 }
                 if (p.amax_out && t < p.L) amax_acc4(omax, v);
