@@ -47,6 +47,9 @@ struct Tap8Cfg {
 // one 1 KiB LDS-DMA transfer: lane l's 16 bytes at gsrc land at LDS byte address lds_dst + 16 l (lds_dst wave-uniform).  Inline asm:
 // hipcc does not count it (cdna_hip_programming.md section 5.7) -- the caller waits with t8_wait<N>() and a barrier before any read.
 __device__ __forceinline__ void t8_glds16(const void* gsrc, unsigned lds_dst) {
+#ifdef T8_ABL_NODMA    // (ablation build, wrong results: no weight stage is fetched)
+    return;
+#endif
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
@@ -176,6 +179,9 @@ __global__ __launch_bounds__(512, 1) void tap_gemm8_kernel(const TapGemmParams p
     constexpr int A_OOB = 0x7fff0000;
     const __amdgpu_buffer_rsrc_t a_rs_null = __builtin_amdgcn_make_buffer_rsrc((void*)(sg.x + (long long)b * sg.bs), 0, 0, 0x00020000);
     auto load_a = [&](int c, bool live, f32x4 (&ra)[A_SLOTS]) {
+#ifdef T8_ABL_NOALOAD  // (ablation build, wrong results: every activation request goes through the zero-record descriptor)
+        live = false;
+#endif
         const int c_ = c * KC;
         if (seg_interior || !live) {
             const int soff = __builtin_amdgcn_readfirstlane(live ? c_ * 4 : 0);
@@ -199,6 +205,9 @@ __global__ __launch_bounds__(512, 1) void tap_gemm8_kernel(const TapGemmParams p
     };
     // the same, ONE slot (SPREAD: the requests of a stage sit between its MFMA units)
     auto load_slot = [&](int c, bool live, f32x4 (&ra)[A_SLOTS], int i) {
+#ifdef T8_ABL_NOALOAD
+        live = false;
+#endif
         const int c_ = c * KC;
         if (seg_interior || !live) {
             const int soff = __builtin_amdgcn_readfirstlane(live ? c_ * 4 : 0);
@@ -220,6 +229,9 @@ __global__ __launch_bounds__(512, 1) void tap_gemm8_kernel(const TapGemmParams p
         //  one wave then issues it, and the counted waits of the stage -- vmcnt(A_SLOTS) -- would let a weight fragment of the
         //  other waves stay in flight across the barrier)
         if (i + 1 == A_SLOTS) asm volatile("" ::"v"(ra[i]));
+#ifdef T8_ABL_NOSTORE  // (ablation build, wrong results: no split, no slab write)
+        return;
+#endif
         if (i + 1 < A_SLOTS || last_slot_ok) {
             const f32x4 v = (a_zero & (1u << i)) ? f32x4{0.f, 0.f, 0.f, 0.f} : ra[i];
             split16_store4s(v, a_rsc[RM ? i : 0], dst, PLANE, a_lds0 + i * (NT / (KC / 4)) * T6_PITCH);
@@ -279,10 +291,14 @@ __global__ __launch_bounds__(512, 1) void tap_gemm8_kernel(const TapGemmParams p
             if (a == WMT - 1 && ks == 0) read_b(1, bf[1]);
 #pragma unroll
             for (int c = 0; c < WN; ++c) {   // lo hi, hi lo, hi hi: tap_gemm6's order
+#ifdef T8_ABL_NOMFMA   // (ablation build, wrong results: the fragment reads stay, the MFMAs go)
+                asm volatile("" ::"v"(af[u & 1][0]), "v"(af[u & 1][1]), "v"(bf[ks][0][c]), "v"(bf[ks][1][c]));
+#else
                 f32x16 v = acc[a][c];
                 v = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[u & 1][1], bf[ks][0][c], v, 0, 0, 0);
                 v = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[u & 1][0], bf[ks][1][c], v, 0, 0, 0);
                 acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[u & 1][0], bf[ks][0][c], v, 0, 0, 0);
+#endif
             }
             hook(u);                                   // (same scheduling region as the unit's MFMAs: VALU / LDS-write work issues in their shadow)
             __builtin_amdgcn_sched_barrier(0);
