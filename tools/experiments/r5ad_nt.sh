@@ -1,0 +1,3 @@
+mkdir -p gpurun_out/r5ad
+for i in 1 2; do for n in encodec mimi wavtokenizer; do for l in old new; do AUDIOCODECS_AMD_LIB=$PWD/tools/experiments/lib_$l.so python tools/experiments/r5l_lib_ab.py $l $n 2>&1 | grep -E "^(old|new) "; done; done; done > gpurun_out/r5ad/ab.txt
+cut -c1-110 gpurun_out/r5ad/ab.txt
