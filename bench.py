@@ -238,9 +238,9 @@ def measured_traffic(kernel_name, unit, codec="encodec", batch=64):
     their canonical spelling); null if absent."""
     import glob
 
-    def rank_of(f):   # r4b_... after r4a_... after r3b_...
+    def rank_of(f):   # r5ae_... after r5z_... after r4b_... after r4a_... (run tags count a, b, .. z, aa, ab, ..)
         m = re.match(r"r(\d+)([a-z]*)", os.path.basename(f))
-        return (int(m.group(1)), m.group(2)) if m else (0, "")
+        return (int(m.group(1)), len(m.group(2)), m.group(2)) if m else (0, 0, "")
 
     files = sorted((f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json"))
                     if (codec in os.path.basename(f)) or (codec == "encodec" and not any(c in os.path.basename(f) for c in ("mimi", "dac", "wavtok")))), key=rank_of)
