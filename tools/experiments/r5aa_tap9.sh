@@ -1,3 +1,4 @@
+# (measures tap_gemm9, which is NOT in the tree: apply profiles/r5ab_tap9_experiment.diff first -- profiles/r5_tapgemm8_notes.md section 11)
 mkdir -p gpurun_out/r5aa
 L=$PWD/tools/experiments/lib_new.so
 for n in encodec mimi; do
