@@ -265,6 +265,39 @@ def measured_traffic(kernel_name, unit, codec="encodec", batch=64):
     return None
 
 
+def measured_step_traffic(codec="encodec", batch=64):
+    """HBM bytes ONE STEP moved, all kernels, from the newest committed PMC summary of that codec (same source and batch rule as
+    measured_traffic): (fetch bytes, write bytes, file) or None.  DAC: the summary is of one 39-clip chunk -- scaled to the batch."""
+    import glob
+
+    def rank_of(f):
+        m = re.match(r"r(\d+)([a-z]*)", os.path.basename(f))
+        return (int(m.group(1)), len(m.group(2)), m.group(2)) if m else (0, 0, "")
+
+    files = sorted((f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json"))
+                    if (codec in os.path.basename(f)) or (codec == "encodec" and not any(c in os.path.basename(f) for c in ("mimi", "dac", "wavtok")))), key=rank_of)
+    default_batch = {"encodec": 64, "mimi": 128, "wavtokenizer": 64, "dac": 256}.get(codec)
+    for f in reversed(files):
+        m = re.search(r"_b(\d+)_", os.path.basename(f))
+        scale = 1.0
+        if not m and batch != default_batch:
+            continue            # (an untagged summary is of the codec's default bench batch)
+        if m:
+            if codec == "dac" and int(m.group(1)) == 39 and batch >= 39:
+                scale = batch / 39.0
+            elif int(m.group(1)) != batch:
+                continue
+        try:
+            ks = json.load(open(f))["kernels"]
+        except Exception:
+            continue
+        fe = sum(k.get("launches", 1) * k["fetch_bytes_per_launch_corrected"] for k in ks.values() if k.get("hbm_bytes_per_launch") is not None)
+        wr = sum(k.get("launches", 1) * k["write_bytes_per_launch"] for k in ks.values() if k.get("hbm_bytes_per_launch") is not None)
+        if fe + wr > 0:
+            return fe * scale, wr * scale, "profiles/" + os.path.basename(f)
+    return None
+
+
 CODEC_LABEL = {"mimi": "Mimi-24k", "dac": "DAC-44.1k", "encodec": "EnCodec-24k", "wavtokenizer": "WavTokenizer-24k-40tok"}
 CODEC_NCB = {"dac": 9, "wavtokenizer": 1, "mimi": 8, "encodec": 8}
 
@@ -362,13 +395,21 @@ def roofline_of(stats, dt, steps, codec_name, batch, exact):
     return roof
 
 
-def whole_path(stats, dt, layer_bytes):
+def whole_path(stats, dt, layer_bytes, codec=None, batch=None, steps=1):
     """Whole-step fractions: (a) layer-boundary bytes of the UNFUSED layer stack per second against 8 TB/s (fused chains move fewer
     bytes than this model, so the fraction measures time, not traffic); (b) the fp16 MFMA flops the split16 kernels EXECUTE per
-    second against the 2.5 PF dense peak."""
+    second against the 2.5 PF dense peak; (c) the HBM bytes a step really moved (FETCH_SIZE / WRITE_SIZE counter passes of the same
+    workload, all kernels: measured_step_traffic) over this run's step time."""
     ex = sum(s_[3] * mfma16_terms(s_[0]) for s_ in stats)
-    return {"hbm_layer_boundary_frac": round(layer_bytes / dt / (PEAK_HBM_GBS * 1e9), 4),
-            "executed_mfma16_tflops": round(ex / dt / 1e12, 1), "executed_mfma16_frac": round(ex / dt / (PEAK_F16_MFMA_TFLOPS * 1e12), 4)}
+    out = {"hbm_layer_boundary_frac": round(layer_bytes / dt / (PEAK_HBM_GBS * 1e9), 4),
+           "executed_mfma16_tflops": round(ex / dt / 1e12, 1), "executed_mfma16_frac": round(ex / dt / (PEAK_F16_MFMA_TFLOPS * 1e12), 4)}
+    tr = measured_step_traffic(codec, batch) if codec else None
+    if tr:
+        per_step_s = dt / steps
+        out.update({"measured_hbm_gb_per_step": round((tr[0] + tr[1]) / 1e9, 2), "measured_hbm_fetch_gb_per_step": round(tr[0] / 1e9, 2),
+                    "measured_hbm_gbs": round((tr[0] + tr[1]) / per_step_s / 1e9, 1), "measured_hbm_frac": round((tr[0] + tr[1]) / per_step_s / (PEAK_HBM_GBS * 1e9), 4),
+                    "measured_hbm_source": tr[2]})
+    return out
 
 
 def kernel_rows(stats, steps, top=None):
@@ -424,7 +465,7 @@ def short_run(name, batch, seconds, steps, warmup, precision=None):
     return {"workload": f"{CODEC_LABEL[name]} {CODEC_NCB[name]} codebooks, encode+decode, {batch} clips x {seconds:g} s on 1 GPU, resident in HBM",
             "value": round(audio_s / dt, 1), "unit": "audio-s/s", "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps, "warmup": warmup,
             "roofline": roofline_of(stats, dt_prof, 1, name, batch, precision == "fp32_exact"),
-            "whole_path": whole_path(stats, dt_prof, sum(s_[4] for s_ in stats)),
+            "whole_path": whole_path(stats, dt_prof, sum(s_[4] for s_ in stats), name, batch),
             "top_kernels": kernel_rows(stats, 1, top=4), "parity": gate, "batch1_latency": b1}
 
 
@@ -555,7 +596,7 @@ def run(args, codec, cfg, sd, sig, sig_cpu, rank, world, dist, device):
     exact = (args.precision or ("fp32_exact" if os.environ.get("AC_GEMM", "") == "fp32" else "fp32")) == "fp32_exact"
     if rank == 0:
         other = args.codec != "encodec"   # not the headline codec: layer-boundary bytes from the kernels' own algorithmic counts
-        wp = whole_path(stats, dt_ev, sum(s_[4] for s_ in stats) if other else LAYER_BYTES_PER_AUDIO_S * audio_s / world)
+        wp = whole_path(stats, dt_ev, sum(s_[4] for s_ in stats) if other else LAYER_BYTES_PER_AUDIO_S * audio_s / world, args.codec, B, args.steps)
         wp["ms_per_step_with_kernel_events"] = round(dt_ev / args.steps * 1e3, 3)
         roof = roofline_of(stats, dt_ev, args.steps, args.codec, B, exact)
         dtype = ("f32 (every product an IEEE fp32 product: the exact-product kernels)" if exact else
