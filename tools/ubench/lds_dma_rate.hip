@@ -2,6 +2,7 @@
 //   MODE 0: global_load_lds_dwordx4 (LDS-DMA, 1 KB per wave-instruction)       -- tap_gemm8's weight stage
 //   MODE 1: global_load_dwordx4 into registers + ds_write_b128                   -- the same bytes through the register file
 //   MODE 2: global_load_dwordx4 into registers only                              -- the bare load path
+//   MODE 3: global_store_dwordx4 of the same bytes (private streams only)
 // One workgroup of W waves per CU (256 workgroups); every wave fetches PIECES x 1 KB per round from a 64 KB window of a buffer that
 // stays in L2 (every workgroup reads the same window, like the weight tiles of a GEMM), waits for all of it, ROUNDS times.
 // Prints shader clocks per 1 KB piece PER CU (wall clocks of the slowest wave / pieces of all waves of the workgroup) and B/clk/CU.
@@ -50,8 +51,14 @@ __global__ __launch_bounds__(1024, 1) void k(const char* __restrict__ src, float
         } else {
             f32x4 v[PIECES];
 #pragma unroll
-            for (int i = 0; i < PIECES; ++i) v[i] = *reinterpret_cast<const f32x4*>(p + (region ? (size_t)i * 1024 : (size_t)((i * 5) & 63) * 1024));
-            if (MODE == 1) {
+            for (int i = 0; i < PIECES; ++i) if (MODE != 3) v[i] = *reinterpret_cast<const f32x4*>(p + (region ? (size_t)i * 1024 : (size_t)((i * 5) & 63) * 1024));
+            if (MODE == 3) {   // the same bytes WRITTEN to the region (global_store_dwordx4)
+                char* q = const_cast<char*>(p);
+#pragma unroll
+                for (int i = 0; i < PIECES; ++i) {
+                    *reinterpret_cast<f32x4*>(q + (region ? (size_t)i * 1024 : (size_t)((i * 5) & 63) * 1024)) = acc;
+                }
+            } else if (MODE == 1) {
 #pragma unroll
                 for (int i = 0; i < PIECES; ++i) *reinterpret_cast<f32x4*>(lds + (size_t)wave * PIECES * 1024 + i * 1024 + lane * 16) = v[i];
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -108,5 +115,6 @@ int main() {
     for (int w : {4, 8, 16}) run<0, 8>(src, sink, clk, w, ratio, 0, (size_t)64 << 10);
     for (int w : {4, 8, 16}) run<0, 8>(src, sink, clk, w, ratio, 0, (size_t)4 << 20);
     for (int w : {4, 8, 16}) run<2, 8>(src, sink, clk, w, ratio, 0, (size_t)4 << 20);
+    for (int w : {8, 16}) run<3, 8>(src, sink, clk, w, ratio, 0, (size_t)4 << 20);      // stores only
     return 0;
 }
