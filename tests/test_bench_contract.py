@@ -93,3 +93,20 @@ def test_traffic_lookup_matches_rocprof_spelling():
     assert got is not None and got[0] > 1e9 and got[1].startswith("profiles/r")
     newest = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_traffic.json") and not any(c in f for c in ("mimi", "dac", "wavtok")))
     assert got[1] >= "profiles/r3b_traffic.json", (got, newest)
+
+
+def test_measured_traffic_sources_exist_and_match_the_batch():
+    """roofline.traffic / whole_path.measured_hbm_* quote committed counter summaries: the newest one of the codec at the codec's bench batch,
+    nothing for a batch no summary was taken at."""
+    import os
+    import bench
+
+    for codec, batch in (("encodec", 64), ("mimi", 128), ("wavtokenizer", 64), ("dac", 256)):
+        tr = bench.measured_step_traffic(codec, batch)
+        assert tr is not None and tr[0] > 0 and tr[1] > 0, codec
+        assert os.path.exists(os.path.join(bench.ROOT, tr[2])), tr[2]
+        one = bench.measured_traffic("tap_gemm6_kernel<1, 4, 4, 1, 2>", "B", codec, batch)
+        assert one is not None and one[0] > 0 and os.path.exists(os.path.join(bench.ROOT, one[1]))
+    assert bench.measured_step_traffic("encodec", 8) is None
+    # run tags count a .. z, aa, ab ..: r5ae is newer than r5m
+    assert "r5ae" in bench.measured_step_traffic("encodec", 64)[2]
