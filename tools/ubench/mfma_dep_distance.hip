@@ -62,23 +62,28 @@ __global__ __launch_bounds__(512, 1) void k(float* out, int iters, unsigned long
 }
 
 template <int PATTERN, int FILL>
-void run() {
+void run(int threads = 512) {
     float* out; CK(hipMalloc(&out, 4));
     unsigned long long* clk; CK(hipMalloc(&clk, 256 * 8 * 8));
     const int iters = 400;
-    hipLaunchKernelGGL((k<PATTERN, FILL>), dim3(256), dim3(512), 0, 0, out, 10, clk);
-    hipLaunchKernelGGL((k<PATTERN, FILL>), dim3(256), dim3(512), 0, 0, out, iters, clk);
+    hipLaunchKernelGGL((k<PATTERN, FILL>), dim3(256), dim3(threads), 0, 0, out, 10, clk);
+    hipLaunchKernelGGL((k<PATTERN, FILL>), dim3(256), dim3(threads), 0, 0, out, iters, clk);
     CK(hipDeviceSynchronize());
     unsigned long long hc[256 * 8]; CK(hipMemcpy(hc, clk, sizeof hc, hipMemcpyDeviceToHost));
-    double st = 0; for (int i = 0; i < 256 * 8; ++i) st += hc[i];
-    st /= 256 * 8;
-    // per SIMD: 2 waves x 48 MFMAs per iteration
-    printf("distance %d fill %d: %.1f cycles per MFMA per SIMD (wave loop %.0f cycles per 48-MFMA stage)\n", PATTERN, FILL, st / iters / 96.0, st / iters);
+    const int waves = threads / 64;
+    double st = 0; for (int b = 0; b < 256; ++b) for (int w = 0; w < waves; ++w) st += hc[b * 8 + w];
+    st /= 256 * waves;
+    // per SIMD: waves / 4 waves x 48 MFMAs per iteration
+    printf("%d wave(s) per SIMD, distance %d fill %d: %.1f cycles per MFMA per SIMD (wave loop %.0f cycles per 48-MFMA stage)\n", waves / 4, PATTERN, FILL,
+           st / iters / (48.0 * waves / 4), st / iters);
 }
 
 int main() {
     run<1, 0>(); run<2, 0>(); run<4, 0>(); run<8, 0>();
     run<1, 1>(); run<2, 1>(); run<4, 1>(); run<8, 1>();
     run<1, 2>(); run<2, 2>(); run<4, 2>(); run<8, 2>();
+    // ONE wave per SIMD (what a wave gets while its SIMD partner is loading or waiting)
+    run<1, 0>(256); run<2, 0>(256); run<4, 0>(256); run<8, 0>(256);
+    run<1, 1>(256); run<2, 1>(256); run<4, 1>(256); run<8, 1>(256);
     return 0;
 }
