@@ -497,6 +497,9 @@ __device__ __forceinline__ void tap6_mainloop(const TapGemmParams& p, const __bf
     // (a buffer load past num_records returns zeros without touching memory; the range check sees the VGPR offset only)
     constexpr int A_OOB = 0x7fff0000;
     auto load_a = [&](int s_, int c_, int j_, bool live) {
+#ifdef T6_ABL_NOALOAD   // (ablation build, wrong results: every activation request aims past the descriptor's last record)
+        live = false;
+#endif
         int voff[A_SLOTS], soff = 0;
         if (seg_interior || !live) {
             // (readfirstlane: the chunk / tap offset IS wave-uniform, but the compiler could not prove it and wrapped every one of the
@@ -524,6 +527,11 @@ __device__ __forceinline__ void tap6_mainloop(const TapGemmParams& p, const __bf
     };
     // split 4 fp32 into the two fp16 planes (split16.h: scaled value = hi + lo) and store them
     auto store_a = [&](__bf16* dst) {
+#ifdef T6_ABL_NOSTORE   // (ablation build, wrong results: no split, no slab write)
+#pragma unroll
+        for (int i = 0; i < A_SLOTS; ++i) asm volatile("" ::"v"(ra[i]));
+        return;
+#endif
 #pragma unroll
         for (int i = 0; i < A_SLOTS; ++i)
             if (i + 1 < A_SLOTS || last_slot_ok) {
@@ -536,6 +544,10 @@ __device__ __forceinline__ void tap6_mainloop(const TapGemmParams& p, const __bf
     constexpr int WPL = 2;    // planes in the weight image
     const __bf16* wbase = wp + ((long long)((n0 + wn * 32 * WN) >> 5) * ksteps) * (WPL * 64 * 8) + lane * 8;
     auto load_b = [&](int s_, bf16x8 (&bf)[3][WN]) {
+#ifdef T6_ABL_NOBLOAD   // (ablation build, wrong results: no weight fragment is fetched)
+        asm volatile("" : "+v"(bf[0][0]), "+v"(bf[1][0]));
+        return;
+#endif
 #pragma unroll
         for (int c = 0; c < WN; ++c)
 #pragma unroll
@@ -580,6 +592,10 @@ __device__ __forceinline__ void tap6_mainloop(const TapGemmParams& p, const __bf
         for (int a = 0; a < WMT; ++a)
 #pragma unroll
             for (int c = 0; c < WN; ++c) {
+#ifdef T6_ABL_NOMFMA    // (ablation build, wrong results: the fragment reads stay, the MFMAs go)
+                asm volatile("" ::"v"(af[0][a]), "v"(af[1][a]), "v"(bf[0][c]), "v"(bf[1][c]));
+                continue;
+#endif
                 f32x16 v = acc[a][c];
                 // lo hi, hi lo, hi hi (small terms first)
                 if constexpr (SWAP) {
