@@ -49,6 +49,7 @@ struct ResBlockPlan {
     PackedGemm fused;  // [ELU(h) | x] * [W1; Ws] + (b1 + bs)
     size_t w3f_off = 0, wff_off = 0;   // rb_fused6.h fragment images of the two matrices (float offsets into the blob)
     size_t winv3_off = 0, winvf_off = 0;   // split16.h: per-row 2^-s of the two images
+    size_t w3p_off = 0, wfp_off = 0;       // rb_stream6.h (C = 64): the same images with every k-step's 32 columns in the lanes' load order
     float hb0 = 0.f, hb1 = 0.f;            // split16.h: |hidden| <= hb0 + hb1 * amax(x)
     bool has6 = false;
 };
@@ -179,6 +180,7 @@ struct ac_handle {
         int tap8_form = 0;          // AC_TAP8_FORM=1|2|3  : force its tile form (256 x 256, 256 x 128, 128 x 256) where the shape allows
         int tap8_spread = 1;        // AC_TAP8_SPREAD=0|1|2: tap_gemm8's requests of a stage at its top / dealt between its MFMA units where that measured faster (128-row tiles) / dealt everywhere (bit-identical)
         int rb6_dbg = 0;            // AC_RB6_DBG          : timing variants of the fused blocks (wrong results)
+        int rb_stream = 1;          // AC_RB_STREAM=0      : the 64-channel causal blocks through rb_fused6.h instead of rb_stream6.h (A/B, cross-check tests)
         int front_seg = 0, tail_seg = 0;   // AC_FRONT_SEG / AC_TAIL_SEG: chunks per stream of the fused chains (0: from the batch size)
         int front_ldspad = 0;       // AC_FRONT_LDSPAD     : extra dynamic LDS (forces one workgroup per CU)
         int lstm_dbg = 0;           // AC_LSTM_DBG         : fault injection / traces of the persistent LSTM
@@ -481,6 +483,13 @@ struct Packer {
         for (int k = 0; sc && k < C; ++k) kf.push_back(hid + k);
         rb.w3f_off = frag16(rb.c3.w_off, hid, rb.c3.Ktot, k3, &rb.winv3_off);
         rb.wff_off = frag16(rb.fused.w_off, C, rb.fused.Ktot, kf, &rb.winvf_off);
+        if (C == 64 && use16()) {   // rb_stream6.h: column 8 kq + e of a k-step <-> channel 4 kq + e (e < 4), 16 + 4 kq + e - 4 (e >= 4) of its 32
+            std::vector<int> k3p(k3.size()), kfp(kf.size());
+            for (size_t k = 0; k < k3.size(); ++k) k3p[k] = k3[(k & ~(size_t)31) + ((k & 4) ? 16 : 0) + 4 * ((k >> 3) & 3) + (k & 3)];
+            for (size_t k = 0; k < kf.size(); ++k) kfp[k] = kf[(k & ~(size_t)31) + ((k & 4) ? 16 : 0) + 4 * ((k >> 3) & 3) + (k & 3)];
+            rb.w3p_off = frag16(rb.c3.w_off, hid, rb.c3.Ktot, k3p);
+            rb.wfp_off = frag16(rb.fused.w_off, C, rb.fused.Ktot, kfp);
+        }
         rb.hb0 = rb.hb1 = 0.f;
         for (int n = 0; n < hid; ++n) {
             double l1 = 0.0;

@@ -30,6 +30,7 @@ struct RbFused6Params {
     float* y_elu;           // optional ELU'd output
     int B, L, Lp;           // Lp: reflect base length (L, or 3 when L <= 2: [HF]:148-155)
     int ntiles;             // tiles per clip
+    int nseg, seg_rows;     // rb_stream6.h: segments per clip, rows per segment (a multiple of 16)
     int pad;                // PAD_REFLECT (EnCodec) / PAD_ZERO (Mimi)
     int lpad;               // rows of left padding of the k3 conv: 2 = causal (EnCodec, Mimi), 1 = centred (WavTokenizer's non-causal SEANet)
     int dbg;                // developer timing modes (AC_RB6_DBG): 1 no stage-A MFMAs, 2 no stage-B MFMAs, 4 no staging,

@@ -115,8 +115,17 @@ def test_mimi_tail_with_the_final_conv_folded_in_is_bit_identical(B, frames):
     with torch.no_grad():
         toks = codec.sig_to_toks(sig)
         debug_set(codec, "mimi_tail", 0)
-        assert "rb_fused6_head_kernel" not in _kernels(codec, lambda: codec.toks_to_sig(toks))
+        # round 6: the stand-alone block runs rb_stream6.h by default (the same arithmetic with every MFMA's 32 products in the lanes' load
+        # order: fp32-faithful, not bit-equal); the folded kernel keeps rb_fused6's order, so the bit-identity is against rb_fused6 + head4
+        names = _kernels(codec, lambda: codec.toks_to_sig(toks))
+        assert "rb_fused6_head_kernel" not in names and "rb_stream6_kernel" in names, names
+        stream = codec.toks_to_sig(toks)
+        debug_set(codec, "rb_stream", 0)
+        names = _kernels(codec, lambda: codec.toks_to_sig(toks))
+        assert "rb_fused6_kernel" in names and "rb_stream6_kernel" not in names and "head4_kernel" in names, names
         ref = codec.toks_to_sig(toks)
+        debug_set(codec, "rb_stream", 1)
+        assert float((stream - ref).abs().max()) <= 2e-5 * max(float(ref.abs().max()), 1e-3), float((stream - ref).abs().max())
         debug_set(codec, "mimi_tail", 1)
         names = _kernels(codec, lambda: codec.toks_to_sig(toks))
         assert "rb_fused6_head_kernel" in names and "head4_kernel" not in names, names
