@@ -74,6 +74,7 @@ static void latch_dev_switches(ac_handle* h) {
     h->dev.tap8_spread = num("AC_TAP8_SPREAD", 1);
     h->dev.rb6_dbg = num("AC_RB6_DBG", 0);
     h->dev.rb_stream = num("AC_RB_STREAM", 1);
+    h->dev.chain_stream = num("AC_CHAIN_STREAM", 1);
     h->dev.front_seg = std::max(0, num("AC_FRONT_SEG", 0));
     h->dev.tail_seg = std::max(0, num("AC_TAIL_SEG", 0));
     h->dev.front_ldspad = std::max(0, num("AC_FRONT_LDSPAD", 0));
@@ -92,7 +93,7 @@ int ac_debug_set(ac_handle* h, const char* key, int value) {
     if (!h || !key) return AC_EINVAL;
     struct { const char* k; int* v; } tab[] = {
         {"tap_epi_staged", &h->dev.tap_epi_staged}, {"tap_dil", &h->dev.tap_dil}, {"tap_stagger", &h->dev.tap_stagger}, {"tap_pick", &h->dev.tap_pick}, {"tap8", &h->dev.tap8}, {"tap8_form", &h->dev.tap8_form}, {"tap8_spread", &h->dev.tap8_spread},
-        {"rb6_dbg", &h->dev.rb6_dbg}, {"rb_stream", &h->dev.rb_stream}, {"front_seg", &h->dev.front_seg}, {"tail_seg", &h->dev.tail_seg}, {"front_ldspad", &h->dev.front_ldspad},
+        {"rb6_dbg", &h->dev.rb6_dbg}, {"rb_stream", &h->dev.rb_stream}, {"chain_stream", &h->dev.chain_stream}, {"front_seg", &h->dev.front_seg}, {"tail_seg", &h->dev.tail_seg}, {"front_ldspad", &h->dev.front_ldspad},
         {"lstm_dbg", &h->dev.lstm_dbg}, {"lstm_fuse_in", &h->dev.lstm_fuse_in}, {"rvq_exact", &h->dev.rvq_exact}, {"prof_detail", &h->dev.prof_detail}, {"head_seq", &h->dev.head_seq}, {"attn_exact", &h->dev.attn_exact}, {"dac_unit", &h->dev.dac_unit}, {"mimi_tail", &h->dev.mimi_tail},
     };
     // (before ac_finalize a value would be overwritten when finalize latches the environment; under stream capture a flipped kernel
@@ -173,6 +174,7 @@ int ac_finalize(ac_handle* h) {
         ok = ok && pk.lstm(a.enc_lstm, a.D, c.num_lstm_layers, h->enc_lstm);
         ok = ok && pk.conv(a.enc_final, h->enc_final);
         if (ok) pk.chain_bounds(h->enc_stem, h->enc_rb[0], h->enc_down[0], h->enc_front);
+        if (ok) pk.stream_enc(h->enc_stem, h->enc_rb[0], h->enc_down[0], h->simg);
     }
     if (h->has_dec) {
         ok = ok && pk.conv(a.dec_first, h->dec_first);
@@ -183,6 +185,7 @@ int ac_finalize(ac_handle* h) {
         }
         ok = ok && pk.conv(a.dec_head, h->dec_head);
         if (ok) pk.tail_bounds(h->dec_up[c.num_ratios - 1], h->dec_rb[c.num_ratios - 1], h->dec_head, h->dec_tail);
+        if (ok) pk.stream_dec(h->dec_up[c.num_ratios - 1], h->dec_rb[c.num_ratios - 1], h->dec_head, h->simg);
     }
     if (!ok) return pk.rc;
     // codebooks: plain [K][C][H], MFMA B-fragment order, squared norms

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Build libaudiocodecs_amd.so for gfx950 (MI355X) in-tree.  Usage: build.sh [extra hipcc flags]
-# Five translation units (core.h has the map), compiled in parallel, linked into one shared library.
+# Six translation units (core.h has the map), compiled in parallel, linked into one shared library.
 # -fno-slp-vectorize: the SLP vectoriser turns the stem's scalar fp32 FMAs (enc_front.h) into v_pk_fma_f32 with op_sel
 # broadcasts, and THAT code returned wrong values in lanes 48..63 of one FMA group per ~100 chunks whenever a second wave shared the
 # SIMD (run-to-run different; never with one wave per SIMD, never without the packed FMAs -- profiles/r3_pk_fma_hazard.md).
@@ -21,12 +21,12 @@ FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -fno-strict-alias
 mkdir -p "$obj"
 pids=()
 # -save-temps=obj: the device assembly of every translation unit stays beside its object for tools/mfma_branch_hazard.py (below)
-for tu in core mimi_path dac_path wavtok_path ac_api; do
+for tu in core mimi_path dac_path wavtok_path stream_path ac_api; do
     "$HIPCC" "${FLAGS[@]}" -save-temps=obj -c "$here/$tu.hip" -o "$obj/$tu.o" &
     pids+=($!)
 done
 for p in "${pids[@]}"; do wait "$p"; done
-"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$out" "$obj"/core.o "$obj"/mimi_path.o "$obj"/dac_path.o "$obj"/wavtok_path.o "$obj"/ac_api.o
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$out" "$obj"/core.o "$obj"/mimi_path.o "$obj"/dac_path.o "$obj"/wavtok_path.o "$obj"/stream_path.o "$obj"/ac_api.o
 echo "built $out"
 bash "$here/check_isa.sh" "$out"
 # The structural scans below read hipcc's device assembly; what they accept was validated against ONE compiler.  A different hipcc
@@ -43,7 +43,7 @@ case "$hipcc_ver" in
        fi ;;
 esac
 asm=()
-for tu in core mimi_path dac_path wavtok_path ac_api; do asm+=("$obj/$tu-hip-amdgcn-amd-amdhsa-gfx950.s"); done    # (explicit list: no stale .s of removed translation units)
+for tu in core mimi_path dac_path wavtok_path stream_path ac_api; do asm+=("$obj/$tu-hip-amdgcn-amd-amdhsa-gfx950.s"); done    # (explicit list: no stale .s of removed translation units)
 # Round 4: hipcc's hazard recogniser left an MFMA -> taken branch -> v_accvgpr_read of the MFMA's result without wait states in one
 # version of rvq16.h's tile loop (run-to-run different tokens; profiles/r4_variants.md).  The scan fails the build if any kernel
 # reads an MFMA result across a branch closer than the matrix pipe needs.

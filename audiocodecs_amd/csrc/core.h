@@ -27,6 +27,7 @@ using namespace ac;
 
 namespace ac {
 constexpr int THIN_MAXK = 8;   // widest kernel of the dedicated stem / head kernels (thin.h)
+struct RbFused6Params;         // rb_fused6.h
 }
 
 namespace acimpl {
@@ -168,6 +169,10 @@ struct ac_handle {
     size_t cb16 = 0, cb16_inv = 0;   // rvq16.h: split16 images of the codebooks + their 2^-s (0: not packed -- other arithmetic or shape)
     // bounds of the fused thin-channel chains (enc_front.h): |stem out| <= sb0 + sb1 amax(sig); |block out| <= fb0 + fb1h H + fb1x X
     struct ChainBounds { float sb0 = 0.f, sb1 = 0.f, fb0 = 0.f, fb1h = 0.f, fb1x = 0.f; bool ok = false; } enc_front, dec_tail;   // dec_tail: sb0 / sb1 are the transposed conv's
+    // enc_stream.h / dec_stream.h (round 6): split16 fragment images with every k-step's 32 columns in the lanes' load order (float offsets
+    // into the blob) and their per-row 2^-s: the stem as a [32][7 -> 32] matrix, the strided conv, the transposed conv, the head as a
+    // [7 -> 16 taps][32] matrix; the 32-channel blocks' images are ResBlockPlan::w3p_off / wfp_off
+    struct StreamImgs { size_t stem_f = 0, stem_inv = 0, down_f = 0, down_inv = 0, up_f = 0, up_inv = 0, head_f = 0, head_inv = 0; bool enc_ok = false, dec_ok = false; } simg;
     // Developer / test switches.  Latched from the environment ONCE, at ac_finalize (latch_dev_switches, ac_api.hip); afterwards only
     // ac_debug_set changes them -- no compute entry point reads the environment (round-3 advisor finding: hundreds of getenv calls per
     // step, racing with a test's setenv, and a stray variable in a user's shell silently changing which kernel runs mid-process).
@@ -181,6 +186,7 @@ struct ac_handle {
         int tap8_spread = 1;        // AC_TAP8_SPREAD=0|1|2: tap_gemm8's requests of a stage at its top / dealt between its MFMA units where that measured faster (128-row tiles) / dealt everywhere (bit-identical)
         int rb6_dbg = 0;            // AC_RB6_DBG          : timing variants of the fused blocks (wrong results)
         int rb_stream = 1;          // AC_RB_STREAM=0      : the 64-channel causal blocks through rb_fused6.h instead of rb_stream6.h (A/B, cross-check tests)
+        int chain_stream = 1;       // AC_CHAIN_STREAM=0   : the fused thin-channel chains through enc_front.h / dec_tail.h instead of enc_stream.h / dec_stream.h
         int front_seg = 0, tail_seg = 0;   // AC_FRONT_SEG / AC_TAIL_SEG: chunks per stream of the fused chains (0: from the batch size)
         int front_ldspad = 0;       // AC_FRONT_LDSPAD     : extra dynamic LDS (forces one workgroup per CU)
         int lstm_dbg = 0;           // AC_LSTM_DBG         : fault injection / traces of the persistent LSTM
@@ -483,7 +489,7 @@ struct Packer {
         for (int k = 0; sc && k < C; ++k) kf.push_back(hid + k);
         rb.w3f_off = frag16(rb.c3.w_off, hid, rb.c3.Ktot, k3, &rb.winv3_off);
         rb.wff_off = frag16(rb.fused.w_off, C, rb.fused.Ktot, kf, &rb.winvf_off);
-        if (C == 64 && use16()) {   // rb_stream6.h: column 8 kq + e of a k-step <-> channel 4 kq + e (e < 4), 16 + 4 kq + e - 4 (e >= 4) of its 32
+        if ((C == 64 || C == 32) && use16()) {   // rb_stream6.h / enc_stream.h / dec_stream.h: column 8 kq + e of a k-step <-> channel 4 kq + e (e < 4), 16 + 4 kq + e - 4 (e >= 4) of its 32
             std::vector<int> k3p(k3.size()), kfp(kf.size());
             for (size_t k = 0; k < k3.size(); ++k) k3p[k] = k3[(k & ~(size_t)31) + ((k & 4) ? 16 : 0) + 4 * ((k >> 3) & 3) + (k & 3)];
             for (size_t k = 0; k < kf.size(); ++k) kfp[k] = kf[(k & ~(size_t)31) + ((k & 4) ? 16 : 0) + 4 * ((k >> 3) & 3) + (k & 3)];
@@ -566,6 +572,36 @@ struct Packer {
         rb6(rb, true);
         return true;
     }
+    // the lanes' load order of the stream kernels (rb_stream6.h): column 8 kq + e of a k-step <-> 4 kq + e (e < 4), 16 + 4 kq + e - 4 (e >= 4)
+    static std::vector<int> perm32(const std::vector<int>& km) {
+        std::vector<int> o(km.size());
+        for (size_t k = 0; k < km.size(); ++k) o[k] = km[(k & ~(size_t)31) + ((k & 4) ? 16 : 0) + 4 * ((k >> 3) & 3) + (k & 3)];
+        return o;
+    }
+    // enc_stream.h: the stem as a [32][7 -> 32] MFMA operand (tap j in column j), the strided conv [64][128] permuted
+    void stream_enc(const PackedGemm& stem, const ResBlockPlan& rb, const PackedGemm& down, ac_handle::StreamImgs& si) {
+        si.enc_ok = false;
+        if (!use16() || !h->enc_front.ok || !rb.w3p_off || stem.N != 32 || stem.Ktot != 7 || down.N != 64 || down.Ktot != 128) return;
+        std::vector<int> k7(32, -1), kd(128);
+        for (int k = 0; k < 7; ++k) k7[k] = k;
+        for (int k = 0; k < 128; ++k) kd[k] = k;
+        si.stem_f = frag16(stem.w_off, 32, 7, k7, &si.stem_inv);
+        si.down_f = frag16(down.w_off, 64, 128, perm32(kd), &si.down_inv);
+        si.enc_ok = true;
+    }
+    // dec_stream.h: the transposed conv [64][128] permuted, the head's [7][32] taps as the rows of a [16][32] matrix (rows 7..15 zero)
+    void stream_dec(const PackedGemm& up, const ResBlockPlan& rb, const PackedGemm& head, ac_handle::StreamImgs& si) {
+        si.dec_ok = false;
+        if (!use16() || !h->dec_tail.ok || !rb.w3p_off || up.N != 64 || up.Ktot != 128 || head.N != 1 || head.Ktot != 7 * 32) return;
+        std::vector<int> ku(128), kh(32);
+        for (int k = 0; k < 128; ++k) ku[k] = k;
+        for (int k = 0; k < 32; ++k) kh[k] = k;
+        si.up_f = frag16(up.w_off, 64, 128, perm32(ku), &si.up_inv);
+        const size_t pad = reserve(16 * 32);
+        for (int i = 0; i < 16 * 32; ++i) blob[pad + i] = i < 7 * 32 ? blob[head.w_off + i] : 0.f;
+        si.head_f = frag16(pad, 16, 32, perm32(kh), &si.head_inv);
+        si.dec_ok = true;
+    }
     // enc_front.h: constants of the bounds that stand in for the amax of the tensors inside a fused chain
     //   |stem(x)| <= sb0 + sb1 amax(x)            (largest |bias|, largest row 1-norm)
     //   |block out| <= fb0 + fb1h bound(hidden) + fb1x bound(block in)
@@ -600,6 +636,17 @@ struct Packer {
             for (int k = 0; k < up.Ktot; ++k) l1 += std::fabs((double)blob[up.w_off + (size_t)n * up.Ktot + k]);
             cb.sb1 = std::max(cb.sb1, (float)(l1 * 1.000001));
             cb.sb0 = std::max(cb.sb0, std::fabs(blob[up.b_off + n]));
+        }
+        // dec_stream.h: |block out| <= fb0 + fb1h bound(hidden) + fb1x bound(block in) -- the scale of ELU(v) as the head's MFMA operand
+        const int hid = rb.C / 2;
+        cb.fb0 = cb.fb1h = cb.fb1x = 0.f;
+        for (int n = 0; n < rb.C; ++n) {
+            double lh = 0.0, lx = 0.0;
+            for (int k = 0; k < hid; ++k) lh += std::fabs((double)blob[rb.fused.w_off + (size_t)n * rb.fused.Ktot + k]);
+            for (int k = hid; k < rb.fused.Ktot; ++k) lx += std::fabs((double)blob[rb.fused.w_off + (size_t)n * rb.fused.Ktot + k]);
+            cb.fb1h = std::max(cb.fb1h, (float)(lh * 1.000001));
+            cb.fb1x = std::max(cb.fb1x, (float)(lx * 1.000001));
+            cb.fb0 = std::max(cb.fb0, std::fabs(blob[rb.fused.b_off + n]));
         }
         cb.ok = true;
     }
@@ -888,6 +935,9 @@ int decoder_fwd(ac_handle* h, hipStream_t st, const long long* toks, int B, int 
 // ---- wrappers around launches whose kernels live in core.hip (the per-codec translation units never include a header that
 // DEFINES a non-template kernel: one definition per library)
 bool rb64_identity_head_fwd(ac_handle* h, hipStream_t st, const ResBlockPlan& rb, const Act2& x, const PackedGemm& head, int head_k, float* sig, int B, int* rc);
+int enc_stream_fwd(ac_handle* h, hipStream_t st, const float* sig, const float* rel_len, int B, int T, float* y, float* dbg_x0, float* dbg_y1, const unsigned* amax_sig, unsigned* amax_out);   // stream_path.hip
+int dec_stream_fwd(ac_handle* h, hipStream_t st, const Act& xe, int B, float* sig, float* dbg_u, float* dbg_v, const unsigned* amax_x);   // stream_path.hip
+int launch_rb_stream6(ac_handle* h, hipStream_t st, RbFused6Params& p, const ResBlockPlan& rb, bool sc, Out out, int B);   // stream_path.hip (p filled by launch_rb_fused6)
 int rb64_identity_fwd(ac_handle* h, hipStream_t st, const ResBlockPlan& rb, const Act2& x, Out out, int B, const unsigned** amax_out);   // rb_fused6<64, false> / rb_fused<64,64,2,false>
 int rb128_identity_fwd(ac_handle* h, hipStream_t st, const ResBlockPlan& rb, const Act2& x, Out out, int B, const unsigned** amax_out); // rb128_fused6<false>
 int rvq_encode_cdist_launch(ac_handle* h, hipStream_t st, const RvqEncParams& p, unsigned blocks, const _Float16* epk16 = nullptr, const float* einv = nullptr);   // rvq_encode16_kernel<16, 1, true> (images given, H = 256) or rvq_encode_kernel<H/16, 1, true>

@@ -12,7 +12,6 @@
 #include "thin.h"
 #include "rb_fused.h"
 #include "rb_fused6.h"
-#include "rb_stream6.h"
 #include "thin_conv6.h"
 #include "rb_fused6_128.h"
 #include "enc_front.h"
@@ -650,32 +649,8 @@ int launch_rb_fused6(ac_handle* h, hipStream_t st, const ResBlockPlan& rb, const
     if (!p.amax_in) return fail(h, AC_ESTATE, "out of amax slots (split16.h)");
     if (with_head) p.amax_out = nullptr;        // nothing reads the block's output but the head
     const double L = x.raw.L;
-    if (C == 64 && !with_head && h->dev.rb_stream && p.lpad == 2 && rb.w3p_off && (long long)x.raw.L * 256 < 0x70000000LL) {
-        // rb_stream6.h: 16 waves per CU, one wave = one segment of one clip.  Segments are sized so that one round of the chip's
-        // 4096 waves covers the batch (the last segment of a clip is the short one)
-        using SCfg = Rs6Cfg<SC>;
-        p.w3f = reinterpret_cast<const __bf16*>(h->blob + rb.w3p_off);
-        p.wff = reinterpret_cast<const __bf16*>(h->blob + rb.wfp_off);
-        const int tiles = cdiv(x.raw.L, 16);
-        const int want = std::max(1, 256 * SCfg::WAVES / std::max(1, B));
-        const int seg_tiles = cdiv(tiles, std::min(tiles, want));
-        p.seg_rows = seg_tiles * 16;
-        p.nseg = cdiv(tiles, seg_tiles);
-        const long long segs = (long long)B * p.nseg;
-        const int grid = (int)std::min<long long>(256, (segs + SCfg::WAVES - 1) / SCfg::WAVES);
-        ProfScope ps(h, st, SC ? "rb_stream6_kernel<true>" : "rb_stream6_kernel<false>",
-                     2.0 * B * L * ((double)(C / 2) * 3 * C + (double)C * (C / 2 + (SC ? C : 0))),
-                     (double)B * L * C * 4.0 * (1 + (out.raw ? 1 : 0) + (out.elu ? 1 : 0)));
-        auto go = [&](auto kern) -> int {
-            if (int rc = ensure_lds(h, reinterpret_cast<const void*>(kern), SCfg::lds_bytes)) return rc;
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), SCfg::lds_bytes, st, p);
-            return AC_OK;
-        };
-        if (out.raw && out.elu) return go(rb_stream6_kernel<SC, true, true>);
-        if (out.elu) return go(rb_stream6_kernel<SC, false, true>);
-        return go(rb_stream6_kernel<SC, true, false>);
-        return AC_OK;
-    }
+    if (C == 64 && !with_head && h->dev.rb_stream && p.lpad == 2 && rb.w3p_off && (long long)x.raw.L * 256 < 0x70000000LL)
+        return launch_rb_stream6(h, st, p, rb, SC, out, B);      // rb_stream6.h (stream_path.hip): 16 waves per CU, one wave = one stream
     const size_t lds6 = with_head ? Cfg::lds_bytes16_head : Cfg::lds_bytes16;
     if (int rc = ensure_lds(h, with_head ? reinterpret_cast<const void*>(rb_fused6_head_kernel) : reinterpret_cast<const void*>(rb_fused6_kernel<C, SC, 2>), lds6)) return rc;
     const long long total = (long long)B * p.ntiles;
@@ -907,6 +882,13 @@ int enc_front_fwd(ac_handle* h, hipStream_t st, const float* sig, const float* r
     p.sb0 = h->enc_front.sb0; p.sb1 = h->enc_front.sb1;
     p.hb0 = rb.hb0; p.hb1 = rb.hb1;
     p.fb0 = h->enc_front.fb0; p.fb1h = h->enc_front.fb1h; p.fb1x = h->enc_front.fb1x;
+    if (h->dev.chain_stream && h->simg.enc_ok) {       // round 6: the sixteen-waves-per-CU form (enc_stream.h, stream_path.hip)
+        if (int rc = enc_stream_fwd(h, st, sig, rel_len, B, T, y, dbg_x0, dbg_y1, p.amax_sig, p.amax_out)) return rc;
+        HIPCHK(h, hipGetLastError());
+        out->raw = Act{y, (long long)p.M * 64, 64, p.M, 64, p.amax_out, B};
+        out->elu = Act{nullptr, (long long)p.M * 64, 64, p.M, 64, p.amax_out, B};
+        return AC_OK;
+    }
     size_t lds = EF_LDS;
     lds += (size_t)h->dev.front_ldspad;     // developer: force one workgroup per CU
     if (int rc = ensure_lds(h, reinterpret_cast<const void*>(enc_front_kernel), lds)) return rc;

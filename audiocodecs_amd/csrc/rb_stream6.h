@@ -20,7 +20,7 @@
 //     group covers the 64 banks exactly once at any tap offset.  Weight fragments are lane-linear (1 KB per wave read).
 // Accumulation order over k-steps and partial products is rb_fused6's; inside one MFMA the 32 products arrive in the permuted channel order.
 #pragma once
-#include "rb_fused6.h"
+#include "rb_params6.h"
 
 namespace ac {
 
@@ -86,6 +86,17 @@ template <bool SC, bool YR, bool YE>
 __global__ __launch_bounds__(1024) void rb_stream6_kernel(const RbFused6Params p) {
     using Cfg = Rs6Cfg<SC>;
     constexpr int KSB = Cfg::KSB;
+#if defined(AC_DEVELOPER) && defined(RS6_ABL)      // timing ablations of developer builds (wrong results): 1 no stage A, 2 no stage B, 4 no staging
+    constexpr int ABL = RS6_ABL;                   // arithmetic, 8 no stores, 16 no loads, 32 no output ELU
+#else
+    constexpr int ABL = 0;
+#endif
+#ifndef RS6_LDAUX
+#define RS6_LDAUX 0
+#endif
+#ifndef RS6_STAUX
+#define RS6_STAUX 0
+#endif
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_rs[];
     unsigned char* Wa = smem_rs;
     unsigned char* Wb = Wa + Cfg::WA_BYTES;
@@ -125,34 +136,47 @@ __global__ __launch_bounds__(1024) void rb_stream6_kernel(const RbFused6Params p
         // rows t .. t + 15 in operand shape: r[kc][h] = channels 32 kc + 16 h + 4 kq + {0..3} of row t + li (rows past the clip: zeros)
         auto request = [&](int t, f32x4 (&r)[2][2]) {
             const int row = t + li;
-            const int ro = row < p.L ? row * 256 + kq * 16 : 0x7fff0000;
+            const int ro = row < p.L && !(ABL & 16) ? row * 256 + kq * 16 : 0x7fff0000;
 #pragma unroll
             for (int kc = 0; kc < 2; ++kc)
 #pragma unroll
-                for (int h = 0; h < 2; ++h) r[kc][h] = bufload16(rs, ro + kc * 128 + h * 64, 0);
+                for (int h = 0; h < 2; ++h) {
+                    if (ABL & 768) {   // address-pattern probes for the loads: 256: 8 rows x 128 B per instruction, 512: 4 rows x 256 B
+                        const int c = kc * 2 + h;
+                        const int r2 = (ABL & 256) ? t + (li & ~1) + (c & 1) : t + (li & ~3) + c;
+                        const int o2 = (ABL & 256) ? ((c >> 1) * 2 + (li & 1)) * 64 + kq * 16 : (li & 3) * 64 + kq * 16;
+                        r[kc][h] = bufload16(rs, r2 < p.L ? r2 * 256 + o2 : 0x7fff0000, 0);
+                    } else
+                    r[kc][h] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, ro + kc * 128 + h * 64, 0, RS6_LDAUX));
+                }
         };
         // ELU + split of one row set -> slab rows `row0 + li` (both planes)
         auto stage_xe = [&](const f32x4 (&r)[2][2], int row0_bytes) {
 #pragma unroll
             for (int kc = 0; kc < 2; ++kc) {
-                const Hl8 e = split16_regs8(elu4p(r[kc][0]), elu4p(r[kc][1]), cs.sx);
+                const Hl8 e = (ABL & 4) ? Hl8{__builtin_bit_cast(f16x8, r[kc][0]), __builtin_bit_cast(f16x8, r[kc][1])} : split16_regs8(elu4p(r[kc][0]), elu4p(r[kc][1]), cs.sx);
                 *reinterpret_cast<f16x8*>(sl + row0_bytes + unit(0, kc, 0)) = e.hi;
                 *reinterpret_cast<f16x8*>(sl + row0_bytes + unit(1, kc, 0)) = e.lo;
             }
         };
 
-        f32x4 rx[2][2];                     // the tile's raw rows (identity shortcut: kept until the output)
-        Hl8 xr[2];                          // ... split with the second stage's scale: the shortcut conv's operand
-        {   // ---- first tile of the segment: its rows and the two halo rows (reflect / zeros: rb_fused6.h load_tile)
-            request(t_beg, rx);
-            f32x4 rh[2][2];
-            int j = t_beg - 2 + li;
+        // the two halo rows in front of row t (reflect / zeros: rb_fused6.h load_tile), lanes li < 2
+        auto request_halo = [&](int t, f32x4 (&r)[2][2]) {
+            int j = t - 2 + li;
             if (p.pad == PAD_REFLECT) j = j < 0 ? -j : (j >= p.Lp ? 2 * (p.Lp - 1) - j : j);
             const int ho = li < 2 && j >= 0 && j < p.L ? j * 256 + kq * 16 : 0x7fff0000;
 #pragma unroll
             for (int kc = 0; kc < 2; ++kc)
 #pragma unroll
-                for (int h = 0; h < 2; ++h) rh[kc][h] = bufload16(rs, ho + kc * 128 + h * 64, 0);
+                for (int h = 0; h < 2; ++h) r[kc][h] = bufload16(rs, ho + kc * 128 + h * 64, 0);
+        };
+
+        f32x4 rx[2][2];                     // the tile's raw rows (identity shortcut: kept until the output)
+        Hl8 xr[2];                          // ... split with the second stage's scale: the shortcut conv's operand
+        {   // ---- first tile of the segment: its rows and the two halo rows
+            request(t_beg, rx);
+            f32x4 rh[2][2];
+            request_halo(t_beg, rh);
             if (li < 2) stage_xe(rh, 0);
             stage_xe(rx, 2 * 16);
             if (SC) { xr[0] = split16_regs8(rx[0][0], rx[0][1], cs.sb); xr[1] = split16_regs8(rx[1][0], rx[1][1], cs.sb); }
@@ -162,11 +186,12 @@ __global__ __launch_bounds__(1024) void rb_stream6_kernel(const RbFused6Params p
             const bool has_next = t + 16 < t_end;
             f32x4 rn[2][2];
             request(has_next ? t + 16 : 0x3fffff00, rn);           // (no next tile: every row out of range, no memory access)
+            __builtin_amdgcn_sched_barrier(0);                     // the requests stay HERE: a tile ahead of their use
 
             // ---- stage A: hidden = ELU(conv_k3(xe) + b3); M = 32 hidden channels (2 tiles), N = this tile's 16 rows, K = 3 taps x 64
             f32x4 accA[2] = {zero4, zero4};
 #pragma unroll
-            for (int ks = 0; ks < 6; ++ks) {
+            for (int ks = 0; ks < ((ABL & 1) ? 0 : 6); ++ks) {
                 const int j = ks >> 1, kc = ks & 1;
                 const f16x8 xh = *reinterpret_cast<const f16x8*>(sl + unit(0, kc, j));
                 const f16x8 xl = *reinterpret_cast<const f16x8*>(sl + unit(1, kc, j));
@@ -193,7 +218,7 @@ __global__ __launch_bounds__(1024) void rb_stream6_kernel(const RbFused6Params p
             // ---- stage B: y = [W1 | Ws] [hidden | x]^T; M = 64 output channels (4 tiles), K = 32 hidden (+ 64 raw channels)
             f32x4 acc[4] = {zero4, zero4, zero4, zero4};
 #pragma unroll
-            for (int ks = 0; ks < KSB; ++ks) {
+            for (int ks = 0; ks < ((ABL & 2) ? 0 : KSB); ++ks) {
                 const f16x8 xh = ks == 0 ? hf.hi : xr[ks - 1 > 0 ? 1 : 0].hi;
                 const f16x8 xl = ks == 0 ? hf.lo : xr[ks - 1 > 0 ? 1 : 0].lo;
 #pragma unroll
@@ -219,7 +244,9 @@ __global__ __launch_bounds__(1024) void rb_stream6_kernel(const RbFused6Params p
             }
             // ---- the next tile is staged BEFORE this tile's stores are issued (the wait for its rows must not cover the stores):
             //      halo = this tile's last two rows, copied inside the slab (lanes 0..31: one 16-byte unit each)
-            if (has_next) {
+            // (unconditionally: behind the segment's last tile the rows are zeros and nobody reads the slab again.  Under `if (has_next)`
+            //  hipcc sinks the REQUEST into the conditional block, next to its use, and every tile waits out a full HBM round trip)
+            {
                 if (lane < 32) {
                     unsigned char* hp = slab + ((lane >> 3) * Cfg::KQ_UNITS + ((lane >> 2) & 1) * Cfg::PL_UNITS + ((lane >> 1) & 1) * Cfg::KC_UNITS + (lane & 1)) * 16;
                     const u32x4_t hv = *reinterpret_cast<const u32x4_t*>(hp + 16 * 16);
@@ -229,15 +256,21 @@ __global__ __launch_bounds__(1024) void rb_stream6_kernel(const RbFused6Params p
                 if (SC) { xr[0] = split16_regs8(rn[0][0], rn[0][1], cs.sb); xr[1] = split16_regs8(rn[1][0], rn[1][1], cs.sb); }
             }
             // ---- stores
-            const int orow = row < p.L ? row * 256 + kq * 16 : 0x7fff0000;       // rows outside the clip: out of range, dropped
+            const int orow = row < p.L && !(ABL & 8) ? row * 256 + kq * 16 : 0x7fff0000;       // rows outside the clip: out of range, dropped
             {
                 const unsigned tm = amax16(acc);
                 omax = row < p.L && tm > omax ? tm : omax;
             }
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                if (YR) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, acc[c]), ry, orow + c * 64, 0, 0);
-                if (YE) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, elu4p(acc[c])), re, orow + c * 64, 0, 0);
+                if (ABL & 192) {       // address-pattern probes (garbage placement): 64: 8 rows x 128 B per instruction, 128: 4 rows x 256 B
+                    const int r2 = (ABL & 64) ? t + (li & ~1) + (c & 1) : t + (li & ~3) + c;
+                    const int o2 = (ABL & 64) ? ((c >> 1) * 2 + (li & 1)) * 64 + kq * 16 : (li & 3) * 64 + kq * 16;
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, acc[c]), re, r2 < p.L ? r2 * 256 + o2 : 0x7fff0000, 0, 0);
+                    continue;
+                }
+                if (YR) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, acc[c]), ry, orow + c * 64, 0, RS6_STAUX);
+                if (YE) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, (ABL & 32) ? acc[c] : elu4p(acc[c])), re, orow + c * 64, 0, RS6_STAUX);
             }
             if (!SC) {
 #pragma unroll

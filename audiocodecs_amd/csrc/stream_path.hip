@@ -1,0 +1,90 @@
+// The stream kernels of the thin stages (round 6): one wave = one stream, weights in LDS, sixteen waves per CU.
+// One translation unit of the library (core.h has the map): owns the kernels of rb_stream6.h and their launchers -- kept apart from core.hip
+// so that a change to these kernels recompiles in seconds.
+#include "core.h"
+#include "rb_stream6.h"
+#include "enc_stream.h"
+
+namespace acimpl {
+
+// The 64-channel causal residual block (EncodecResnetBlock, [HF] modeling_encodec.py:252-282; Mimi's identity-shortcut form).  `p` arrives
+// filled by launch_rb_fused6 (core.hip): tensors, amax slots, scales and bounds; here the permuted images, the segment geometry, the launch.
+int launch_rb_stream6(ac_handle* h, hipStream_t st, RbFused6Params& p, const ResBlockPlan& rb, bool sc, Out out, int B) {
+    constexpr int WAVES = Rs6Cfg<true>::WAVES;
+    p.w3f = reinterpret_cast<const __bf16*>(h->blob + rb.w3p_off);
+    p.wff = reinterpret_cast<const __bf16*>(h->blob + rb.wfp_off);
+    // segments are sized so that one round of the chip's 4096 waves covers the batch (the last segment of a clip is the short one)
+    const int tiles = cdiv(p.L, 16);
+    const int want = std::max(1, 256 * WAVES / std::max(1, B));
+    const int seg_tiles = h->dev.rb_stream > 1 ? std::min(tiles, h->dev.rb_stream - 1) : cdiv(tiles, std::min(tiles, want));   // (rb_stream = n + 1: n tiles per segment -- developer probe)
+    p.seg_rows = seg_tiles * 16;
+    p.nseg = cdiv(tiles, seg_tiles);
+    const long long segs = (long long)B * p.nseg;
+    const int grid = (int)std::min<long long>(256, (segs + WAVES - 1) / WAVES);
+    const double L = p.L;
+    ProfScope ps(h, st, sc ? "rb_stream6_kernel<true>" : "rb_stream6_kernel<false>",
+                 2.0 * B * L * (32.0 * 192 + 64.0 * (32 + (sc ? 64 : 0))),
+                 (double)B * L * 64 * 4.0 * (1 + (out.raw ? 1 : 0) + (out.elu ? 1 : 0)));
+    auto go = [&](auto kern, size_t lds) -> int {
+        if (int rc = ensure_lds(h, reinterpret_cast<const void*>(kern), lds)) return rc;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), lds, st, p);
+        return AC_OK;
+    };
+    if (sc) {
+        constexpr size_t lds = Rs6Cfg<true>::lds_bytes;
+        if (out.raw && out.elu) return go(rb_stream6_kernel<true, true, true>, lds);
+        if (out.elu) return go(rb_stream6_kernel<true, false, true>, lds);
+        return go(rb_stream6_kernel<true, true, false>, lds);
+    }
+    constexpr size_t lds = Rs6Cfg<false>::lds_bytes;
+    if (out.raw && out.elu) return go(rb_stream6_kernel<false, true, true>, lds);
+    if (out.elu) return go(rb_stream6_kernel<false, false, true>, lds);
+    return go(rb_stream6_kernel<false, true, false>, lds);
+}
+
+
+// ---- the encoder's thin-channel head (enc_stream.h): stem -> ResBlock(32) -> ELU -> Conv1d(32, 64, k4, s2); called by enc_front_fwd (core.hip),
+// which owns the shape checks, the amax slots and the output descriptors
+int enc_stream_fwd(ac_handle* h, hipStream_t st, const float* sig, const float* rel_len, int B, int T, float* y, float* dbg_x0, float* dbg_y1,
+                   const unsigned* amax_sig, unsigned* amax_out) {
+    const ResBlockPlan& rb = h->enc_rb[0];
+    const PackedGemm& gd = h->enc_down[0];
+    EncStreamParams p{};
+    p.sig = sig;
+    p.rel_len = rel_len;
+    p.w0f = reinterpret_cast<const __bf16*>(h->blob + h->simg.stem_f);
+    p.w3f = reinterpret_cast<const __bf16*>(h->blob + rb.w3p_off);
+    p.wff = reinterpret_cast<const __bf16*>(h->blob + rb.wfp_off);
+    p.wdf = reinterpret_cast<const __bf16*>(h->blob + h->simg.down_f);
+    p.b0 = h->blob + h->enc_stem.b_off;
+    p.winv0 = h->blob + h->simg.stem_inv;
+    p.b3 = h->blob + rb.c3.b_off;
+    p.winv3 = h->blob + rb.winv3_off;
+    p.bf = h->blob + rb.fused.b_off;
+    p.winvf = h->blob + rb.winvf_off;
+    p.bd = h->blob + gd.b_off;
+    p.winvd = h->blob + h->simg.down_inv;
+    p.y = y;
+    p.dbg_x0 = dbg_x0;
+    p.dbg_y1 = dbg_y1;
+    p.B = B;
+    p.T = T;
+    p.M = cdiv(T, 2);
+    const int nchunks = cdiv(T, 32);
+    p.seg_chunks = std::max(8, cdiv(nchunks, std::max(1, 256 * ES_WAVES / B)));     // one round of the chip's 4096 waves
+    if (h->dev.front_seg > 0) p.seg_chunks = h->dev.front_seg;
+    p.segs_per_clip = cdiv(nchunks, p.seg_chunks);
+    p.amax_sig = amax_sig;
+    p.amax_out = amax_out;
+    p.sb0 = h->enc_front.sb0; p.sb1 = h->enc_front.sb1;
+    p.hb0 = rb.hb0; p.hb1 = rb.hb1;
+    p.fb0 = h->enc_front.fb0; p.fb1h = h->enc_front.fb1h; p.fb1x = h->enc_front.fb1x;
+    if (int rc = ensure_lds(h, reinterpret_cast<const void*>(enc_stream_kernel), ES_LDS)) return rc;
+    const long long streams = (long long)B * p.segs_per_clip;
+    ProfScope ps(h, st, "enc_stream_kernel", 2.0 * B * (double)T * (7.0 * 32 + 16.0 * 96 + 32.0 * 48 + 64.0 * 128 / 2),
+                 (double)B * T * 4.0 + (double)B * p.M * 256.0);
+    hipLaunchKernelGGL(enc_stream_kernel, dim3((unsigned)cdiv((int)streams, ES_WAVES)), dim3(64 * ES_WAVES), ES_LDS, st, p);
+    return AC_OK;
+}
+
+}  // namespace acimpl

@@ -15,7 +15,7 @@ sig = torch.from_numpy((prng.normal(123, f"bench.sig.{name}", (batch, T)) * 0.1)
 res = {}
 with torch.no_grad():
     codec.sig_to_toks(sig[:2])
-    for mode in (1, 0, 1, 0):
+    for mode in [int(m) for m in os.environ.get('RB_MODES', '1,0,1,0').split(',')]:
         debug_set(codec, "rb_stream", mode)
         toks = codec.sig_to_toks(sig); wav = codec.toks_to_sig(toks); torch.cuda.synchronize()
         st = codec.profile_kernels(lambda: [codec.toks_to_sig(codec.sig_to_toks(sig)) for _ in range(5)])
@@ -26,7 +26,7 @@ with torch.no_grad():
         tot = sum(s[2] for s in st) / 5
         print(f"rb_stream={mode}: step kernels {tot:.3f} ms | " + " ".join(f"{k}={v:.3f}" for k, v in sorted(rb.items())), flush=True)
         res[mode] = (toks.cpu().numpy(), wav.cpu().numpy())
-t1, w1 = res[1]; t0, w0 = res[0]
+ks = sorted(res); t1, w1 = res[ks[-1]]; t0, w0 = res[ks[0]]
 print("tokens differing:", int((t1 != t0).sum()), "of", t1.size)
 d = (w1.astype(np.float64) - w0.astype(np.float64))
 print("waveform: bit-equal" if np.array_equal(w1, w0) else f"waveform max abs diff {np.abs(d).max():.3e} rms {np.sqrt((d**2).mean()):.3e} (signal rms {np.sqrt((w0.astype(np.float64)**2).mean()):.3e})")
