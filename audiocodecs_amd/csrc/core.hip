@@ -945,6 +945,11 @@ int dec_tail_fwd(ac_handle* h, hipStream_t st, const Act& xe, int B, float* sig,
     if (!p.amax_x) return fail(h, AC_ESTATE, "out of amax slots (split16.h)");
     p.ub0 = h->dec_tail.sb0; p.ub1 = h->dec_tail.sb1;
     p.hb0 = rb.hb0; p.hb1 = rb.hb1;
+    if (h->dev.chain_stream && h->simg.dec_ok) {       // round 6: the sixteen-waves-per-CU form (dec_stream.h, stream_path.hip)
+        if (int rc = dec_stream_fwd(h, st, xe, B, sig, dbg_u, dbg_v, p.amax_x)) return rc;
+        HIPCHK(h, hipGetLastError());
+        return AC_OK;
+    }
     if (int rc = ensure_lds(h, reinterpret_cast<const void*>(dec_tail_kernel), DT_LDS)) return rc;
     const long long streams = (long long)B * p.segs_per_clip;
     {

@@ -4,6 +4,7 @@
 #include "core.h"
 #include "rb_stream6.h"
 #include "enc_stream.h"
+#include "dec_stream.h"
 
 namespace acimpl {
 
@@ -84,6 +85,48 @@ int enc_stream_fwd(ac_handle* h, hipStream_t st, const float* sig, const float* 
     ProfScope ps(h, st, "enc_stream_kernel", 2.0 * B * (double)T * (7.0 * 32 + 16.0 * 96 + 32.0 * 48 + 64.0 * 128 / 2),
                  (double)B * T * 4.0 + (double)B * p.M * 256.0);
     hipLaunchKernelGGL(enc_stream_kernel, dim3((unsigned)cdiv((int)streams, ES_WAVES)), dim3(64 * ES_WAVES), ES_LDS, st, p);
+    return AC_OK;
+}
+
+
+// ---- the decoder's thin-channel tail (dec_stream.h): ConvTranspose1d(64, 32, k4, s2) -> ResBlock(32) -> ELU -> Conv1d(32, 1, k7); called by
+// dec_tail_fwd (core.hip)
+int dec_stream_fwd(ac_handle* h, hipStream_t st, const Act& xe, int B, float* sig, float* dbg_u, float* dbg_v, const unsigned* amax_x) {
+    const int last = h->cfg.num_ratios - 1;
+    const ResBlockPlan& rb = h->dec_rb[last];
+    const PackedGemm& gu = h->dec_up[last];
+    DecStreamParams p{};
+    p.xe = xe.p;
+    p.wuf = reinterpret_cast<const __bf16*>(h->blob + h->simg.up_f);
+    p.w3f = reinterpret_cast<const __bf16*>(h->blob + rb.w3p_off);
+    p.wff = reinterpret_cast<const __bf16*>(h->blob + rb.wfp_off);
+    p.whf = reinterpret_cast<const __bf16*>(h->blob + h->simg.head_f);
+    p.bu = h->blob + gu.b_off;
+    p.winvu = h->blob + h->simg.up_inv;
+    p.b3 = h->blob + rb.c3.b_off;
+    p.winv3 = h->blob + rb.winv3_off;
+    p.bf = h->blob + rb.fused.b_off;
+    p.winvf = h->blob + rb.winvf_off;
+    p.bh = h->blob + h->dec_head.b_off;
+    p.winvh = h->blob + h->simg.head_inv;
+    p.sig = sig;
+    p.dbg_u = dbg_u;
+    p.dbg_v = dbg_v;
+    p.B = B;
+    p.L = xe.L;
+    const int nchunks = cdiv(xe.L, 16);
+    p.seg_chunks = std::max(8, cdiv(nchunks, std::max(1, 256 * DS_WAVES / B)));
+    if (h->dev.tail_seg > 0) p.seg_chunks = h->dev.tail_seg;
+    p.segs_per_clip = cdiv(nchunks, p.seg_chunks);
+    p.amax_x = amax_x;
+    p.ub0 = h->dec_tail.sb0; p.ub1 = h->dec_tail.sb1;
+    p.hb0 = rb.hb0; p.hb1 = rb.hb1;
+    p.fb0 = h->dec_tail.fb0; p.fb1h = h->dec_tail.fb1h; p.fb1x = h->dec_tail.fb1x;
+    if (int rc = ensure_lds(h, reinterpret_cast<const void*>(dec_stream_kernel), DS_LDS)) return rc;
+    const long long streams = (long long)B * p.segs_per_clip;
+    ProfScope ps(h, st, "dec_stream_kernel", 2.0 * B * (double)xe.L * (64.0 * 128 + 2.0 * (16.0 * 96 + 32.0 * 48 + 7.0 * 32)),
+                 (double)B * xe.L * 256.0 + (double)B * xe.L * 8.0);
+    hipLaunchKernelGGL(dec_stream_kernel, dim3((unsigned)cdiv((int)streams, DS_WAVES)), dim3(64 * DS_WAVES), DS_LDS, st, p);
     return AC_OK;
 }
 
