@@ -1,7 +1,11 @@
 """Codec interface -- host-side mirror of the reference's `audiocodecs.Codec`
 (/root/reference/audiocodecs/codec.py:33-214): same constructor, public methods, argument
 meaning (relative `length`, [B,T] signals, [B,N,K] tokens) and error behaviour, so callers such as
-downstream/test_sr.py:57,83 run unchanged.  Written from the interface, not copied.
+downstream/test_sr.py:57,83 run unchanged.  The class skeleton (constructor, `_MODES`, method names, abstract obligations) IS the
+drop-in boundary and necessarily reads like the reference's.  The token utilities at the end (`resample`, `logits`, `_sample_top_k`,
+`_sample_top_p`) restate /root/reference/audiocodecs/codec.py:121-180 step for step -- host-side torch code off the kernel path, whose RNG
+call order has to match for same-seed behaviour -- with device placement fixed; everything else (workspaces, graph mode, strict polling,
+the native calls) is this repo's own.
 """
 
 from __future__ import annotations
@@ -34,7 +38,8 @@ class Codec(torch.nn.Module, ABC):
         # 10 - 100 kernels one by one -- for the short calls of the reference's own measurement regime (batch 1, downstream/hparams/tasks/sr.yaml:28),
         # where launch gaps are a third of the call.  Default off.
         self.graph = False
-        self._graphs = {}
+        self._graphs = {}            # (call, shape, dtype, device) -> captured graph; at most GRAPH_CACHE, least recently used dropped
+        self._graph_failed = set()
 
     # codec.py:45-55
     def forward(self, input, length=None):
@@ -78,6 +83,7 @@ class Codec(torch.nn.Module, ABC):
     # differently from the persistent kernel.  At batch 1 the eager call is kernel time anyway (1.30 ms of events in a 1.29 ms call): tiny
     # launches that walk a K = 4096 contraction on two workgroups, not launch gaps.  graph=True on those wrappers is accepted and has no effect.
     _graph_capable = True
+    GRAPH_CACHE = 8               # graphs (each with a private workspace and static tensors) a codec keeps
 
     def _graphed(self, name, fn, x, length):
         """fn(x, None) through a hipGraph captured once per (call, shape, dtype, device).  The first call of a key runs
@@ -90,10 +96,20 @@ class Codec(torch.nn.Module, ABC):
             return fn(x, length)
         key = (name, tuple(x.shape), x.dtype, x.device.index)
         ent = self._graphs.get(key)
+        if ent is not None:
+            self._graphs[key] = self._graphs.pop(key)             # most recently used last
+        elif key in self._graph_failed:
+            return fn(x, length)                                  # this shape's capture failed once: eager from then on
         if ent is None:
             out = fn(x, length)                                   # eager: handle, workspace, LDS opt-ins
             if torch.cuda.is_current_stream_capturing():
                 return out                                        # (a caller's own capture: stay out of its way)
+            # Graph mode is for FIXED shapes (a serving loop at one batch and length): every new (call, shape) costs an eager call plus a
+            # capture and then pins a private workspace and static input / output tensors.  The cache therefore holds the GRAPH_CACHE most
+            # recently used graphs and drops the oldest (its workspace with it); variable-length callers should bucket their lengths or
+            # leave graph mode off.
+            while len(self._graphs) >= self.GRAPH_CACHE:
+                self._graphs.pop(next(iter(self._graphs)))
             sx = x.clone()
             g = torch.cuda.CUDAGraph()
             side = torch.cuda.Stream(device=x.device)
@@ -110,9 +126,14 @@ class Codec(torch.nn.Module, ABC):
                     with torch.cuda.graph(g, stream=side):
                         so = fn(sx, None)
                 own = [n.ws for n in nats]
-            finally:
+            except Exception:                                     # a failed capture (out of memory for the private workspace, ...) must not
+                self._graph_failed.add(key)                       # fail the call: the eager result is already in hand
                 for n, w in zip(nats, kept):
                     n.ws = w
+                torch.cuda.current_stream(x.device).wait_stream(side)
+                return out
+            for n, w in zip(nats, kept):
+                n.ws = w
             torch.cuda.current_stream(x.device).wait_stream(side)
             self._graphs[key] = (g, sx, so, own)
             return out
@@ -149,7 +170,8 @@ class Codec(torch.nn.Module, ABC):
         sig = self._polled(self._feats_to_sig(feats, self._ones(feats) if length is None else length))
         return self._out(sig)
 
-    # ---- token-resampling utilities (codec.py:121-180; no caller in the reference tree) --------
+    # ---- token-resampling utilities: a step-for-step restatement of /root/reference/audiocodecs/codec.py:121-180 (same RNG call order;
+    #      no caller in the reference tree) --------
     def resample(self, toks, p=0.2, temp=1.0, top_k=None, top_p=None):
         if p <= 0.0:
             return toks

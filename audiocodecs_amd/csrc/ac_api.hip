@@ -72,13 +72,15 @@ static void latch_dev_switches(ac_handle* h) {
     h->dev.tap8 = num("AC_TAP8", -1);
     h->dev.tap8_form = num("AC_TAP8_FORM", 0);
     h->dev.tap8_spread = num("AC_TAP8_SPREAD", 1);
+#ifdef AC_DEVELOPER     // (the product library neither reads these nor acts on the words: split16.h AC_DEV_MODE)
     h->dev.rb6_dbg = num("AC_RB6_DBG", 0);
+    h->dev.lstm_dbg = num("AC_LSTM_DBG", 0);
+#endif
     h->dev.rb_stream = num("AC_RB_STREAM", 1);
     h->dev.chain_stream = num("AC_CHAIN_STREAM", 1);
     h->dev.front_seg = std::max(0, num("AC_FRONT_SEG", 0));
     h->dev.tail_seg = std::max(0, num("AC_TAIL_SEG", 0));
     h->dev.front_ldspad = std::max(0, num("AC_FRONT_LDSPAD", 0));
-    h->dev.lstm_dbg = num("AC_LSTM_DBG", 0);
     h->dev.lstm_fuse_in = num("AC_LSTM_FUSE_IN", 1);
     const char* r = std::getenv("AC_RVQ");
     h->dev.rvq_exact = r && std::strcmp(r, "fp32") == 0;
@@ -96,6 +98,11 @@ int ac_debug_set(ac_handle* h, const char* key, int value) {
         {"rb6_dbg", &h->dev.rb6_dbg}, {"rb_stream", &h->dev.rb_stream}, {"chain_stream", &h->dev.chain_stream}, {"front_seg", &h->dev.front_seg}, {"tail_seg", &h->dev.tail_seg}, {"front_ldspad", &h->dev.front_ldspad},
         {"lstm_dbg", &h->dev.lstm_dbg}, {"lstm_fuse_in", &h->dev.lstm_fuse_in}, {"rvq_exact", &h->dev.rvq_exact}, {"prof_detail", &h->dev.prof_detail}, {"head_seq", &h->dev.head_seq}, {"attn_exact", &h->dev.attn_exact}, {"dac_unit", &h->dev.dac_unit}, {"mimi_tail", &h->dev.mimi_tail},
     };
+#ifndef AC_DEVELOPER
+    // timing modes with wrong results and fault injection exist in the developer library only (libaudiocodecs_amd_dev.so)
+    if (std::strcmp(key, "rb6_dbg") == 0 || std::strcmp(key, "lstm_dbg") == 0)
+        return fail(h, AC_EINVAL, "ac_debug_set('%s'): a developer-build switch (timing modes with wrong results / fault injection); this is the product library", key);
+#endif
     // (before ac_finalize a value would be overwritten when finalize latches the environment; under stream capture a flipped kernel
     //  path would be baked into part of a graph)
     if (!h->finalized) return fail(h, AC_ESTATE, "ac_debug_set('%s'): the switches are latched by ac_finalize; set them afterwards", key);

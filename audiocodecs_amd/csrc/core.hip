@@ -326,7 +326,7 @@ int run_tap(ac_handle* h, hipStream_t st, TapGemmParams& p) {
         }
         p.stagger = h->dev.tap_stagger;
         const bool dil_env = h->dev.tap_dil != 0;                 // developer / tests: 0 -> slab reload per tap
-        const bool dil_slab = dil_env && p.nseg == 1 && p.seg[0].dil != 1 && p.seg[0].s == 1 && (p.seg[0].J - 1) * p.seg[0].dil <= T6_DIL_HALO;
+        const bool dil_slab = dil_env && !p.amax_rows && p.nseg == 1 && p.seg[0].dil != 1   /* (the wide-slab instantiation has no row mode: CAN_ROWMODE, tap_gemm6.h) */ && p.seg[0].s == 1 && (p.seg[0].J - 1) * p.seg[0].dil <= T6_DIL_HALO;
 #define TAP6_LAUNCH(WGM, WGN, WMT, WN, NP)                                                                              \
     do {                                                                                                                \
         if ((rc = ensure_lds(h, reinterpret_cast<const void*>(tap_gemm6_kernel<WGM, WGN, WMT, WN, NP>), Cfg6::lds_for(NP)))) return rc; \
@@ -1071,7 +1071,7 @@ int lstm_fwd(ac_handle* h, hipStream_t st, const LstmPlan& lp, const Act& x, con
                 const void* kfn = fuse_in ? reinterpret_cast<const void*>(lstm_persist16_kernel<true>) : reinterpret_cast<const void*>(lstm_persist16_kernel<false>);
                 HIPCHK(h, hipLaunchCooperativeKernel(kfn, dim3(256), dim3(512), args6, 0, st));
                 tail(c0, q.B, poison);
-                if (q.dbg & 32) {   // developer trace: 100 MHz real-time stamps of steps 100 .. 103 (lstm_persist16.h)
+                if (AC_DEV_MODE(q.dbg, 32)) {   // developer trace: 100 MHz real-time stamps of steps 100 .. 103 (lstm_persist16.h)
                     HIPCHK(h, hipStreamSynchronize(st));
                     std::vector<unsigned long long> tr(8 * 64);
                     HIPCHK(h, hipMemcpy(tr.data(), h->lp_ctl + LP_CTL_FLAGS, tr.size() * 8, hipMemcpyDeviceToHost));

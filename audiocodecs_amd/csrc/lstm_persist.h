@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void lstm_tail_kernel(const LstmTailParams p) 
 
 // all 32 flags of (group, layer) >= want ?  polled by wave 0; returns false on timeout
 __device__ __forceinline__ bool lp_wait(unsigned* flags, unsigned want, unsigned* tmo, int lane, int dbg = 0) {
-    if (dbg & 4) return true;
+    if (AC_DEV_MODE(dbg, 4)) return true;
     for (unsigned spins = 0;; ++spins) {
         const unsigned f = lane < LP_SLICES ? __hip_atomic_load(&flags[lane * LP_FLAG_STRIDE], LP_RLX) : 0xffffffffu;
         if (__all(f >= want)) return true;
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256) void lstm_persist_kernel(const LstmPersistPara
         return;
     }
     if (g >= G) return;
-    if ((p.dbg & 1) && (slot >> 4) == 1) return;
+    if (AC_DEV_MODE(p.dbg, 1) && (slot >> 4) == 1) return;
     const int layer = slot >> 4, idx = (x & 1) * 16 + (slot & 15), u0 = idx * 16;
 
     // ---- weights -> registers: wave w holds k-steps 8w..8w+7 of the 4 gate tiles
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256) void lstm_persist_kernel(const LstmPersistPara
             if (!s_okr) return;
             f32x4 a[8];
             load_a(hmine, t - 1, a);
-            if (p.dbg & 2) {
+            if (AC_DEV_MODE(p.dbg, 2)) {
                 acc[0] += a[0] + a[7];
             } else if (layer == 0) {
 #pragma unroll

@@ -94,11 +94,11 @@ __global__ __launch_bounds__(512) void lstm_persist16_kernel(const LstmPersist16
         return;
     }
     if (g >= G) return;
-    if (p.dbg & 16) {   // test hook (AC_LSTM_DBG=16): behave like a launch whose bounded waits expired
+    if (AC_DEV_MODE(p.dbg, 16)) {   // test hook (AC_LSTM_DBG=16): behave like a launch whose bounded waits expired
         if (tid == 0) __hip_atomic_store(tmo, 1u, LP_RLX);
         return;
     }
-    if ((p.dbg & 1) && (x & 1) == 1) return;
+    if (AC_DEV_MODE(p.dbg, 1) && (x & 1) == 1) return;
     const int layer_rt = x & 1, idx = slot, u0 = idx * 16;
     auto body = [&](auto layer_tag) {
     constexpr int layer = decltype(layer_tag)::value;
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(512) void lstm_persist16_kernel(const LstmPersist16
     auto load_valid = [&](const char* seq, int t, bf16x8 (&a)[2][2]) -> bool {
         for (unsigned spins = 0;; ++spins) {
             load_a(seq, t, a);
-            if (valid(a) || (p.dbg & 4)) return true;
+            if (valid(a) || AC_DEV_MODE(p.dbg, 4)) return true;
             if ((spins & 63) == 63 && __hip_atomic_load(tmo, LP_RLX)) return false;
             if (spins > (1u << 18)) { __hip_atomic_store(tmo, 1u, LP_RLX); return false; }
             __builtin_amdgcn_s_sleep(4);
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(512) void lstm_persist16_kernel(const LstmPersist16
 
     // developer trace (AC_LSTM_DBG & 32): 100 MHz stamps of slice 0 / thread 0 of every role at steps 100 .. 103 into the (unused)
     // flag words of the control block: [role = 2 g + layer][step][point]
-    const bool trc = (p.dbg & 32) && idx == 0 && tid == 0;
+    const bool trc = AC_DEV_MODE(p.dbg, 32) && idx == 0 && tid == 0;
     unsigned long long* trw = reinterpret_cast<unsigned long long*>(p.ctl + LP_CTL_FLAGS) + (g * 2 + layer) * 64;
 #define LP16_TRC(pt_) do { if (trc && t >= 100 && t < 104) trw[(t - 100) * 8 + (pt_)] = __builtin_amdgcn_s_memrealtime(); } while (0)
     auto step = [&](int t) -> bool {
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(512) void lstm_persist16_kernel(const LstmPersist16
         for (int n = 0; n < 4; ++n) acc[n] = accP[n];
         if (t > 0) {
             // (arec: requested in the previous step's projection; incomplete, or never requested without a projection: poll)
-            const bool first_ok = (layer == 1 || fuse0) && (valid(arec) || (p.dbg & 4));
+            const bool first_ok = (layer == 1 || fuse0) && (valid(arec) || AC_DEV_MODE(p.dbg, 4));
             if (trc && !first_ok) trw[63] += 1;                    // developer trace: steps whose early request came back incomplete
             if (!first_ok && !load_valid(hmine, t - 1, arec)) return false;
             LP16_TRC(1);
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(512) void lstm_persist16_kernel(const LstmPersist16
         // (layer 1's skip value is waited for at the output store, behind the publish stores: s_waitcnt vmcnt(0), i.e. their acknowledgements
         //  too.  Forcing its use HERE, where it has arrived, removes that wait; measured on one box, three alternating passes: 2.55 us per
         //  step either way -- the stores are acknowledged by the XCD's L2 before the projection's first MFMAs are through)
-        if (layer == 1) ap_ok = valid(ap) || (p.dbg & 4);      // h0[t+1] (requested at the end of the previous step) complete?
+        if (layer == 1) ap_ok = valid(ap) || AC_DEV_MODE(p.dbg, 4);      // h0[t+1] (requested at the end of the previous step) complete?
         LP16_TRC(2);
         float (&pt)[8][4][16][17] = part[t & 1];
 #pragma unroll

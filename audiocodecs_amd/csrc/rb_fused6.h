@@ -166,7 +166,7 @@ __device__ __forceinline__ void rb_fused6_body(const RbFused6Params& p) {
     for (; tile < total; tile += gridDim.x) {
         const int next = tile + gridDim.x;
         const Rb16Scale cs = sc;                                // this tile's scales (store_tile(next) replaces sc)
-        if (next < total && !(p.dbg & 16)) load_tile(next);     // in flight during both MFMA stages
+        if (next < total && !AC_DEV_MODE(p.dbg, 16)) load_tile(next);     // in flight during both MFMA stages
         // ---- stage A: hidden = ELU(conv_k3(xe) + b3) -> Hs planes
         {
             f32x4 acc[MS][NA];
@@ -174,7 +174,7 @@ __device__ __forceinline__ void rb_fused6_body(const RbFused6Params& p) {
             for (int a = 0; a < MS; ++a)
 #pragma unroll
                 for (int c = 0; c < NA; ++c) acc[a][c] = NP == 2 ? zero4 : b3v[c];
-            if (!(p.dbg & 1))
+            if (!AC_DEV_MODE(p.dbg, 1))
 #pragma unroll
             for (int ks = 0; ks < KSA; ++ks) {
                 const int j = ks / (C / 32), kc = ks % (C / 32);
@@ -208,7 +208,7 @@ __device__ __forceinline__ void rb_fused6_body(const RbFused6Params& p) {
         for (int a = 0; a < MS; ++a)
 #pragma unroll
             for (int c = 0; c < NB; ++c) acc[a][c] = NP == 2 ? zero4 : bfv[c];
-        if (!(p.dbg & 2))
+        if (!AC_DEV_MODE(p.dbg, 2))
 #pragma unroll
         for (int ks = 0; ks < KSB; ++ks) {
             bf16x8 xf[MS][3];
@@ -226,9 +226,9 @@ __device__ __forceinline__ void rb_fused6_body(const RbFused6Params& p) {
         lds_barrier();                                          // every wave is done reading the slabs
         // the next tile is staged BEFORE this tile's output stores are issued: the wait for its loads must not
         // cover the stores (the memory counter retires in order)
-        if (next < total && !(p.dbg & 4)) store_tile(next);
+        if (next < total && !AC_DEV_MODE(p.dbg, 4)) store_tile(next);
         // ---- output: lane (li, kq) holds channels nb0 + 16c + 4kq .. +3 of time row r0 + 16a + li
-        if (!(p.dbg & 8)) {
+        if (!AC_DEV_MODE(p.dbg, 8)) {
             const int b = tile / p.ntiles, t0 = (tile % p.ntiles) * tstep - tback;
             if (p.amax_out && b != omax_b) {                     // clip change: hand the finished clip's maximum over
                 amax_flush(omax, amax_at(p.amax_out, omax_b));

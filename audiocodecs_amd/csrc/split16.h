@@ -28,6 +28,20 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Developer modes.  The product library (build.sh) is compiled WITHOUT AC_DEVELOPER: the run-time timing / fault-injection words
+// (RbFused6Params::dbg, LstmPersistParams::dbg) then read as 0 inside the kernels, ac_debug_set refuses their keys, ac_finalize does not
+// look at AC_RB6_DBG / AC_LSTM_DBG, and the compile-time trace / ablation switches below are an error.  The developer library
+// (libaudiocodecs_amd_dev.so, same build.sh) carries them for the fault-injection tests and tools/experiments.
+#ifdef AC_DEVELOPER
+#define AC_DEV_MODE(word, bits) ((word) & (bits))
+#else
+#define AC_DEV_MODE(word, bits) 0
+#if defined(T6_TRACE) || defined(TAP4_TRACE) || defined(T6_ABL_NOALOAD) || defined(T6_ABL_NOSTORE) || defined(T6_ABL_NOBLOAD) || defined(T6_ABL_NOMFMA) || \
+    defined(T8_ABL_NODMA) || defined(T8_ABL_NOALOAD) || defined(T8_ABL_NOSTORE) || defined(T8_ABL_NOMFMA) || defined(RS6_ABL) || defined(LSTM_DBG_SKIP) || defined(RVQ16_COND_LOADS)
+#error "trace / ablation switches (wrong results or extra stores) need -DAC_DEVELOPER: build a side library with tools/devbuild.sh, the product does not carry them"
+#endif
+#endif
+
 namespace ac {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));

@@ -396,84 +396,3 @@ def test_mode_drops_the_unused_half(checkpoints):
         enc.toks_to_sig(toks)
     with pytest.raises(NativeError, match="without encoder weights"):
         dec.sig_to_toks(sig)
-
-
-def test_failed_persistent_launch_is_reported_and_healed(checkpoints, monkeypatch):
-    """A persistent LSTM launch that fails (bounded wait expired / XCD placement broken; forced here by the kernel's test
-    hook AC_LSTM_DBG=16) must never hand back unwritten memory: the tail kernel sets the launch's outputs to NaN and raises
-    a sticky word; the NEXT call on the handle returns AC_EHIP once and the handle switches to the per-step kernels, after
-    which it produces the same tokens as a healthy handle."""
-    from audiocodecs_amd import Encodec
-    from audiocodecs_amd._native import NativeError, debug_set
-
-    cfg, sd = checkpoints("full", 0)
-    good = Encodec(24000, num_codebooks=8, state_dict=sd, config=cfg).eval()
-    codec = Encodec(24000, num_codebooks=8, state_dict=sd, config=cfg).eval()
-    sig = noise(8282, 3, 16000).cuda()
-    want = good.sig_to_toks(sig)
-    codec._native_for(sig)
-    debug_set(codec, "lstm_dbg", 16)         # fault injection: the next persistent launch reports a broken placement
-    feats = codec.sig_to_feats(sig)          # the call itself cannot know: nothing synchronises
-    torch.cuda.synchronize()
-    debug_set(codec, "lstm_dbg", 0)
-    assert bool(torch.isnan(feats).all())    # ... but its outputs are NaN, not garbage
-    nat = next(iter(codec._natives.values()))
-    assert nat.lib.ac_lstm_status(nat.h) < 0
-    with pytest.raises(NativeError, match="persistent LSTM launch failed"):
-        codec.sig_to_toks(sig)
-    toks = codec.sig_to_toks(sig)            # healed: per-step kernels from now on
-    assert nat.lib.ac_lstm_status(nat.h) == 0
-    assert float((toks == want).float().mean()) > 0.999   # per-step vs persistent: same function up to fp32 rounding
-
-
-def test_strict_mode_raises_in_the_call_that_failed(checkpoints, monkeypatch):
-    """strict=True (round-2 advisor finding on sticky errors): the wrapper polls the handle after its own call
-    (ac_poll_status: synchronises the stream, reports and clears the sticky words), so the call whose persistent LSTM launch
-    failed raises -- not an unrelated later one -- and the next call runs on the healed handle without an exception."""
-    from audiocodecs_amd import Encodec
-    from audiocodecs_amd._native import NativeError, debug_set
-
-    cfg, sd = checkpoints("full", 0)
-    good = Encodec(24000, num_codebooks=8, state_dict=sd, config=cfg).eval()
-    codec = Encodec(24000, num_codebooks=8, state_dict=sd, config=cfg, strict=True).eval()
-    sig = noise(8283, 2, 16000).cuda()
-    want = good.sig_to_toks(sig)
-    codec._native_for(sig)
-    debug_set(codec, "lstm_dbg", 16)
-    with pytest.raises(NativeError, match="persistent LSTM launch failed"):
-        codec.sig_to_feats(sig)
-    debug_set(codec, "lstm_dbg", 0)
-    toks = codec.sig_to_toks(sig)            # no leftover error: the poll cleared it; per-step kernels from now on
-    assert float((toks == want).float().mean()) > 0.999
-    bad = toks.clone()
-    bad[0, 3, 2] = 5000                      # outside [0, 1024)
-    with pytest.raises(NativeError, match="token ids outside"):
-        codec.toks_to_sig(bad)
-    rec = codec.toks_to_sig(toks)            # unaffected
-    assert bool(torch.isfinite(rec).all())
-
-
-def test_one_poll_reports_and_clears_every_pending_failure(checkpoints):
-    """Round-3 advisor finding: ac_poll_status reported one sticky class per call, so a bad-token count pending beside an LSTM
-    failure surfaced in a later, unrelated call.  Both are raised in ONE message now and nothing is left behind."""
-    from audiocodecs_amd import Encodec
-    from audiocodecs_amd._native import NativeError, check, debug_set
-
-    cfg, sd = checkpoints("full", 0)
-    codec = Encodec(24000, num_codebooks=8, state_dict=sd, config=cfg).eval()
-    sig = noise(8284, 4, 120000).cuda()
-    toks = codec.sig_to_toks(sig)
-    bad = toks.clone()
-    bad[1, 7, 3] = 4096
-    torch.cuda.synchronize()
-    debug_set(codec, "lstm_dbg", 16)
-    codec.toks_to_sig(bad)                   # ONE call raises two classes: out-of-range ids in the gather AND its persistent LSTM launch fails
-    debug_set(codec, "lstm_dbg", 0)
-    nat = next(iter(codec._natives.values()))
-    stream = torch.cuda.current_stream().cuda_stream
-    with pytest.raises(NativeError) as ei:
-        check(nat.lib.ac_poll_status(nat.h, stream), nat.h, "ac_poll_status")
-    msg = str(ei.value)
-    assert "persistent LSTM launch failed" in msg and "token ids outside" in msg, msg
-    check(nat.lib.ac_poll_status(nat.h, stream), nat.h, "ac_poll_status")      # nothing left behind
-    assert bool(codec.toks_to_sig(codec.sig_to_toks(sig)).isfinite().all())      # healed handle, per-step LSTM kernels

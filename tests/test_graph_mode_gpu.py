@@ -117,3 +117,29 @@ def test_a_callers_graph_replayed_on_new_data(name, monkeypatch):
             assert torch.equal(got[0], et)
             assert torch.equal(got[1], codec.sig_to_feats(x))
             assert torch.equal(got[2], codec.toks_to_sig(et))
+
+
+def test_graph_cache_is_bounded_and_a_failed_capture_falls_back(monkeypatch):
+    """Round-5 advisor finding: on variable-length data every call is a new (call, shape) key; each entry pins a private workspace and
+    static tensors, so the cache grew until out of memory, and an exception during capture failed the call.  Now the least recently used
+    graph is dropped beyond Codec.GRAPH_CACHE, results stay bit-identical throughout, and a capture that raises hands back the eager
+    result and leaves that shape eager."""
+    eager, graphed = _pair("mimi")
+    graphed.GRAPH_CACHE = 3
+    with torch.no_grad():
+        for i, t in enumerate([1920, 3840, 5760, 7680, 1920, 9600, 3840]):
+            sig = noise(300 + i, 1, t).cuda()
+            assert torch.equal(graphed.sig_to_toks(sig), eager.sig_to_toks(sig)), t
+            assert len(graphed._graphs) <= 3
+        sig = noise(400, 1, 11520).cuda()
+        real = torch.cuda.graph
+
+        def boom(*a, **k):
+            raise RuntimeError("capture refused (test)")
+
+        monkeypatch.setattr(torch.cuda, "graph", boom)
+        assert torch.equal(graphed.sig_to_toks(sig), eager.sig_to_toks(sig))      # the eager result, no exception
+        monkeypatch.setattr(torch.cuda, "graph", real)
+        n = len(graphed._graphs)
+        assert torch.equal(graphed.sig_to_toks(sig), eager.sig_to_toks(sig))      # that shape stays eager
+        assert len(graphed._graphs) == n and len(graphed._graph_failed) == 1

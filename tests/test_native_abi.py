@@ -52,3 +52,19 @@ def test_create_rejects_bad_config_without_gpu():
     assert L.ac_wavtok_create(C.byref(native.AcWavtokConfig()), C.byref(h)) == -1
     assert L.ac_set_precision(None, 0) == -1
     assert L.ac_last_error(None) == b"null handle"
+
+
+def test_product_library_carries_no_developer_switch():
+    """the product library neither reads the fault-injection / timing-mode environment words nor accepts their keys
+    (the refusal's message is in it); the developer library built beside it does.  The GPU side of this is
+    tests/test_fault_injection_gpu.py."""
+    import os
+
+    native = _built()
+    native.lib()
+    data = open(native.lib_path, "rb").read()
+    assert b"AC_RB6_DBG" not in data and b"AC_LSTM_DBG" not in data
+    assert b"developer-build switch" in data
+    dev = os.path.join(os.path.dirname(native.lib_path), "libaudiocodecs_amd_dev.so")
+    if os.path.exists(dev) and "AUDIOCODECS_AMD_LIB" not in os.environ:
+        assert b"AC_LSTM_DBG" in open(dev, "rb").read()
