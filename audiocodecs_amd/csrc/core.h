@@ -84,6 +84,9 @@ struct MimiPlan {
     size_t rope_cos = 0, rope_sin = 0;                 // [rope_T][head_dim]
     int rope_T = 0;
     int D = 0;                                         // SEANet width at the bottleneck
+    // rb_stream6m.h (round 6): the encoder stem as a [64][7 -> 32] operand image and the decoder head as a [k -> 16 taps][64] one (float
+    // offsets into the blob, their 2^-s), the stem's bound |x0| <= sb0 + sb1 amax(sig), the last block's |y - x| <= fb0 + fb1h bound(hidden)
+    struct StreamM { size_t stem_f = 0, stem_inv = 0, head_f = 0, head_inv = 0; float sb0 = 0.f, sb1 = 0.f, fb0 = 0.f, fb1h = 0.f; bool stem_ok = false, head_ok = false; } sm;
 };
 
 struct DacResUnitPlan {
@@ -578,6 +581,40 @@ struct Packer {
         for (size_t k = 0; k < km.size(); ++k) o[k] = km[(k & ~(size_t)31) + ((k & 4) ? 16 : 0) + 4 * ((k >> 3) & 3) + (k & 3)];
         return o;
     }
+    // rb_stream6m.h: Mimi's stem [64][7] as an MFMA operand image + its bound; the head's [k][64] taps as the rows of a [16][64] matrix + the
+    // bound of the last block's residual branch
+    void stream_mimi(const PackedGemm& stem, const ResBlockPlan& enc_rb, const ResBlockPlan& dec_rb, const PackedGemm& head, int head_k, MimiPlan::StreamM& sm) {
+        sm.stem_ok = sm.head_ok = false;
+        if (!use16()) return;
+        if (stem.N == 64 && stem.Ktot == 7 && stem.has_bias && enc_rb.C == 64 && enc_rb.w3p_off) {
+            std::vector<int> k7(32, -1);
+            for (int k = 0; k < 7; ++k) k7[k] = k;
+            sm.stem_f = frag16(stem.w_off, 64, 7, k7, &sm.stem_inv);
+            sm.sb0 = sm.sb1 = 0.f;
+            for (int n = 0; n < 64; ++n) {
+                double l1 = 0.0;
+                for (int k = 0; k < 7; ++k) l1 += std::fabs((double)blob[stem.w_off + (size_t)n * 7 + k]);
+                sm.sb1 = std::max(sm.sb1, (float)(l1 * 1.000001));
+                sm.sb0 = std::max(sm.sb0, std::fabs(blob[stem.b_off + n]));
+            }
+            sm.stem_ok = true;
+        }
+        if (head.N == 1 && head_k >= 1 && head_k <= 8 && head.Ktot == head_k * 64 && head.has_bias && dec_rb.C == 64 && dec_rb.w3p_off && dec_rb.fused.Ktot == 32) {
+            std::vector<int> kh(64);
+            for (int k = 0; k < 64; ++k) kh[k] = k;
+            const size_t pad = reserve(16 * 64);
+            for (int i = 0; i < 16 * 64; ++i) blob[pad + i] = i < head_k * 64 ? blob[head.w_off + i] : 0.f;
+            sm.head_f = frag16(pad, 16, 64, perm32(kh), &sm.head_inv);
+            sm.fb0 = sm.fb1h = 0.f;
+            for (int n = 0; n < 64; ++n) {
+                double lh = 0.0;
+                for (int k = 0; k < 32; ++k) lh += std::fabs((double)blob[dec_rb.fused.w_off + (size_t)n * 32 + k]);
+                sm.fb1h = std::max(sm.fb1h, (float)(lh * 1.000001));
+                sm.fb0 = std::max(sm.fb0, std::fabs(blob[dec_rb.fused.b_off + n]));
+            }
+            sm.head_ok = true;
+        }
+    }
     // enc_stream.h: the stem as a [32][7 -> 32] MFMA operand (tap j in column j), the strided conv [64][128] permuted
     void stream_enc(const PackedGemm& stem, const ResBlockPlan& rb, const PackedGemm& down, ac_handle::StreamImgs& si) {
         si.enc_ok = false;
@@ -937,6 +974,10 @@ int decoder_fwd(ac_handle* h, hipStream_t st, const long long* toks, int B, int 
 bool rb64_identity_head_fwd(ac_handle* h, hipStream_t st, const ResBlockPlan& rb, const Act2& x, const PackedGemm& head, int head_k, float* sig, int B, int* rc);
 int enc_stream_fwd(ac_handle* h, hipStream_t st, const float* sig, const float* rel_len, int B, int T, float* y, float* dbg_x0, float* dbg_y1, const unsigned* amax_sig, unsigned* amax_out);   // stream_path.hip
 int dec_stream_fwd(ac_handle* h, hipStream_t st, const Act& xe, int B, float* sig, float* dbg_u, float* dbg_v, const unsigned* amax_x);   // stream_path.hip
+// rb_stream6m.h (stream_path.hip): Mimi's 64-channel identity block with the stem (sig != null: x is computed from the samples) or the head
+// (head_y != null: one sample per row is stored instead of the block's output) folded in
+int launch_rb_stream6m(ac_handle* h, hipStream_t st, const ResBlockPlan& rb, const float* xr, const float* sig, int B, int L, Out out, float* head_y, int head_k,
+                       const unsigned* amax_in, unsigned* amax_out);
 int launch_rb_stream6(ac_handle* h, hipStream_t st, RbFused6Params& p, const ResBlockPlan& rb, bool sc, Out out, int B);   // stream_path.hip (p filled by launch_rb_fused6)
 int rb64_identity_fwd(ac_handle* h, hipStream_t st, const ResBlockPlan& rb, const Act2& x, Out out, int B, const unsigned** amax_out);   // rb_fused6<64, false> / rb_fused<64,64,2,false>
 int rb128_identity_fwd(ac_handle* h, hipStream_t st, const ResBlockPlan& rb, const Act2& x, Out out, int B, const unsigned** amax_out); // rb128_fused6<false>

@@ -306,22 +306,42 @@ int mimi_encoder_fwd(ac_handle* h, hipStream_t st, const float* sig, int B, int 
     Act xin{sig, (long long)T, 1, T, 1};
     Act2 x, y;
     int rc;
+    // round 6: the stem folded into the first residual block (rb_stream6m.h STEM): the 64-channel tensor at the sample rate is never written.
+    // (The capture hook wants the stem's output as a tensor: the separate kernels then.)
+    int first_block = 0;
+    const bool fold_stem = !dbg && h->dev.rb_stream && !h->gemm_fp32 && m.sm.stem_ok && F == 64 && c.kernel_size == 7 && c.num_ratios >= 1 &&
+                           c.residual_kernel_size == 3 && c.compress == 2 && (long long)T * 256 < 0x70000000LL;
+    if (fold_stem) {
+        const bool v4 = T % 4 == 0 && aligned16(sig);
+        const unsigned* am_sig = amax_of(h, st, sig, T, v4 ? 4 : 1, v4 ? T / 4 : T, v4 ? 4 : 1, B, nullptr);
+        if (!am_sig) return fail(h, AC_ESTATE, "out of amax slots (split16.h)");
+        unsigned* am_out = amax_new(h);
+        Out o{nullptr, ws.take()};                         // the down-sampler reads ELU(y) only
+        rc = launch_rb_stream6m(h, st, m.enc_rb[0], nullptr, sig, B, T, o, nullptr, 0, am_sig, am_out);
+        if (rc) return rc;
+        HIPCHK(h, hipGetLastError());
+        x.raw = Act{nullptr, (long long)T * 64, 64, T, 64, am_out, B};
+        x.elu = Act{o.elu, (long long)T * 64, 64, T, 64, am_out, B};
+        first_block = 1;
+    } else
     if (F % 4 == 0 && F <= 64 && c.kernel_size <= THIN_MAXK)
         rc = thin_stem(h, st, m.enc_stem, F, c.kernel_size, PAD_ZERO, sig, nullptr, B, T,
                        Out{ws.take(), mimi_rb_self_elu(h, c, F) ? nullptr : ws.take()}, &x);
     else
         rc = mimi_conv(h, st, m.enc_stem, xin, c.kernel_size, 1, PAD_ZERO, Out{ws.take(), ws.take()}, B, &x);
     if (rc) return rc;
-    capture(h, st, x.raw, B);
+    if (!first_block) capture(h, st, x.raw, B);
     for (int i = 0; i < c.num_ratios; ++i) {
         const int ratio = c.upsampling_ratios[c.num_ratios - 1 - i];
-        float* hb = ws.take();
-        rc = mimi_resblock(h, st, m.enc_rb[i], x, hb, Out{dbg ? ws.take() : nullptr, ws.take()}, B, &y);
-        if (rc) return rc;
-        ws.give(hb);
-        ws.give(x);
-        if (dbg) { capture(h, st, y.raw, B); ws.give(y.raw.p); y.raw.p = nullptr; }
-        x = y;
+        if (i >= first_block) {
+            float* hb = ws.take();
+            rc = mimi_resblock(h, st, m.enc_rb[i], x, hb, Out{dbg ? ws.take() : nullptr, ws.take()}, B, &y);
+            if (rc) return rc;
+            ws.give(hb);
+            ws.give(x);
+            if (dbg) { capture(h, st, y.raw, B); ws.give(y.raw.p); y.raw.p = nullptr; }
+            x = y;
+        }
         const bool last = i == c.num_ratios - 1;     // the last down-sampler feeds ELU -> final conv only
         const int cout = m.enc_down[i].N;
         Out o = last ? Out{dbg ? ws.take() : nullptr, ws.take()} : Out{ws.take(), mimi_rb_self_elu(h, c, cout) ? nullptr : ws.take()};
@@ -388,6 +408,14 @@ int mimi_decoder_fwd(ac_handle* h, hipStream_t st, const float* qfeats, int B, i
         if (i == c.num_ratios - 1 && m.dec_rb[i].C == 64 && c.residual_kernel_size == 3 && c.compress == 2 && c.num_filters == 64 && x.raw.ts == 64 &&
             x.raw.bs == (long long)x.raw.L * 64 && aligned16(x.raw.p)) {
             int rc2 = AC_OK;
+            if (!dbg && h->dev.rb_stream && h->dev.mimi_tail && !h->gemm_fp32 && m.sm.head_ok && (long long)x.raw.L * 256 < 0x70000000LL) {   // rb_stream6m.h HEAD
+                const unsigned* am = amax_of(h, st, x.raw.p, x.raw.bs, x.raw.ts, x.raw.L, x.raw.C, B, x.raw.amax_n == B ? x.raw.amax : nullptr);
+                if (!am) return fail(h, AC_ESTATE, "out of amax slots (split16.h)");
+                rc2 = launch_rb_stream6m(h, st, m.dec_rb[i], x.raw.p, nullptr, B, x.raw.L, Out{}, sig, c.last_kernel_size, am, nullptr);
+                if (!rc2) HIPCHK(h, hipGetLastError());
+                ws.give(x);
+                return rc2;
+            }
             if (rb64_identity_head_fwd(h, st, m.dec_rb[i], x, m.dec_head, c.last_kernel_size, sig, B, &rc2)) {
                 ws.give(x);
                 return rc2;
@@ -454,6 +482,7 @@ int mimi_finalize(ac_handle* h, Packer& pk) {
     }
     ok = ok && pk.conv(ConvSpec{P("decoder", i + 1, ".conv"), 0, ch, 1, c.last_kernel_size, 1}, m.dec_head);
     if (!ok) return pk.rc;
+    if (n >= 1 && c.residual_kernel_size == 3 && c.compress == 2) pk.stream_mimi(m.enc_stem, m.enc_rb[0], m.dec_rb[n - 1], m.dec_head, c.last_kernel_size, m.sm);
     {   // depthwise up-sampler [H][1][2s]
         const std::vector<float>* w = pk.get("upsample.conv.weight", (size_t)H * 2 * c.resample_stride);
         if (!w) return pk.rc;

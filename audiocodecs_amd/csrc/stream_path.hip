@@ -5,6 +5,7 @@
 #include "rb_stream6.h"
 #include "enc_stream.h"
 #include "dec_stream.h"
+#include "rb_stream6m.h"
 
 namespace acimpl {
 
@@ -43,6 +44,62 @@ int launch_rb_stream6(ac_handle* h, hipStream_t st, RbFused6Params& p, const Res
     return go(rb_stream6_kernel<false, true, false>, lds);
 }
 
+
+// ---- Mimi's 64-channel identity block with its neighbour folded in (rb_stream6m.h)
+int launch_rb_stream6m(ac_handle* h, hipStream_t st, const ResBlockPlan& rb, const float* xr, const float* sig, int B, int L, Out out, float* head_y, int head_k,
+                       const unsigned* amax_in, unsigned* amax_out) {
+    const MimiPlan::StreamM& sm = h->mimi.sm;
+    const bool stem = sig != nullptr, head = head_y != nullptr;
+    RbStreamMParams p{};
+    p.xr = xr;
+    p.sig = sig;
+    p.w0f = reinterpret_cast<const __bf16*>(h->blob + sm.stem_f);
+    p.w3f = reinterpret_cast<const __bf16*>(h->blob + rb.w3p_off);
+    p.wff = reinterpret_cast<const __bf16*>(h->blob + rb.wfp_off);
+    p.whf = reinterpret_cast<const __bf16*>(h->blob + sm.head_f);
+    p.b0 = h->blob + h->mimi.enc_stem.b_off;
+    p.winv0 = h->blob + sm.stem_inv;
+    p.b3 = h->blob + rb.c3.b_off;
+    p.winv3 = h->blob + rb.winv3_off;
+    p.bf = h->blob + rb.fused.b_off;
+    p.winvf = h->blob + rb.winvf_off;
+    p.bh = h->blob + h->mimi.dec_head.b_off;
+    p.winvh = h->blob + sm.head_inv;
+    p.y = out.raw;
+    p.y_elu = out.elu;
+    p.head_y = head_y;
+    p.head_k = head_k;
+    p.B = B;
+    p.L = L;
+    const int tiles = cdiv(L, 16);
+    const int want = std::max(1, 256 * 16 / std::max(1, B));
+    const int seg_tiles = std::max(head ? 8 : 1, cdiv(tiles, std::min(tiles, want)));     // (HEAD: a segment pays one warm-up tile)
+    p.seg_rows = seg_tiles * 16;
+    p.nseg = cdiv(tiles, seg_tiles);
+    p.amax_in = amax_in;
+    p.amax_out = amax_out;
+    p.sb0 = sm.sb0; p.sb1 = sm.sb1;
+    p.hb0 = rb.hb0; p.hb1 = rb.hb1;
+    p.fb0 = sm.fb0; p.fb1h = sm.fb1h;
+    const long long segs = (long long)B * p.nseg;
+    const int grid = (int)std::min<long long>(256, (segs + 15) / 16);
+    const double Ld = L;
+    ProfScope ps(h, st, stem ? "rb_stream6m_kernel<stem>" : head ? "rb_stream6m_kernel<head>" : "rb_stream6m_kernel<>",
+                 2.0 * B * Ld * (32.0 * 192 + 64.0 * 32 + (stem ? 64.0 * 7 : 0.0) + (head ? 64.0 * head_k : 0.0)),
+                 (double)B * Ld * 4.0 * ((stem ? 1 : 64) + (head ? 1 : 64 * ((out.raw ? 1 : 0) + (out.elu ? 1 : 0)))));
+    auto go = [&](auto kern) -> int {
+        if (int rc = ensure_lds(h, reinterpret_cast<const void*>(kern), RM_LDS)) return rc;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), RM_LDS, st, p);
+        return AC_OK;
+    };
+    if (head) return go(rb_stream6m_kernel<false, true, false, false>);
+    if (stem) {
+        if (out.raw && out.elu) return go(rb_stream6m_kernel<true, false, true, true>);
+        if (out.elu) return go(rb_stream6m_kernel<true, false, false, true>);
+        return go(rb_stream6m_kernel<true, false, true, false>);
+    }
+    return fail(h, AC_ESTATE, "rb_stream6m without a folded layer: use rb_stream6");
+}
 
 // ---- the encoder's thin-channel head (enc_stream.h): stem -> ResBlock(32) -> ELU -> Conv1d(32, 64, k4, s2); called by enc_front_fwd (core.hip),
 // which owns the shape checks, the amax slots and the output descriptors

@@ -112,23 +112,31 @@ def test_mimi_tail_with_the_final_conv_folded_in_is_bit_identical(B, frames):
 
     codec = _codec("mimi")
     sig = noise(9700 + frames, B, 1920 * frames + 13).cuda()
+    close = lambda a, r: float((a - r).abs().max()) <= 2e-5 * max(float(r.abs().max()), 1e-3)
     with torch.no_grad():
         toks = codec.sig_to_toks(sig)
-        debug_set(codec, "mimi_tail", 0)
-        # round 6: the stand-alone block runs rb_stream6.h by default (the same arithmetic with every MFMA's 32 products in the lanes' load
-        # order: fp32-faithful, not bit-equal); the folded kernel keeps rb_fused6's order, so the bit-identity is against rb_fused6 + head4
-        names = _kernels(codec, lambda: codec.toks_to_sig(toks))
-        assert "rb_fused6_head_kernel" not in names and "rb_stream6_kernel" in names, names
-        stream = codec.toks_to_sig(toks)
+        # the round-4 pair, bit-identical: rb_fused6<64, false> + head4_kernel against rb_fused6_head_kernel
         debug_set(codec, "rb_stream", 0)
+        debug_set(codec, "mimi_tail", 0)
         names = _kernels(codec, lambda: codec.toks_to_sig(toks))
-        assert "rb_fused6_kernel" in names and "rb_stream6_kernel" not in names and "head4_kernel" in names, names
+        assert "rb_fused6_kernel" in names and "head4_kernel" in names and not any(n.startswith("rb_stream6") for n in names), names
         ref = codec.toks_to_sig(toks)
-        debug_set(codec, "rb_stream", 1)
-        assert float((stream - ref).abs().max()) <= 2e-5 * max(float(ref.abs().max()), 1e-3), float((stream - ref).abs().max())
         debug_set(codec, "mimi_tail", 1)
         names = _kernels(codec, lambda: codec.toks_to_sig(toks))
         assert "rb_fused6_head_kernel" in names and "head4_kernel" not in names, names
         new = codec.toks_to_sig(toks)
-    assert new.shape == ref.shape
-    assert torch.equal(new, ref), float((new - ref).abs().max())
+        assert new.shape == ref.shape
+        assert torch.equal(new, ref), float((new - ref).abs().max())
+        # round 6: the stream kernels (the same arithmetic with every MFMA's 32 products in the lanes' load order, the head on the matrix
+        # pipe: fp32-faithful, not bit-equal) -- the block alone, and with the head folded in (rb_stream6m.h), tile seams every 16 samples
+        debug_set(codec, "rb_stream", 1)
+        debug_set(codec, "mimi_tail", 0)
+        names = _kernels(codec, lambda: codec.toks_to_sig(toks))
+        assert "rb_stream6_kernel" in names and "head4_kernel" in names, names
+        assert close(codec.toks_to_sig(toks), ref)
+        debug_set(codec, "mimi_tail", 1)
+        names = _kernels(codec, lambda: codec.toks_to_sig(toks))
+        assert "rb_stream6m_kernel" in names and "head4_kernel" not in names and "rb_fused6_head_kernel" not in names, names
+        fold = codec.toks_to_sig(toks)
+        assert close(fold, ref), float((fold - ref).abs().max())
+        assert torch.equal(fold, codec.toks_to_sig(toks))
