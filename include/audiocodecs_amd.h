@@ -323,10 +323,14 @@ int ac_profile_end(ac_handle* h, ac_kernel_stat* out, int cap);
  * ac_debug_captured returns the floats appended so far (may exceed cap_floats: nothing is written
  * past the capacity).  Disarm with ac_debug_capture(h, NULL, 0). */
 int ac_debug_capture(ac_handle* h, float* buf_dev, size_t cap_floats);
-/* Developer / test switches of a handle (A/B paths, fault injection, timing variants): "tap_epi_staged", "tap_dil", "tap_stagger",
- * "tap_pick", "tap8", "tap8_form", "rb6_dbg", "front_seg", "tail_seg", "front_ldspad", "lstm_dbg", "lstm_fuse_in", "rvq_exact", "prof_detail", "head_seq", "attn_exact", "dac_unit", "mimi_tail".  Their
- * initial values come from the environment variables of the same meaning (AC_TAP_EPI, AC_TAP_DIL, ...), read ONCE, at ac_finalize; no
- * compute entry point reads the environment.  Not part of the product interface. */
+/* Developer / test switches of a handle: A/B paths whose results are EQUIVALENT (bit-identical or fp32-faithful; named in the
+ * parity tests): "tap_epi_staged", "tap_dil", "tap_stagger", "tap_pick", "tap8", "tap8_form", "tap8_spread", "rb_stream",
+ * "chain_stream", "front_seg", "tail_seg", "front_ldspad", "lstm_fuse_in", "rvq_exact", "prof_detail", "head_seq", "attn_exact",
+ * "dac_unit", "mimi_tail".  Their initial values come from the environment variables of the same meaning (AC_TAP_EPI, AC_TAP_DIL,
+ * ...), read ONCE, at ac_finalize; no compute entry point reads the environment.
+ * "rb6_dbg" (timing modes with WRONG results) and "lstm_dbg" (fault injection, traces) exist in the DEVELOPER library only
+ * (libaudiocodecs_amd_dev.so, built beside the product by csrc/build.sh with -DAC_DEVELOPER): the product library returns AC_EINVAL for
+ * them, does not read AC_RB6_DBG / AC_LSTM_DBG, and its kernels ignore the words.  Not part of the product interface. */
 int ac_debug_set(ac_handle* h, const char* key, int value);
 size_t ac_debug_captured(const ac_handle* h);
 
