@@ -258,14 +258,18 @@ __global__ __launch_bounds__(64 * DS_WAVES) void dec_stream_kernel(const DecStre
             const f16x8 whh = *reinterpret_cast<const f16x8*>(wh_l);
             const f16x8 whl = *reinterpret_cast<const f16x8*>(wh_l + 1024);
             const float ihv = cs[DS_IH + li] * iv;              // this lane's tap column: 2^-s of its weight row x 2^-s of ELU(v)
+            f32x4 bfv[2], ifv[2];                               // (read once per chunk)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                bfv[c] = *reinterpret_cast<const f32x4*>(c_l + DS_BF + 16 * c);
+                ifv[c] = *reinterpret_cast<const f32x4*>(c_l + DS_IF + 16 * c) * ib;
+            }
 #pragma unroll
             for (int ph = 0; ph < 2; ++ph) {
                 f32x4 v[2];
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
-                    const f32x4 bfv = *reinterpret_cast<const f32x4*>(c_l + DS_BF + 16 * c);
-                    const f32x4 ifv = *reinterpret_cast<const f32x4*>(c_l + DS_IF + 16 * c) * ib;
-                    v[c] = es_fma4(acc[ph][c], ifv, bfv);
+                    v[c] = es_fma4(acc[ph][c], ifv[c], bfv[c]);
                     const int t = t0 + 2 * li + ph;
                     if (p.dbg_v && emit && t < T) *reinterpret_cast<f32x4*>(p.dbg_v + (ob + t) * 32 + 16 * c + 4 * kq) = v[c];
                 }

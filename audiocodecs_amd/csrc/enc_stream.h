@@ -152,6 +152,12 @@ __global__ __launch_bounds__(64 * ES_WAVES) void enc_stream_kernel(const EncStre
         // ---- stem on the matrix pipe: x0[a][c] = W0 tile c * window(rows 16 a ..)^T;  operand element e of lane (li, 0) = sample t - 6 + e
         f32x4 x0[2][2];
         Hl8 xr[2];
+        f32x4 b0v[2], i0v[2];                                   // (read once per chunk: inside the loop every row tile would re-read them)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            b0v[c] = *reinterpret_cast<const f32x4*>(c_l + ES_B0 + 16 * c);
+            i0v[c] = *reinterpret_cast<const f32x4*>(c_l + ES_I0 + 16 * c) * is;
+        }
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
             const float* wp = kq == 0 ? sg + 2 + 16 * a + li : sg + 48;
@@ -163,9 +169,7 @@ __global__ __launch_bounds__(64 * ES_WAVES) void enc_stream_kernel(const EncStre
                 const f16x8 wh = *reinterpret_cast<const f16x8*>(w0_l + (c * 2 + 0) * 1024);
                 const f16x8 wl = *reinterpret_cast<const f16x8*>(w0_l + (c * 2 + 1) * 1024);
                 const f32x4 acc = mma16(wh, wl, so.hi, so.lo, zero4);
-                const f32x4 b0v = *reinterpret_cast<const f32x4*>(c_l + ES_B0 + 16 * c);
-                const f32x4 i0v = *reinterpret_cast<const f32x4*>(c_l + ES_I0 + 16 * c) * is;
-                x0[a][c] = es_fma4(acc, i0v, b0v);
+                x0[a][c] = es_fma4(acc, i0v[c], b0v[c]);
                 const int t = t0 + 16 * a + li;
                 if (p.dbg_x0 && emit && t < p.T) *reinterpret_cast<f32x4*>(p.dbg_x0 + ((long long)b * p.T + t) * 32 + 16 * c + 4 * kq) = x0[a][c];
             }
@@ -229,14 +233,18 @@ __global__ __launch_bounds__(64 * ES_WAVES) void enc_stream_kernel(const EncStre
 #pragma unroll
                     for (int c = 0; c < 2; ++c) acc[a][c] = es_mfma(wh[c], ks ? xr[a].hi : hf[a].hi, acc[a][c]);
             }
+            f32x4 bfv[2], ifv[2];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                bfv[c] = *reinterpret_cast<const f32x4*>(c_l + ES_BF + 16 * c);
+                ifv[c] = *reinterpret_cast<const f32x4*>(c_l + ES_IF + 16 * c) * ib;
+            }
 #pragma unroll
             for (int a = 0; a < 2; ++a) {
                 f32x4 v[2];
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
-                    const f32x4 bfv = *reinterpret_cast<const f32x4*>(c_l + ES_BF + 16 * c);
-                    const f32x4 ifv = *reinterpret_cast<const f32x4*>(c_l + ES_IF + 16 * c) * ib;
-                    v[c] = es_fma4(acc[a][c], ifv, bfv);
+                    v[c] = es_fma4(acc[a][c], ifv[c], bfv[c]);
                     const int t = t0 + 16 * a + li;
                     if (p.dbg_y1 && emit && t < p.T) *reinterpret_cast<f32x4*>(p.dbg_y1 + ((long long)b * p.T + t) * 32 + 16 * c + 4 * kq) = v[c];
                 }
