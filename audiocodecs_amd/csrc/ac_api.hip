@@ -78,6 +78,7 @@ static void latch_dev_switches(ac_handle* h) {
 #endif
     h->dev.rb_stream = num("AC_RB_STREAM", 1);
     h->dev.chain_stream = num("AC_CHAIN_STREAM", 1);
+    h->dev.rb128_stream = num("AC_RB128_STREAM", 1);
     h->dev.front_seg = std::max(0, num("AC_FRONT_SEG", 0));
     h->dev.tail_seg = std::max(0, num("AC_TAIL_SEG", 0));
     h->dev.front_ldspad = std::max(0, num("AC_FRONT_LDSPAD", 0));
@@ -95,7 +96,7 @@ int ac_debug_set(ac_handle* h, const char* key, int value) {
     if (!h || !key) return AC_EINVAL;
     struct { const char* k; int* v; } tab[] = {
         {"tap_epi_staged", &h->dev.tap_epi_staged}, {"tap_dil", &h->dev.tap_dil}, {"tap_stagger", &h->dev.tap_stagger}, {"tap_pick", &h->dev.tap_pick}, {"tap8", &h->dev.tap8}, {"tap8_form", &h->dev.tap8_form}, {"tap8_spread", &h->dev.tap8_spread},
-        {"rb6_dbg", &h->dev.rb6_dbg}, {"rb_stream", &h->dev.rb_stream}, {"chain_stream", &h->dev.chain_stream}, {"front_seg", &h->dev.front_seg}, {"tail_seg", &h->dev.tail_seg}, {"front_ldspad", &h->dev.front_ldspad},
+        {"rb6_dbg", &h->dev.rb6_dbg}, {"rb_stream", &h->dev.rb_stream}, {"chain_stream", &h->dev.chain_stream}, {"rb128_stream", &h->dev.rb128_stream}, {"front_seg", &h->dev.front_seg}, {"tail_seg", &h->dev.tail_seg}, {"front_ldspad", &h->dev.front_ldspad},
         {"lstm_dbg", &h->dev.lstm_dbg}, {"lstm_fuse_in", &h->dev.lstm_fuse_in}, {"rvq_exact", &h->dev.rvq_exact}, {"prof_detail", &h->dev.prof_detail}, {"head_seq", &h->dev.head_seq}, {"attn_exact", &h->dev.attn_exact}, {"dac_unit", &h->dev.dac_unit}, {"mimi_tail", &h->dev.mimi_tail},
     };
 #ifndef AC_DEVELOPER

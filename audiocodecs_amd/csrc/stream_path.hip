@@ -6,6 +6,7 @@
 #include "enc_stream.h"
 #include "dec_stream.h"
 #include "rb_stream6m.h"
+#include "rb_stream128m.h"
 
 namespace acimpl {
 
@@ -99,6 +100,40 @@ int launch_rb_stream6m(ac_handle* h, hipStream_t st, const ResBlockPlan& rb, con
         return go(rb_stream6m_kernel<true, false, true, false>);
     }
     return fail(h, AC_ESTATE, "rb_stream6m without a folded layer: use rb_stream6");
+}
+
+// ---- Mimi's 128-channel identity block (rb_stream128m.h)
+int launch_rb_stream128m(ac_handle* h, hipStream_t st, RbFused6Params& q, const ResBlockPlan& rb, Out out, int B) {
+    constexpr int WAVES = 16;
+    RbStream128Params p{};
+    p.xr = q.xr;
+    p.w3f = reinterpret_cast<const __bf16*>(h->blob + rb.w3p_off);
+    p.wff = reinterpret_cast<const __bf16*>(h->blob + rb.wfp_off);
+    p.b3 = q.b3; p.winv3 = q.winv3; p.bf = q.bf; p.winvf = q.winvf;
+    p.y = out.raw;
+    p.y_elu = out.elu;
+    p.B = B;
+    p.L = q.L;
+    const int tiles = cdiv(p.L, 16);
+    const int want = std::max(1, 256 * WAVES / std::max(1, B));
+    const int seg_tiles = cdiv(tiles, std::min(tiles, want));
+    p.seg_rows = seg_tiles * 16;
+    p.nseg = cdiv(tiles, seg_tiles);
+    p.amax_in = q.amax_in;
+    p.amax_out = q.amax_out;
+    p.hb0 = q.hb0; p.hb1 = q.hb1;
+    const long long segs = (long long)B * p.nseg;
+    const int grid = (int)std::min<long long>(256, (segs + WAVES - 1) / WAVES);
+    const double L = p.L;
+    ProfScope ps(h, st, "rb_stream128m_kernel", 2.0 * B * L * (64.0 * 384 + 128.0 * 64), (double)B * L * 128 * 4.0 * (1 + (out.raw ? 1 : 0) + (out.elu ? 1 : 0)));
+    auto go = [&](auto kern) -> int {
+        if (int rc = ensure_lds(h, reinterpret_cast<const void*>(kern), r128_lds<WAVES>())) return rc;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WAVES), r128_lds<WAVES>(), st, p);
+        return AC_OK;
+    };
+    if (out.raw && out.elu) return go(rb_stream128m_kernel<WAVES, true, true>);
+    if (out.elu) return go(rb_stream128m_kernel<WAVES, false, true>);
+    return go(rb_stream128m_kernel<WAVES, true, false>);
 }
 
 // ---- the encoder's thin-channel head (enc_stream.h): stem -> ResBlock(32) -> ELU -> Conv1d(32, 64, k4, s2); called by enc_front_fwd (core.hip),

@@ -180,7 +180,7 @@ def parity_gate(codec_name, codec):
 
 _SHAPE_SUFFIX = re.compile(r"\s+B\d+ M\d+ N\d+ K\d+.*$")
 SPLIT_FAMILIES = ("tap_gemm6_kernel", "tap_gemm8_kernel", "rb_fused6_kernel", "rb128_fused6_kernel", "thin_conv6_kernel", "lstm_persist16_kernel",
-                  "enc_front_kernel", "dec_tail_kernel", "rb_stream6_kernel", "rb_stream6m_kernel", "enc_stream_kernel", "dec_stream_kernel", "rvq_encode16_kernel", "attention16_kernel", "dac_unit6_kernel", "rb_fused6_head_kernel")
+                  "enc_front_kernel", "dec_tail_kernel", "rb_stream6_kernel", "rb_stream6m_kernel", "rb_stream128m_kernel", "enc_stream_kernel", "dec_stream_kernel", "rvq_encode16_kernel", "attention16_kernel", "dac_unit6_kernel", "rb_fused6_head_kernel")
 
 
 def parse_kernel(name):

@@ -325,7 +325,7 @@ int ac_profile_end(ac_handle* h, ac_kernel_stat* out, int cap);
 int ac_debug_capture(ac_handle* h, float* buf_dev, size_t cap_floats);
 /* Developer / test switches of a handle: A/B paths whose results are EQUIVALENT (bit-identical or fp32-faithful; named in the
  * parity tests): "tap_epi_staged", "tap_dil", "tap_stagger", "tap_pick", "tap8", "tap8_form", "tap8_spread", "rb_stream",
- * "chain_stream", "front_seg", "tail_seg", "front_ldspad", "lstm_fuse_in", "rvq_exact", "prof_detail", "head_seq", "attn_exact",
+ * "rb128_stream", "chain_stream", "front_seg", "tail_seg", "front_ldspad", "lstm_fuse_in", "rvq_exact", "prof_detail", "head_seq", "attn_exact",
  * "dac_unit", "mimi_tail".  Their initial values come from the environment variables of the same meaning (AC_TAP_EPI, AC_TAP_DIL,
  * ...), read ONCE, at ac_finalize; no compute entry point reads the environment.
  * "rb6_dbg" (timing modes with WRONG results) and "lstm_dbg" (fault injection, traces) exist in the DEVELOPER library only

@@ -3,6 +3,7 @@ covered where their round-3 forms were (tests/test_fused_chains_gpu.py, the tap 
   * rb_stream6 against rb_fused6<64> on the EnCodec path (ac_debug_set "rb_stream"): two fp32-faithful evaluations of one function;
   * Mimi's first encoder block with the stem folded in (rb_stream6m.h STEM) against stem_kernel + the block, and its last decoder block with
     the head folded in (HEAD: also tests/test_round4_kernels_gpu.py) at lengths around the 16-row tile and the stream-segment seams;
+  * Mimi's 128-channel identity blocks without a slab (rb_stream128m.h: the k3 conv's row offsets by DPP row shifts + a 1 KB halo);
   * a stream's result must not depend on its batch neighbours (segments are cut by batch size)."""
 import pytest
 import torch
@@ -33,6 +34,7 @@ def test_mimi_stem_and_head_folds_match_the_separate_kernels(B, T):
     with torch.no_grad():
         names = _kernels(codec, lambda: codec.toks_to_sig(codec.sig_to_toks(sig)))
         assert "rb_stream6m_kernel" in names and "stem_kernel" not in names and "rb_fused6_head_kernel" not in names, names
+        assert "rb_stream128m_kernel" in names and "rb128_fused6_kernel" not in names, names      # the slab-less 128-channel block (rb_stream128m.h)
         feats, toks = codec.sig_to_feats(sig), codec.sig_to_toks(sig)
         wav = codec.toks_to_sig(toks)
         assert torch.equal(codec.sig_to_toks(sig), toks) and torch.equal(codec.toks_to_sig(toks), wav)      # reruns are bit-equal
