@@ -493,7 +493,7 @@ struct Packer {
         for (int k = 0; sc && k < C; ++k) kf.push_back(hid + k);
         rb.w3f_off = frag16(rb.c3.w_off, hid, rb.c3.Ktot, k3, &rb.winv3_off);
         rb.wff_off = frag16(rb.fused.w_off, C, rb.fused.Ktot, kf, &rb.winvf_off);
-        if ((C == 64 || C == 32 || (C == 128 && !sc)) && use16()) {   // rb_stream6.h / enc_stream.h / dec_stream.h / rb_stream128m.h (identity shortcut): column 8 kq + e of a k-step <-> channel 4 kq + e (e < 4), 16 + 4 kq + e - 4 (e >= 4) of its 32
+        if ((C == 64 || C == 32 || C == 128) && use16()) {   // rb_stream6.h / enc_stream.h / dec_stream.h / rb_stream128m.h (identity shortcut): column 8 kq + e of a k-step <-> channel 4 kq + e (e < 4), 16 + 4 kq + e - 4 (e >= 4) of its 32
             std::vector<int> k3p(k3.size()), kfp(kf.size());
             for (size_t k = 0; k < k3.size(); ++k) k3p[k] = k3[(k & ~(size_t)31) + ((k & 4) ? 16 : 0) + 4 * ((k >> 3) & 3) + (k & 3)];
             for (size_t k = 0; k < kf.size(); ++k) kfp[k] = kf[(k & ~(size_t)31) + ((k & 4) ? 16 : 0) + 4 * ((k >> 3) & 3) + (k & 3)];
@@ -979,8 +979,9 @@ int dec_stream_fwd(ac_handle* h, hipStream_t st, const Act& xe, int B, float* si
 // (head_y != null: one sample per row is stored instead of the block's output) folded in
 int launch_rb_stream6m(ac_handle* h, hipStream_t st, const ResBlockPlan& rb, const float* xr, const float* sig, int B, int L, Out out, float* head_y, int head_k,
                        const unsigned* amax_in, unsigned* amax_out);
-// rb_stream128m.h (stream_path.hip): Mimi's 128-channel identity block; `p` arrives filled by launch_rb128_fused6 (core.hip)
-int launch_rb_stream128m(ac_handle* h, hipStream_t st, RbFused6Params& p, const ResBlockPlan& rb, Out out, int B);
+// rb_stream128m.h (stream_path.hip): the 128-channel block without a slab (Mimi's identity form, EnCodec's 1x1-shortcut form); `p` arrives
+// filled by launch_rb128_fused6 (core.hip)
+int launch_rb_stream128m(ac_handle* h, hipStream_t st, RbFused6Params& p, const ResBlockPlan& rb, bool sc, Out out, int B);
 int launch_rb_stream6(ac_handle* h, hipStream_t st, RbFused6Params& p, const ResBlockPlan& rb, bool sc, Out out, int B);   // stream_path.hip (p filled by launch_rb_fused6)
 int rb64_identity_fwd(ac_handle* h, hipStream_t st, const ResBlockPlan& rb, const Act2& x, Out out, int B, const unsigned** amax_out);   // rb_fused6<64, false> / rb_fused<64,64,2,false>
 int rb128_identity_fwd(ac_handle* h, hipStream_t st, const ResBlockPlan& rb, const Act2& x, Out out, int B, const unsigned** amax_out); // rb128_fused6<false>

@@ -685,8 +685,8 @@ int launch_rb128_fused6(ac_handle* h, hipStream_t st, const ResBlockPlan& rb, co
     p.pad = pad;
     if (!rb_split16(h, st, rb, x, B, p, amax_out)) return fail(h, AC_ESTATE, "fused residual block without split16 images");
     if (!p.amax_in) return fail(h, AC_ESTATE, "out of amax slots (split16.h)");
-    if (!SC && h->dev.rb_stream && h->dev.rb128_stream && p.lpad == 2 && pad == PAD_ZERO && rb.w3p_off && (long long)x.raw.L * 512 < 0x70000000LL)
-        return launch_rb_stream128m(h, st, p, rb, out, B);      // rb_stream128m.h (stream_path.hip): sixteen waves per CU, no slab
+    if (h->dev.rb_stream && h->dev.rb128_stream && p.lpad == 2 && pad == (SC ? PAD_REFLECT : PAD_ZERO) && rb.w3p_off && (long long)x.raw.L * 512 < 0x70000000LL)
+        return launch_rb_stream128m(h, st, p, rb, SC, out, B);  // rb_stream128m.h (stream_path.hip): twelve / sixteen waves per CU, no slab
     if (int rc = ensure_lds(h, reinterpret_cast<const void*>(rb128_fused6_kernel<SC, 2>), Cfg::lds_bytes)) return rc;
     const long long total = (long long)B * p.ntiles;
     const int grid = (int)std::min<long long>(total, 256);   // persistent, one workgroup per CU

@@ -4,7 +4,10 @@
 // per-wave copy of ELU(x) (9 KB at 128 channels), so the k3 conv's row offsets are taken in REGISTERS: a tap that reads row li - s is the
 // lane's own operand fragment moved s lanes up inside its 16-lane row (v_mov_b32_dpp row_shr:s), and the s lanes that fall off the row's
 // start take the previous tile's last rows from a 1 KB halo area per wave (read into the destination first: row_shr leaves the lanes
-// without a source untouched).  The 1x1-shortcut block of EnCodec (another 64 KB of weights) does not fit this way either; rb128_fused6.
+// without a source untouched).
+// SC (EnCodec's block: a 1x1 shortcut conv instead of the identity, another 64 KB of weight planes): those do not fit LDS either way; the
+// shortcut's fragments are read from the packed image in L2 per tile (32 KB... x 2 planes = 64 KB per 16 rows and wave through the CU's L1
+// path, under the MFMAs of sixteen waves), its operand is the raw rows split in registers (rb_stream6.h); reflect padding at the clip start.
 // Arithmetic, scales and accumulation order as rb_stream6.h / rb128_fused6 (k-steps in order, lo hi / hi lo / hi hi); zero padding (Mimi).
 #pragma once
 #include "enc_stream.h"
@@ -14,7 +17,7 @@ namespace ac {
 struct RbStream128Params {
     const float* xr;         // [B][L][128] raw input
     const __bf16* w3f;       // k3 conv   [4 n-tiles][12 k-steps][2 planes][64][8]   (permuted columns: core.h perm32)
-    const __bf16* wff;       // 1x1 conv  [8][2][2][64][8]
+    const __bf16* wff;       // 1x1 conv  [8][2][2][64][8];  SC: [1x1 | shortcut] [8][6][2][64][8] (k-steps 0, 1 hidden, 2..5 the raw rows)
     const float *b3, *winv3; // [64]
     const float *bf, *winvf; // [128]
     float* y;                // optional raw output [B][L][128]
@@ -24,6 +27,7 @@ struct RbStream128Params {
     const unsigned* amax_in;
     unsigned* amax_out;
     float hb0, hb1;          // |hidden| <= hb0 + hb1 amax(x)
+    int pad, Lp;             // SC: PAD_REFLECT and its base length (rb_fused6.h); the identity form pads with zeros
 };
 
 constexpr int R128_WA = 0, R128_WB = 98304, R128_CONST = R128_WB + 32768;               // byte offsets
@@ -32,8 +36,10 @@ constexpr int R128_HALO = 2 * 4 * 2 * 4 * 16;                                   
 constexpr int R128_SHARED_BYTES = R128_CONST + R128_CONST_FLOATS * 4;
 template <int WAVES> constexpr size_t r128_lds() { return (size_t)R128_SHARED_BYTES + (size_t)WAVES * R128_HALO; }
 
-template <int WAVES, bool YR, bool YE>
+template <int WAVES, bool SC, bool YR, bool YE>
 __global__ __launch_bounds__(64 * WAVES) void rb_stream128m_kernel(const RbStream128Params p) {
+    constexpr int KSB = SC ? 6 : 2;                              // k-steps of the second image
+    constexpr int GRP = 4;                                        // output tiles finished together
     extern __shared__ __attribute__((aligned(16))) unsigned char r128_smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -41,7 +47,8 @@ __global__ __launch_bounds__(64 * WAVES) void rb_stream128m_kernel(const RbStrea
     {
         u32x4_t* d = reinterpret_cast<u32x4_t*>(r128_smem);
         for (int i = tid; i < 98304 / 16; i += 64 * WAVES) d[R128_WA / 16 + i] = reinterpret_cast<const u32x4_t*>(p.w3f)[i];
-        for (int i = tid; i < 32768 / 16; i += 64 * WAVES) d[R128_WB / 16 + i] = reinterpret_cast<const u32x4_t*>(p.wff)[i];
+        // the hidden k-steps of the second image: tile c's k-steps 0, 1 (4 KB) out of its KSB
+        for (int i = tid; i < 32768 / 16; i += 64 * WAVES) d[R128_WB / 16 + i] = reinterpret_cast<const u32x4_t*>(p.wff)[(i >> 8) * (KSB * 128) + (i & 255)];
         float* cs = reinterpret_cast<float*>(r128_smem + R128_CONST);
         for (int e = tid; e < R128_CONST_FLOATS; e += 64 * WAVES)
             cs[e] = e < R128_I3 ? p.b3[e] : e < R128_BF ? p.winv3[e - R128_I3] : e < R128_IF ? p.bf[e - R128_BF] : p.winvf[e - R128_IF];
@@ -50,6 +57,9 @@ __global__ __launch_bounds__(64 * WAVES) void rb_stream128m_kernel(const RbStrea
 
     const unsigned char* wa_l = r128_smem + R128_WA + lane * 16;
     const unsigned char* wb_l = r128_smem + R128_WB + lane * 16;
+    // SC: the shortcut's fragments come from L2 through a buffer descriptor (lane offset in a VGPR, fragment offset in an SGPR: with flat
+    // 64-bit addresses hipcc kept one address pair per fragment, 128 registers, and spilled them)
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)p.wff, 0, SC ? 8 * 6 * 2 * 1024 : 0, 0x00020000);
     const float* c_l = reinterpret_cast<const float*>(r128_smem + R128_CONST) + 4 * kq;
     unsigned char* halo = r128_smem + R128_SHARED_BYTES + wave * R128_HALO;
     auto hunit = [&](int pl, int kc, int row) { return halo + (((pl * 4 + kc) * 2 + row) * 4 + kq) * 16; };
@@ -103,7 +113,17 @@ __global__ __launch_bounds__(64 * WAVES) void rb_stream128m_kernel(const RbStrea
         f32x4 rx[4][2];
         {   // ---- the segment's first tile, and the two rows in front of it into the halo area (zeros left of the clip)
             f32x4 rh[4][2];
-            request(t_beg - 16, rh);                             // rows t_beg - 16 .. t_beg - 1: lanes 14, 15 are the halo
+            if constexpr (SC) {                                  // rows t_beg - 16 .. t_beg - 1: lanes 14, 15 are the halo
+                int j = t_beg - 16 + li;
+                if (p.pad == PAD_REFLECT) j = j < 0 ? -j : (j >= p.Lp ? 2 * (p.Lp - 1) - j : j);     // ([HF]:157-176, rb_fused6.h)
+                const int ho = li >= 14 && j >= 0 && j < p.L ? j * 512 + kq * 16 : 0x7fff0000;
+#pragma unroll
+                for (int kc = 0; kc < 4; ++kc)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) rh[kc][h] = bufload16(rs, ho + kc * 128 + h * 64, 0);
+            } else {
+                request(t_beg - 16, rh);
+            }
             request(t_beg, rx);
             Hl8 he[4];
 #pragma unroll
@@ -116,6 +136,11 @@ __global__ __launch_bounds__(64 * WAVES) void rb_stream128m_kernel(const RbStrea
             Hl8 xe[4];
 #pragma unroll
             for (int kc = 0; kc < 4; ++kc) xe[kc] = split16_regs8(elu4p(rx[kc][0]), elu4p(rx[kc][1]), cs.sx);
+            Hl8 xr[4];                                             // SC: the raw rows as the shortcut conv's operand (the fp32 registers are free then)
+            if (SC) {
+#pragma unroll
+                for (int kc = 0; kc < 4; ++kc) xr[kc] = split16_regs8(rx[kc][0], rx[kc][1], cs.sb);
+            }
             // ---- stage A: hidden = ELU(conv_k3(xe) + b3); M = 64 hidden channels (4 tiles), K = 3 taps x 128
             f32x4 accA[4] = {zero4, zero4, zero4, zero4};
 #pragma unroll
@@ -133,10 +158,13 @@ __global__ __launch_bounds__(64 * WAVES) void rb_stream128m_kernel(const RbStrea
                 }
             }
             save_halo(xe);                                         // (behind stage A's halo reads: the wave's LDS operations stay in order)
-            // the next tile's rows travel under stage B and the output (the planes' registers are free now)
+            // the next tile's rows travel under stage B and the output (the planes' registers are free now).  SC: requested BEHIND the
+            // shortcut's fragment loads -- the memory counter retires in order, and a fragment must not wait for an HBM round trip
             f32x4 rn[4][2];
-            request(t + 16 < t_end ? t + 16 : 0x3fffff00, rn);
-            __builtin_amdgcn_sched_barrier(0);
+            if (!SC) {
+                request(t + 16 < t_end ? t + 16 : 0x3fffff00, rn);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             Hl8 hf[2];
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
@@ -153,12 +181,24 @@ __global__ __launch_bounds__(64 * WAVES) void rb_stream128m_kernel(const RbStrea
             // ---- stage B + output: y = x + W1 hidden + bf, tile c = channels 16 c + 4 kq .. = the rows' load (c >> 1, c & 1)
             const int row = t + li;
             const int orow = row < p.L ? row * 512 + kq * 16 : 0x7fff0000;
+            // SC: the shortcut's fragments of output tile c (8 KB from L2) sit in ONE register set, requested while tile c - 1's values are
+            // finished and stored (a second set, requested a tile earlier, measured SLOWER: 1.62 against 1.55 ms per step -- the fragments'
+            // latency is not what the waves wait for); sched_barriers pin the requests where they stand
+            f16x8 wsh[4], wsl[4];
+            auto request_ws = [&](int c) {
 #pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                f32x4 acc[4];
+                for (int kc = 0; kc < 4; ++kc) {
+                    wsh[kc] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rsw, lane * 16, ((c * 6 + 2 + kc) * 2 + 0) * 1024, 0));
+                    wsl[kc] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rsw, lane * 16, ((c * 6 + 2 + kc) * 2 + 1) * 1024, 0));
+                }
+            };
+            if (SC) { request_ws(0); __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int c = 4 * half + q;
+            for (int half = 0; half < 8 / GRP; ++half) {
+                f32x4 acc[GRP];
+#pragma unroll
+                for (int q = 0; q < GRP; ++q) {
+                    const int c = GRP * half + q;
                     f32x4 a = zero4;
 #pragma unroll
                     for (int ks = 0; ks < 2; ++ks) {
@@ -166,17 +206,32 @@ __global__ __launch_bounds__(64 * WAVES) void rb_stream128m_kernel(const RbStrea
                         const f16x8 wl = *reinterpret_cast<const f16x8*>(wb_l + ((c * 2 + ks) * 2 + 1) * 1024);
                         a = mma16(wh, wl, hf[ks].hi, hf[ks].lo, a);
                     }
+                    if (SC) {
+#pragma unroll
+                        for (int kc = 0; kc < 4; ++kc) a = mma16(wsh[kc], wsl[kc], xr[kc].hi, xr[kc].lo, a);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (c < 7) request_ws(c + 1);
+                        else request(t + 16 < t_end ? t + 16 : 0x3fffff00, rn);   // every fragment of the tile is requested: now the next tile's rows
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                     const f32x4 bfv = *reinterpret_cast<const f32x4*>(c_l + R128_BF + 16 * c);
                     const f32x4 ifv = *reinterpret_cast<const f32x4*>(c_l + R128_IF + 16 * c) * cs.ib;
                     const f32x4 v = es_fma4(a, ifv, bfv);
-                    const f32x4 xv = rx[c >> 1][c & 1];
-                    acc[q] = f32x4{__fadd_rn(xv.x, v.x), __fadd_rn(xv.y, v.y), __fadd_rn(xv.z, v.z), __fadd_rn(xv.w, v.w)};
+                    if (SC) acc[q] = v;
+                    else {
+                        const f32x4 xv = rx[c >> 1][c & 1];
+                        acc[q] = f32x4{__fadd_rn(xv.x, v.x), __fadd_rn(xv.y, v.y), __fadd_rn(xv.z, v.z), __fadd_rn(xv.w, v.w)};
+                    }
                 }
-                const unsigned tm = amax16(acc);
-                omax = row < p.L && tm > omax ? tm : omax;
+                {
+                    unsigned tm = 0;
+                    if constexpr (GRP == 4) tm = amax16(acc);
+                    else { const f32x4 two[4] = {acc[0], acc[1], acc[0], acc[1]}; tm = amax16(two); }
+                    omax = row < p.L && tm > omax ? tm : omax;
+                }
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int c = 4 * half + q;
+                for (int q = 0; q < GRP; ++q) {
+                    const int c = GRP * half + q;
                     if (YR) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, acc[q]), ry, orow + c * 64, 0, 0);
                     if (YE) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, elu4p(acc[q])), re, orow + c * 64, 0, 0);
                 }

@@ -102,9 +102,30 @@ int launch_rb_stream6m(ac_handle* h, hipStream_t st, const ResBlockPlan& rb, con
     return fail(h, AC_ESTATE, "rb_stream6m without a folded layer: use rb_stream6");
 }
 
-// ---- Mimi's 128-channel identity block (rb_stream128m.h)
-int launch_rb_stream128m(ac_handle* h, hipStream_t st, RbFused6Params& q, const ResBlockPlan& rb, Out out, int B) {
-    constexpr int WAVES = 16;
+// ---- the 128-channel residual block without a slab (rb_stream128m.h): Mimi's identity form at sixteen waves per CU, EnCodec's 1x1-shortcut
+// form (its shortcut weights read from L2 per tile) at twelve
+template <int WAVES, bool SC>
+static int rb_stream128m_go(ac_handle* h, hipStream_t st, RbStream128Params& p, Out out, int B) {
+    const int tiles = cdiv(p.L, 16);
+    const int want = std::max(1, 256 * WAVES / std::max(1, B));
+    const int seg_tiles = cdiv(tiles, std::min(tiles, want));
+    p.seg_rows = seg_tiles * 16;
+    p.nseg = cdiv(tiles, seg_tiles);
+    const long long segs = (long long)B * p.nseg;
+    const int grid = (int)std::min<long long>(256, (segs + WAVES - 1) / WAVES);
+    const double L = p.L;
+    ProfScope ps(h, st, SC ? "rb_stream128m_kernel<true>" : "rb_stream128m_kernel<false>", 2.0 * B * L * (64.0 * 384 + 128.0 * (64 + (SC ? 128 : 0))),
+                 (double)B * L * 128 * 4.0 * (1 + (out.raw ? 1 : 0) + (out.elu ? 1 : 0)));
+    auto go = [&](auto kern) -> int {
+        if (int rc = ensure_lds(h, reinterpret_cast<const void*>(kern), r128_lds<WAVES>())) return rc;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WAVES), r128_lds<WAVES>(), st, p);
+        return AC_OK;
+    };
+    if (out.raw && out.elu) return go(rb_stream128m_kernel<WAVES, SC, true, true>);
+    if (out.elu) return go(rb_stream128m_kernel<WAVES, SC, false, true>);
+    return go(rb_stream128m_kernel<WAVES, SC, true, false>);
+}
+int launch_rb_stream128m(ac_handle* h, hipStream_t st, RbFused6Params& q, const ResBlockPlan& rb, bool sc, Out out, int B) {
     RbStream128Params p{};
     p.xr = q.xr;
     p.w3f = reinterpret_cast<const __bf16*>(h->blob + rb.w3p_off);
@@ -114,26 +135,12 @@ int launch_rb_stream128m(ac_handle* h, hipStream_t st, RbFused6Params& q, const 
     p.y_elu = out.elu;
     p.B = B;
     p.L = q.L;
-    const int tiles = cdiv(p.L, 16);
-    const int want = std::max(1, 256 * WAVES / std::max(1, B));
-    const int seg_tiles = cdiv(tiles, std::min(tiles, want));
-    p.seg_rows = seg_tiles * 16;
-    p.nseg = cdiv(tiles, seg_tiles);
     p.amax_in = q.amax_in;
     p.amax_out = q.amax_out;
     p.hb0 = q.hb0; p.hb1 = q.hb1;
-    const long long segs = (long long)B * p.nseg;
-    const int grid = (int)std::min<long long>(256, (segs + WAVES - 1) / WAVES);
-    const double L = p.L;
-    ProfScope ps(h, st, "rb_stream128m_kernel", 2.0 * B * L * (64.0 * 384 + 128.0 * 64), (double)B * L * 128 * 4.0 * (1 + (out.raw ? 1 : 0) + (out.elu ? 1 : 0)));
-    auto go = [&](auto kern) -> int {
-        if (int rc = ensure_lds(h, reinterpret_cast<const void*>(kern), r128_lds<WAVES>())) return rc;
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WAVES), r128_lds<WAVES>(), st, p);
-        return AC_OK;
-    };
-    if (out.raw && out.elu) return go(rb_stream128m_kernel<WAVES, true, true>);
-    if (out.elu) return go(rb_stream128m_kernel<WAVES, false, true>);
-    return go(rb_stream128m_kernel<WAVES, true, false>);
+    p.pad = q.pad; p.Lp = q.Lp;
+    if (sc) return rb_stream128m_go<12, true>(h, st, p, out, B);     // (the two fragment sets of the shortcut do not fit 128 registers)
+    return rb_stream128m_go<16, false>(h, st, p, out, B);
 }
 
 // ---- the encoder's thin-channel head (enc_stream.h): stem -> ResBlock(32) -> ELU -> Conv1d(32, 64, k4, s2); called by enc_front_fwd (core.hip),

@@ -66,7 +66,7 @@ def test_every_split16_kernel_name_maps_to_three_products():
              "tap_gemm6_kernel<1, 4, 4, 2, 2>" + shape, "void ac::tap_gemm6_kernel<1, 4, 4, 2, 2, 7>(ac::TapGemmParams, __bf16 const*)",
              "tap_gemm6_kernel<1, 8, 4, 1, 2, 56>", "tap_gemm8_kernel<2, 4, 4, 2, 2>", "rb_fused6_kernel<64, true, 2>", "rb_fused6_kernel<64, false, 2>", "rb128_fused6_kernel<true, 2>",
              "thin_conv6_kernel<2>", "lstm_persist16_kernel<true>", "lstm_persist16_kernel<false>", "enc_front_kernel", "dec_tail_kernel", "rvq_encode16_kernel", "attention16_kernel", "dac_unit6_kernel<3>", "dac_unit6_kernel<3, dil>", "rb_fused6_head_kernel",
-             "rb_stream6_kernel<true>", "rb_stream6_kernel<false>", "rb_stream6m_kernel<stem>", "rb_stream6m_kernel<head>", "rb_stream128m_kernel", "enc_stream_kernel", "dec_stream_kernel"]
+             "rb_stream6_kernel<true>", "rb_stream6_kernel<false>", "rb_stream6m_kernel<stem>", "rb_stream6m_kernel<head>", "rb_stream128m_kernel<true>", "rb_stream128m_kernel<false>", "enc_stream_kernel", "dec_stream_kernel"]
     for nm in three:
         assert bench.mfma16_terms(nm) == 3, nm
     for nm in ("tap_gemm4_kernel<2, 2, 4, 4>" + shape, "tap_gemm_kernel<2, 2, 4, 4, true>", "rb_fused_kernel<64, 64, 2>", "lstm_persist_kernel", "lstm_step_kernel",

@@ -63,11 +63,12 @@ def test_rb_stream6_matches_rb_fused6_on_the_encodec_path(checkpoints, T):
     with torch.no_grad():
         names = _kernels(codec, lambda: codec.toks_to_sig(codec.sig_to_toks(sig)))
         assert "rb_stream6_kernel" in names and "rb_fused6_kernel" not in names, names
+        assert "rb_stream128m_kernel" in names and "rb128_fused6_kernel" not in names, names      # the 128-channel block, 1x1-shortcut form
         f1, t1 = codec.sig_to_feats(sig), codec.sig_to_toks(sig)
         w1 = codec.toks_to_sig(t1)
         debug_set(codec, "rb_stream", 0)
         names = _kernels(codec, lambda: codec.toks_to_sig(codec.sig_to_toks(sig)))
-        assert "rb_fused6_kernel" in names and "rb_stream6_kernel" not in names, names
+        assert "rb_fused6_kernel" in names and "rb_stream6_kernel" not in names and "rb128_fused6_kernel" in names, names
         f0, t0 = codec.sig_to_feats(sig), codec.sig_to_toks(sig)
         w0 = codec.toks_to_sig(t1)
         debug_set(codec, "rb_stream", 1)
