@@ -14,6 +14,9 @@ T = int(round(10.0 * cfg.sampling_rate))
 sig = torch.from_numpy((prng.normal(123, f"bench.sig.{name}", (batch, T)) * 0.1).astype(np.float32)).cuda()
 with torch.no_grad():
     codec.sig_to_toks(sig[:1])
+    if os.environ.get('CHAIN'):
+        from audiocodecs_amd._native import debug_set
+        debug_set(codec, 'chain_stream', int(os.environ['CHAIN']))
     if os.environ.get('RB128'):
         from audiocodecs_amd._native import debug_set
         debug_set(codec, 'rb128_stream', int(os.environ['RB128']))
