@@ -10,8 +10,8 @@
 //     16 bits below the table's largest keep fp32-grade relative precision, split16.h), image
 //         epk16[K][C/16 code tiles][H/32 k-steps][2 planes][64 lanes][8 fp16]
 //   * dist = -((|x|^2 - 2 dot) + |e|^2) with |x|^2 and |e|^2 exact fp32 as before; dot = acc * 2^-(sx + se) is exact scaling.
-// One wave owns 16 MS frames; MS = 3 at the benchmark size: 1000 waves for 1024 SIMDs, 382 registers, and a code tile fetched
-// from L2 (8 KB) feeds 36 MFMAs (the CU's 64 B/clk L1 path is the next bound: 57 B/clk).
+// One wave owns 16 MS frames; MS = 3 at the benchmark size: 1000 waves for 1024 SIMDs, 393 registers, and a code tile fetched
+// from L2 (8 KB) feeds 36 MFMAs; tile t's distances and argmax run beside tile t + 1's MFMAs (round 6, below).
 // The error of a dot product equals that of an fp32 FMA chain (split16.h); the token policy (exact outside fp64 near-ties of
 // 1e-4 relative margin) holds unchanged (tests/test_gpu_parity.py, test_gpu_fullsize.py).
 #pragma once
@@ -114,8 +114,12 @@ __global__ __launch_bounds__(64 * WS) void rvq_encode16_kernel(const RvqEnc16Par
             }
             eev = eek[ct * 16 + li];
         };
-        auto run_tile = [&](int ct, const f16x8 (&bh)[KS], const f16x8 (&bl)[KS], float eev) {
-            f32x4 acc[MS];
+        // a tile = its 12 MS MFMAs (mm_tile) + the distances and the running argmax (pick_tile).  The batch form below runs tile t's pick
+        // BESIDE tile t + 1's MFMAs: two accumulator sets make the two independent pieces of one straight-line block, and the scheduler
+        // interleaves them (~2.5 vector instructions per MFMA).  With one accumulator set a wave alternated 36 MFMAs on three dependent
+        // chains with the 12 distances' compare / select chain, at one wave per SIMD: 0.396 -> 0.339 ms at 64 x 10 s, tokens identical
+        // (tools/experiments/r6r_rvq_pipe.py).
+        auto mm_tile = [&](const f16x8 (&bh)[KS], const f16x8 (&bl)[KS], f32x4 (&acc)[MS]) {
 #pragma unroll
             for (int m = 0; m < MS; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -127,6 +131,8 @@ __global__ __launch_bounds__(64 * WS) void rvq_encode16_kernel(const RvqEnc16Par
 #pragma unroll
                 for (int m = 0; m < MS; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh[m][s], bh[s], acc[m], 0, 0, 0);
             }
+        };
+        auto pick_tile = [&](int ct, const f32x4 (&acc)[MS], float eev) {
             const int code = ct * 16 + li;
 #pragma unroll
             for (int m = 0; m < MS; ++m)
@@ -137,6 +143,11 @@ __global__ __launch_bounds__(64 * WS) void rvq_encode16_kernel(const RvqEnc16Par
                     d = CDIST ? -sqrtf(fmaxf(d, 1e-30f)) : -d;
                     if (d > best[m][r]) { best[m][r] = d; bidx[m][r] = code; }
                 }
+        };
+        auto run_tile = [&](int ct, const f16x8 (&bh)[KS], const f16x8 (&bl)[KS], float eev) {
+            f32x4 acc[MS];
+            mm_tile(bh, bl, acc);
+            pick_tile(ct, acc, eev);
         };
         if constexpr (WS > 1) {            // this wave's share: tiles wv, wv + WS, ... (double-buffered like below)
             f16x8 bh0[KS], bl0[KS], bh1[KS], bl1[KS];
@@ -158,6 +169,22 @@ __global__ __launch_bounds__(64 * WS) void rvq_encode16_kernel(const RvqEnc16Par
                 run_tile(ct + WS, bh1, bl1, ee1);
             }
 #endif
+        } else if constexpr (HV <= 16 && MS > 1 && !K1) {   // the batch form (C % 32 == 0): two tile sets a tile ahead, two accumulator sets (above)
+            f16x8 bh0[KS], bl0[KS], bh1[KS], bl1[KS];
+            float ee0, ee1 = 0.f;
+            f32x4 accA[MS], accB[MS];
+            load_tile(0, bh0, bl0, ee0);
+            load_tile(1, bh1, bl1, ee1);
+            mm_tile(bh0, bl0, accA);
+            for (int ct = 0; ct < ctiles; ct += 2) {
+                const float e0 = ee0, e1 = ee1;
+                load_tile(ct + 2 < ctiles ? ct + 2 : ct, bh0, bl0, ee0);
+                mm_tile(bh1, bl1, accB);
+                pick_tile(ct, accA, e0);
+                load_tile(ct + 3 < ctiles ? ct + 3 : ct + 1, bh1, bl1, ee1);
+                mm_tile(bh0, bl0, accA);                       // (behind the last tile: a repeat of tile ct, never picked)
+                pick_tile(ct + 1, accB, e1);
+            }
         } else if constexpr (HV <= 16 || K1) {    // code tiles double-buffered in registers: tile ct + 1 travels under tile ct's MFMAs
             f16x8 bh0[KS], bl0[KS], bh1[KS], bl1[KS];
             float ee0, ee1 = 0.f;
