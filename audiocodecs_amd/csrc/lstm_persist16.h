@@ -65,6 +65,16 @@ constexpr float LP16_HSCALE = LP16_HEXP ? 2.0f : 1.0f, LP16_HINV = LP16_HEXP ? 0
 #define LP16_BATCH_N 4      // steps of h0 per hand-over to layer 1 (measured: 1: 4.49 ms, 2: 4.39, 4: 4.37, 8: 4.39, 16: 4.43, 32: 4.48 per EnCodec step)
 #endif
 constexpr int LP16_BATCH = LP16_BATCH_N;                        // steps of h0 per hand-over to layer 1
+// Waves 4 .. 7 (LATE, below) request the recurrent operand when this workgroup's gate waves have issued their publish stores (an LDS
+// word per gate wave) + LP16_LATE_SLEEP x 64 clocks.  Measured per EnCodec step (two launches; one box, alternating processes): request in
+// the middle of the projection (rounds 4 - 5) 3.75 ms; at its end + a fixed sleep of 0 / 6 / 12 / 18 / 24 units 3.65 / 3.56 / 3.51 / 3.58 /
+// 3.90; on the flag + 0 / 2 / 4 units 3.50 / 3.54 / 3.58; on a flag posted BEFORE the stores 3.68.
+#ifndef LP16_LATE_FLAG
+#define LP16_LATE_FLAG 1
+#endif
+#ifndef LP16_LATE_SLEEP
+#define LP16_LATE_SLEEP 0
+#endif
 
 // FUSE: compile-time copy of LstmPersist16Params::fuse_in (a run-time branch around the gin loads would make the compiler wait
 // for ALL outstanding memory operations in front of the gate arithmetic)
@@ -76,11 +86,13 @@ __global__ __launch_bounds__(512) void lstm_persist16_kernel(const LstmPersist16
     constexpr long long GROUP_BYTES = LP16_GROUP_BYTES;
     __shared__ float part[2][8][4][16][17];      // [step parity][wave = K eighth][gate][clip][unit]
     __shared__ unsigned s_x, s_slot;
+    __shared__ __attribute__((aligned(16))) unsigned pubflag[4];      // LATE: step + 1 of the last publish of each gate wave
     __shared__ unsigned short hist[LP16_BATCH][2][256];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // uniform for the compiler too (buffer descriptors depend on it)
     const int li = lane & 15, kq = lane >> 4;
     unsigned* tmo = p.ctl + LP_CTL_TIMEOUT;
+    if (tid < 4) pubflag[tid] = 0;
     if (tid == 0) {
         s_x = lp_xcc_id();
         s_slot = __hip_atomic_fetch_add(&p.ctl[LP_CTL_SLOTS + (s_x & 7) * 16], 1u, LP_RLX);
@@ -100,8 +112,31 @@ __global__ __launch_bounds__(512) void lstm_persist16_kernel(const LstmPersist16
     }
     if (AC_DEV_MODE(p.dbg, 1) && (x & 1) == 1) return;
     const int layer_rt = x & 1, idx = slot, u0 = idx * 16;
-    auto body = [&](auto layer_tag) {
+    auto body = [&](auto layer_tag, auto late_tag) {
     constexpr int layer = decltype(layer_tag)::value;
+    // LATE: waves 4 .. 7 hold no gate threads: behind the barrier they go straight into the next step's projection, ~0.5 us BEFORE waves
+    // 0 .. 3 (here and on the 31 peers) have published h[t].  A recurrent request in the middle of that projection always came back
+    // incomplete, the next step began with a fresh polling load for half of the K eighths, and the gate waves waited for them at the
+    // barrier (0.16 us of the 2.24 us step, tools/experiments/r6u_lstm_trace.py).  These waves request at the END of their projection,
+    // behind a short sleep; the gate waves, whose projection follows their own publish, at its START.  Compile-time copies of the body:
+    // a request under a run-time condition becomes a register copy at the join, and the copy waits for the load (project0).
+    constexpr bool LATE = decltype(late_tag)::value;
+    // LATE waves: until this workgroup's four gate waves have issued the publish stores of step t (the peers do so at about the same
+    // time), then LP16_LATE_SLEEP x 64 clocks for the stores to reach the L2.  Bounded: a gate wave that left on a timeout never posts.
+    auto await_publish = [&](int t) {
+#if LP16_LATE_FLAG
+        for (int spins = 0; spins < (1 << 12); ++spins) {
+            const u32x4_t f = *reinterpret_cast<volatile u32x4_t*>(pubflag);
+            const unsigned lo = f.x < f.y ? f.x : f.y, lo2 = f.z < f.w ? f.z : f.w;
+            if ((lo < lo2 ? lo : lo2) > (unsigned)t) break;
+            if ((spins & 63) == 63 && __hip_atomic_load(tmo, LP_RLX)) break;      // the launch is being abandoned
+            __builtin_amdgcn_s_sleep(1);
+        }
+#else
+        (void)t;
+#endif
+        __builtin_amdgcn_s_sleep(LP16_LATE_SLEEP);
+    };
 
     // ---- weights -> registers: [gate][k-step of 32 inside this wave's 64 k][plane].  The packed image is
     // [matrix][32 slices][4 K quarters][4 gates][4 k-steps][2 planes][64 lanes][8]: wave w = quarter w / 2, k-steps 2 (w & 1) ..
@@ -242,13 +277,18 @@ __global__ __launch_bounds__(512) void lstm_persist16_kernel(const LstmPersist16
         for (int n = 0; n < 4; ++n) accP[n] = f32x4{0.f, 0.f, 0.f, 0.f};
         // NO request below sits under a condition: a register that is loaded on one path and carried on the other becomes a
         // copy at the join -- and the copy waits for the load (the loop latch then waited for every request of the step)
+        if constexpr (decltype(rec_tag)::value && !LATE) load_a(hmine, trec, arec);
         mac(a, wb, accP, 0, 1);
-        if constexpr (decltype(rec_tag)::value) load_a(hmine, trec, arec);
         mac(a, wb, accP, 1, 2);
 #pragma unroll
         for (int n = 0; n < 4; ++n)
 #pragma unroll
             for (int r = 0; r < 4; ++r) accP[n][r] *= xcr[r];
+        if constexpr (decltype(rec_tag)::value && LATE) {
+            __builtin_amdgcn_sched_barrier(0);
+            await_publish(trec);
+            load_a(hmine, trec, arec);
+        }
         (void)t;
     };
     auto project = [&](int t) -> bool {                        // layer 1, polling path
@@ -360,6 +400,7 @@ __global__ __launch_bounds__(512) void lstm_persist16_kernel(const LstmPersist16
             __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, hh), rs, hpos, 0, LP_SC0);
             __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, hl), rs, 512 + hpos, 0, LP_SC0);
             LP16_TRC(7);
+            if (lane == 0) pubflag[wave] = (unsigned)t + 1u;    // (LATE waves: await_publish)
             if (layer == 0) {   // the copy layer 1 reads from the neighbouring XCD: kept for the batch store below
                 hist[t % LP16_BATCH][0][tid] = __builtin_bit_cast(unsigned short, hh);
                 hist[t % LP16_BATCH][1][tid] = __builtin_bit_cast(unsigned short, hl);
@@ -385,11 +426,17 @@ __global__ __launch_bounds__(512) void lstm_persist16_kernel(const LstmPersist16
             if (!ap_ok && !load_valid(h0b, t1, ap)) return false;   // layer 0 is steps ahead: normally complete
 #pragma unroll
             for (int n = 0; n < 4; ++n) accP[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (!LATE) load_a(hmine, t, arec);
             mac(ap, wa, accP, 0, 1);
-            load_a(hmine, t, arec);
             // cross-XCD / HBM round trips go BEHIND the recurrent request and have a whole step to arrive
-            skip_next = skip_row[(long long)t1 * D];
+            if constexpr (!LATE) skip_next = skip_row[(long long)t1 * D];
             mac(ap, wa, accP, 1, 2);
+            if constexpr (LATE) {
+                __builtin_amdgcn_sched_barrier(0);
+                await_publish(t);
+                load_a(hmine, t, arec);
+                skip_next = skip_row[(long long)t1 * D];
+            }
             load_a(h0b, t + 2 < p.T ? t + 2 : t1, ap);
         } else if (fuse0) {
             project0(t + 1 < p.T ? t + 1 : t, t, std::true_type{});
@@ -401,8 +448,13 @@ __global__ __launch_bounds__(512) void lstm_persist16_kernel(const LstmPersist16
         if (!step(t)) return;
 #undef LP16_TRC
     };
-    if (layer_rt == 0) body(std::integral_constant<int, 0>{});
-    else body(std::integral_constant<int, 1>{});
+    if (wave < 4) {
+        if (layer_rt == 0) body(std::integral_constant<int, 0>{}, std::false_type{});
+        else body(std::integral_constant<int, 1>{}, std::false_type{});
+    } else {
+        if (layer_rt == 0) body(std::integral_constant<int, 0>{}, std::true_type{});
+        else body(std::integral_constant<int, 1>{}, std::true_type{});
+    }
 }
 
 }  // namespace ac
