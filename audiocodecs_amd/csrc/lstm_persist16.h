@@ -16,9 +16,10 @@
 //     value) are issued right BEHIND the request for the next recurrent operand and have a whole step to arrive; layer 0's x[t+2]
 //     (32 KB per CU and step, as much as the exchange) is requested in FRONT of the barrier and passes under the partial sums and
 //     the gate arithmetic (round 4: behind the recurrent request it shared the path with the peers' h and layer 0 bound the
-//     kernel).  The recurrent request itself is issued in the middle of the projection that follows the publish (the peers
-//     publish at about the same time), so its round trip runs under the projection's MFMAs; when it comes back incomplete, the
-//     step starts with the ordinary polling load.
+//     kernel).  The recurrent request itself is issued in the projection that follows the publish (the peers publish at
+//     about the same time), so its round trip runs under the projection's MFMAs -- by the gate waves (0 .. 3) at the start of their
+//     projection, by waves 4 .. 7, whose projection runs BESIDE the gates, when the gate waves have posted their publish (round 6:
+//     LATE below); when it comes back incomplete, the step starts with the ordinary polling load.
 // h lies in [-1, 1]: it travels as 2 h = hi + lo with |hi| < 2 (bit 14 clear: the exchange's "has arrived" test).  1.0 itself occurs
 // when the gates saturate, and fp16(2.0) has bit 14 set: hi is capped at the largest fp16 below 2, lo takes the rest; the rows of
 // [W_ih | W_hh] of a layer share one power-of-two scale per gate row; the fused layer-0 projection scales x[t] by its clip's amax
