@@ -70,6 +70,9 @@ constexpr int LP16_BATCH = LP16_BATCH_N;                        // steps of h0 p
 // word per gate wave) + LP16_LATE_SLEEP x 64 clocks.  Measured per EnCodec step (two launches; one box, alternating processes): request in
 // the middle of the projection (rounds 4 - 5) 3.75 ms; at its end + a fixed sleep of 0 / 6 / 12 / 18 / 24 units 3.65 / 3.56 / 3.51 / 3.58 /
 // 3.90; on the flag + 0 / 2 / 4 units 3.50 / 3.54 / 3.58; on a flag posted BEFORE the stores 3.68.
+#ifndef LP16_PART_PITCH
+#define LP16_PART_PITCH 16  // 16-byte units per clip row of the partial sums (measured per EnCodec step: 16: 3.35 ms, 17 / 18: 3.37 - 3.38; one float per access: 3.46)
+#endif
 #ifndef LP16_LATE_FLAG
 #define LP16_LATE_FLAG 1
 #endif
@@ -85,7 +88,10 @@ __global__ __launch_bounds__(512) void lstm_persist16_kernel(const LstmPersist16
     constexpr int D = LP_D, NP = 2;
     constexpr int SLICE_BYTES = LP16_SLICE_BYTES;
     constexpr long long GROUP_BYTES = LP16_GROUP_BYTES;
-    __shared__ float part[2][8][4][16][17];      // [step parity][wave = K eighth][gate][clip][unit]
+    // partial sums of the eight K eighths: [step parity][wave][clip][unit (+ pad)] x the FOUR gates of the unit as one 16-byte word -- a lane's
+    // accumulators hold gate n of (clip kq * 4 + r, unit li) in acc[n][r], so a lane writes 4 x 16 bytes and a gate thread reads 8 x 16 bytes
+    // (round 6; one float per access before: 16 writes, 32 reads on the step's critical path)
+    __shared__ f32x4 part[2][8][16][LP16_PART_PITCH];
     __shared__ unsigned s_x, s_slot;
     __shared__ __attribute__((aligned(16))) unsigned pubflag[4];      // LATE: step + 1 of the last publish of each gate wave
     __shared__ unsigned short hist[LP16_BATCH][2][256];
@@ -363,20 +369,20 @@ __global__ __launch_bounds__(512) void lstm_persist16_kernel(const LstmPersist16
         //  step either way -- the stores are acknowledged by the XCD's L2 before the projection's first MFMAs are through)
         if (layer == 1) ap_ok = valid(ap) || AC_DEV_MODE(p.dbg, 4);      // h0[t+1] (requested at the end of the previous step) complete?
         LP16_TRC(2);
-        float (&pt)[8][4][16][17] = part[t & 1];
+        f32x4 (&pt)[8][16][LP16_PART_PITCH] = part[t & 1];
 #pragma unroll
-        for (int n = 0; n < 4; ++n)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) pt[wave][n][kq * 4 + r][li] = acc[n][r];
+        for (int r = 0; r < 4; ++r) pt[wave][kq * 4 + r][li] = f32x4{acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
         lds_barrier();
         LP16_TRC(3);
         float hn = 0.f;
         if (gate_thr) {
             float pre[4];
+            f32x4 pv[8];
+#pragma unroll
+            for (int w = 0; w < 8; ++w) pv[w] = pt[w][ec][ej];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const float sum = ((pt[0][q][ec][ej] + pt[1][q][ec][ej]) + (pt[2][q][ec][ej] + pt[3][q][ec][ej])) +
-                                  ((pt[4][q][ec][ej] + pt[5][q][ec][ej]) + (pt[6][q][ec][ej] + pt[7][q][ec][ej]));
+                const float sum = ((pv[0][q] + pv[1][q]) + (pv[2][q] + pv[3][q])) + ((pv[4][q] + pv[5][q]) + (pv[6][q] + pv[7][q]));
                 pre[q] = __fmaf_rn(sum, wiv[q], gpre[q]);
             }
             const float ig = sigmoid_rcp(pre[0]), fg = sigmoid_rcp(pre[1]), gg = tanh_rcp(pre[2]), og = sigmoid_rcp(pre[3]);
